@@ -1,0 +1,243 @@
+/*
+ * nerfacc_hip.h — C ABI of libnerfacc_hip.so, the MI355X (gfx950) implementation of the
+ * nerfacc OccGrid sampling + volumetric-rendering hot path.
+ *
+ * This is the drop-in boundary.  In the reference the same boundary is the pybind11
+ * module `nerfacc.csrc` (nerfacc/cuda/csrc/nerfacc.cpp:126-163) whose attributes are looked
+ * up lazily by nerfacc/cuda/__init__.py:8-53.  Every entry point below names the reference
+ * function it stands in for.  The reference passes torch::Tensor; here everything is a raw
+ * device pointer + sizes + a stream, so the library has no torch (or Python) dependency and
+ * can be bound from ctypes / cffi / pybind alike (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous arrays unless marked [host];
+ *     float = fp32 values, int64_t = offsets/indices/counts, uint8_t = torch.bool storage;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *     every call only enqueues work on that stream and returns — no call synchronises;
+ *   - nothing is allocated: outputs and scratch are caller-provided (sizes are either
+ *     stated or returned by the matching *_workspace_bytes function);
+ *   - inputs are never written;
+ *   - return value: NFA_OK (0) or an NFA_ERR_* code; nfa_last_error() gives the text of the
+ *     last failure on the calling thread.  Arguments are validated before anything is launched.
+ *   - n == 0 is legal everywhere and enqueues nothing.
+ *   - ray_indices / keys must be grouped by ray (each ray's samples contiguous, as produced
+ *     by traversal); sortedness is not required except where stated.
+ */
+#ifndef NERFACC_HIP_H
+#define NERFACC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFA_OK 0
+#define NFA_ERR_INVALID_ARG 1
+#define NFA_ERR_LAUNCH 2
+#define NFA_ERR_UNSUPPORTED 3
+
+#define NFA_MAX_GRID_LEVELS 8 /* grid.cu:18 */
+
+/* library identification: "nerfacc_hip <version> gfx950" */
+const char *nfa_version(void);
+/* text of the last error raised on this thread ("" if none) */
+const char *nfa_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Grid: ray/AABB test and multi-level occupancy-grid traversal
+ * ------------------------------------------------------------------------------------- */
+
+/* replaces ray_aabb_intersect (nerfacc.cpp:63-69, grid.cu:477-519).
+ * t_mins, t_maxs: [n_rays, n_aabbs] float; hits: [n_rays, n_aabbs] bool. */
+int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays,
+                           const float *aabbs, int64_t n_aabbs, float near_plane, float far_plane,
+                           float miss_value, float *t_mins, float *t_maxs, uint8_t *hits, void *stream);
+
+/* Bit-packed occupancy bricks.  The traversal kernels do not read the 1-byte-per-voxel
+ * `binaries` tensor (occ_grid.py:72-75) directly: it is first packed into 4x4x4 bricks, one
+ * uint64 per brick (bit = (x&3)*16 + (y&3)*4 + (z&3)), bricks x-major like the voxels.
+ * nfa_packed_grid_words: number of uint64 words for [n_grids, rx, ry, rz]. */
+int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t rz);
+int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
+                      uint64_t *bricks, void *stream);
+
+/* Arguments of traverse_grids (nerfacc.cpp:71-98, grid.cu:320-474).  The reference does
+ * count -> cumsum + .item() -> allocate -> fill inside one C++ call; a C ABI cannot allocate
+ * torch tensors, so the two halves are separate calls and the caller allocates in between
+ * from `totals`.  Pointers documented "nullable" may be NULL. */
+typedef struct nfa_traverse_args {
+    /* rays */
+    int64_t n_rays;
+    const float *rays_o;        /* [n_rays, 3] */
+    const float *rays_d;        /* [n_rays, 3] */
+    const uint8_t *rays_mask;   /* [n_rays] nullable: rays with 0 are skipped (grid.cu:100) */
+    /* grids */
+    int32_t n_grids;            /* <= NFA_MAX_GRID_LEVELS */
+    int32_t res[3];
+    const uint64_t *bricks;     /* from nfa_pack_binaries */
+    const float *aabbs;         /* [n_grids, 6] */
+    /* sorted ray/grid intersections (grid.py:156-162).  All three nullable together: when
+     * NULL the kernel runs the slab test and the per-ray sort of the 2*n_grids events itself. */
+    const uint8_t *hits;        /* [n_rays, n_grids] */
+    const float *t_sorted;      /* [n_rays, 2*n_grids] */
+    const int64_t *t_indices;   /* [n_rays, 2*n_grids] */
+    /* options */
+    const float *near_planes;   /* [n_rays] */
+    const float *far_planes;    /* [n_rays] */
+    float step_size;
+    float cone_angle;
+    int32_t traverse_steps_limit; /* <= 0: unlimited */
+    /* per-ray counts / offsets: written by nfa_traverse_count, read by nfa_traverse_fill.
+     * iv_* describe interval edges (RaySegmentsSpec intervals), sm_* samples. iv pair nullable. */
+    int64_t *iv_cnts, *iv_starts; /* [n_rays] */
+    int64_t *sm_cnts, *sm_starts; /* [n_rays] */
+    int64_t *totals;            /* [2] = {n_edges, n_samples}; device-visible (pinned host ok) */
+    /* fill outputs, each nullable (grid.cu:219-255) */
+    float *iv_vals; int64_t *iv_ray_indices; uint8_t *iv_is_left; uint8_t *iv_is_right; /* [n_edges]; masks pre-zeroed */
+    float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;                      /* [n_samples] */
+    float *t_starts; float *t_ends; /* [n_samples]: interval of each sample, written directly
+                                       (what occ_grid.py:174-175 extracts with is_left/is_right) */
+    float *terminate_planes;    /* [n_rays] nullable */
+} nfa_traverse_args;
+
+/* pass 1 (grid.cu:413): per-ray counts, then their exclusive sums and the two totals.
+ * workspace: nfa_traverse_workspace_bytes(n_rays) bytes of device scratch. */
+int64_t nfa_traverse_workspace_bytes(int64_t n_rays);
+int nfa_traverse_count(const nfa_traverse_args *args, void *workspace, void *stream);
+/* pass 2 (grid.cu:445 / the single over-allocated pass :375): write edges / samples at
+ * iv_starts / sm_starts.  `skip_empty`: skip rays whose stored count is 0 (grid.cu:103-106).
+ * `rewrite_counts`: store the actual per-ray counts back (over-allocated mode, grid.cu:277-280). */
+int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t rewrite_counts, void *stream);
+
+/* chunk_starts = cumsum(cnts) - cnts, total -> *total (data_spec.hpp:86-106). total nullable. */
+int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * pack_info (pack.py:10-49): ray_indices [n] (sorted) -> packed_info [n_rays, 2]
+ * ------------------------------------------------------------------------------------- */
+int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, void *stream);
+/* inverse: packed_info -> ray_indices [n]; elements outside every chunk get -1 */
+int nfa_unpack_info(const int64_t *chunk_starts, const int64_t *chunk_cnts, int64_t n_rays,
+                    int64_t *ray_indices, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Segmented scans (scan.cu, scan_cub.cu).  op: 0 sum, 1 product.
+ * ------------------------------------------------------------------------------------- */
+#define NFA_OP_SUM 0
+#define NFA_OP_PROD 1
+
+/* chunked by (chunk_starts, chunk_cnts): inclusive_sum / exclusive_sum /
+ * {inclusive,exclusive}_prod_forward (nerfacc.cpp:17-37, scan.cu:9-126,128-166,215-257).
+ * `reverse` scans each chunk from its last element (= the reference's backward=true).
+ * `normalize` divides by the chunk total (utils_scan.cuh:101-109). */
+int nfa_scan_packed(const int64_t *chunk_starts, const int64_t *chunk_cnts, int64_t n_rays,
+                    const float *inputs, float *outputs, int64_t n,
+                    int32_t op, int32_t inclusive, int32_t reverse, int32_t normalize, void *stream);
+
+/* keyed by ray index: {inclusive,exclusive}_sum_cub, {inclusive,exclusive}_prod_cub_forward
+ * (nerfacc.cpp:40-60, scan_cub.cu:66-182,220-250). */
+int nfa_scan_keyed(const int64_t *keys, const float *inputs, float *outputs, int64_t n,
+                   int32_t op, int32_t inclusive, int32_t reverse, void *stream);
+
+/* {inclusive,exclusive}_prod(_cub)_backward (scan.cu:169-214,259-304; scan_cub.cu:184-218,
+ * 252-287): grad_in = revscan(grad_out * out) / clamp_min(in, 1e-10), fused in one kernel.
+ * Exactly one of (keys) / (chunk_starts, chunk_cnts) is given. */
+int nfa_prod_backward(const int64_t *keys, const int64_t *chunk_starts, const int64_t *chunk_cnts,
+                      int64_t n_rays, const float *inputs, const float *outputs,
+                      const float *grad_outputs, float *grad_inputs, int64_t n, int32_t inclusive,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused volumetric rendering (volrend.py; pure torch + one scan in the reference)
+ * ------------------------------------------------------------------------------------- */
+
+/* render_weight_from_density / render_transmittance_from_density (volrend.py:219-278,326-376):
+ * sd = sigma*(t_end-t_start); alpha = 1-exp(-sd); trans = exp(-excl_sum(sd)) [* prefix_trans];
+ * weight = trans*alpha.  Outputs nullable individually. */
+int nfa_render_weight_from_density_fwd(const int64_t *ray_indices, const float *t_starts,
+                                       const float *t_ends, const float *sigmas,
+                                       const float *prefix_trans /* nullable */, int64_t n,
+                                       float *weights, float *trans, float *alphas, void *stream);
+/* its vector-Jacobian product w.r.t. sigmas; any of g_weights/g_trans/g_alphas nullable.
+ * trans / alphas are the forward outputs. */
+int nfa_render_weight_from_density_bwd(const int64_t *ray_indices, const float *t_starts,
+                                       const float *t_ends, const float *sigmas, const float *trans,
+                                       const float *alphas, const float *g_weights,
+                                       const float *g_trans, const float *g_alphas, int64_t n,
+                                       float *g_sigmas, void *stream);
+
+/* render_visibility_from_density + the three mask compactions of OccGridEstimator.sampling
+ * (occ_grid.py:194-220, volrend.py:435-494) in one go: keep sample i iff
+ * trans_i >= early_stop_eps and (alpha_thre <= 0 or alpha_i >= alpha_thre).
+ * Outputs are compacted into the first *n_out entries of out_* (capacity n each).
+ * workspace: nfa_visibility_workspace_bytes(n) bytes.  n_out: [1], device-visible. */
+int64_t nfa_visibility_workspace_bytes(int64_t n);
+int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                           const float *sigmas /* or alphas when from_alpha */, int32_t from_alpha,
+                           int64_t n, float early_stop_eps, float alpha_thre,
+                           int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends,
+                           uint8_t *out_mask /* [n] nullable */, int64_t *n_out, void *workspace,
+                           void *stream);
+
+/* accumulate_along_rays / accumulate_along_rays_ (volrend.py:497-587):
+ * outputs[r, :] += sum_{i in r} w_i * values[i, :]  (values NULL: D = 1, values = 1). */
+int nfa_accumulate_along_rays(const int64_t *ray_indices, const float *weights,
+                              const float *values /* [n, D] nullable */, int64_t n, int32_t D,
+                              int64_t n_rays, float *outputs /* [n_rays, D] */, void *stream);
+/* VJP: g_weights [n] and/or g_values [n, D] (either nullable) from g_outputs [n_rays, D] */
+int nfa_accumulate_along_rays_bwd(const int64_t *ray_indices, const float *weights,
+                                  const float *values, const float *g_outputs, int64_t n, int32_t D,
+                                  float *g_weights, float *g_values, void *stream);
+
+/* rendering() after rgb_sigma_fn (volrend.py:104-164), one kernel: weights/trans/alphas [n],
+ * colors [n_rays,3], opacities [n_rays,1], depths [n_rays,1] incl. depth normalisation
+ * (expected_depths) and background blend (bkgd [3], nullable).  ray_indices sorted. */
+int nfa_rendering_fwd(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                      const float *sigmas, const float *rgbs /* [n,3] */, int64_t n, int64_t n_rays,
+                      const float *bkgd, int32_t expected_depths, float *weights, float *trans,
+                      float *alphas, float *colors, float *opacities, float *depths, void *stream);
+/* VJP of the above w.r.t. sigmas and rgbs.  g_colors/g_opacities/g_depths per ray,
+ * g_weights/g_trans/g_alphas per sample; all six nullable.  opacities/depths: forward outputs. */
+int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                      const float *sigmas, const float *rgbs, const float *weights,
+                      const float *trans, const float *alphas, const float *opacities,
+                      const float *depths, int64_t n, int64_t n_rays, const float *bkgd,
+                      int32_t expected_depths, const float *g_colors, const float *g_opacities,
+                      const float *g_depths, const float *g_weights, const float *g_trans,
+                      const float *g_alphas, float *g_sigmas, float *g_rgbs, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * pdf (pdf.cu): importance_sampling (int overload, nerfacc.cpp:100-112) and searchsorted
+ * (nerfacc.cpp:114-117).
+ * ------------------------------------------------------------------------------------- */
+/* device view of a RaySegmentsSpec (data_spec.hpp:6-14, data_spec_packed.cuh:10-41):
+ * batched [n_rays, n_edges_per_ray] when chunk_starts == NULL, else flattened [n_edges] with
+ * per-ray (chunk_starts, chunk_cnts) and optional ray_indices. */
+typedef struct nfa_ray_segments {
+    const float *vals;
+    const int64_t *chunk_starts; /* [n_rays] nullable => batched */
+    const int64_t *chunk_cnts;   /* [n_rays] */
+    const int64_t *ray_indices;  /* [n_edges] nullable */
+    int64_t n_edges;             /* total number of values */
+    int64_t n_rays;
+    int64_t n_edges_per_ray;     /* batched only */
+} nfa_ray_segments;
+
+/* Resample every ray to n_intervals intervals by inverting its cdf (pdf.cu:98-241).
+ * Outputs are batched: out_mids [n_rays, n_intervals], out_edges [n_rays, n_intervals+1].
+ * jitter: per-ray offsets in [0,1) (nullable => 0.5, i.e. stratified = false).  The reference
+ * draws one Philox uniform per ray inside the kernel (pdf.cu:138-144); here the caller's
+ * generator produces them, which keeps the library free of RNG state. */
+int nfa_importance_sampling(const nfa_ray_segments *segments, const float *cdfs, int64_t n_intervals,
+                            const float *jitter, float *out_edges, float *out_mids, void *stream);
+/* For every query value find (left, right) with key[left] <= q < key[right] in the same ray's
+ * key edges, clamped to the ray (pdf.cu:245-286).  ids are relative to the ray for a batched
+ * query and absolute positions in key.vals for a flattened one, as in the reference. */
+int nfa_searchsorted(const nfa_ray_segments *query, const nfa_ray_segments *key,
+                     int64_t *ids_left, int64_t *ids_right, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFACC_HIP_H */

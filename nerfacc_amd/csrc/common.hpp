@@ -1,0 +1,173 @@
+// common.hpp — shared host/device helpers for libnerfacc_hip.so (gfx950 / wave64 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/nerfacc_hip.h"
+
+#define NFA_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace nfa {
+
+// ----------------------------------------------------------------------------------------
+// host side: error reporting + launch geometry
+// ----------------------------------------------------------------------------------------
+char *last_error_buffer();  // thread-local, defined in grid.hip
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define NFA_REQUIRE(cond, ...)                                            \
+    do {                                                                  \
+        if (!(cond)) return ::nfa::fail(NFA_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NFA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return NFA_OK;
+}
+
+constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kBlock = 256;         // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kNumCU = 256;         // MI355X
+constexpr int kNumXCD = 8;
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid for a grid-stride elementwise kernel: enough blocks to fill the chip (>= 8 waves/SIMD
+// worth), capped so tiny problems do not launch empty blocks.
+inline unsigned blocks_for(int64_t n_threads_needed) {
+    int64_t b = ceil_div(n_threads_needed, kBlock);
+    const int64_t cap = (int64_t)kNumCU * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ----------------------------------------------------------------------------------------
+// device side: wave64 primitives
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ unsigned long long lanes_le(int lane) {  // bits [0, lane]
+    return (lane >= 63) ? ~0ull : ((2ull << lane) - 1ull);
+}
+__device__ __forceinline__ unsigned long long lanes_lt(int lane) {  // bits [0, lane)
+    return (1ull << lane) - 1ull;
+}
+
+struct OpSum {
+    static __device__ __forceinline__ float identity() { return 0.0f; }
+    static __device__ __forceinline__ float apply(float a, float b) { return a + b; }
+};
+struct OpProd {
+    static __device__ __forceinline__ float identity() { return 1.0f; }
+    static __device__ __forceinline__ float apply(float a, float b) { return a * b; }
+};
+
+// Segmented inclusive scan over the 64 lanes of a wave, forward (towards higher lanes).
+// `dist` = number of lanes between this lane and the first lane of its segment inside this
+// wave-chunk (0 for a segment head).  Hillis-Steele with ds_bpermute shuffles; a lane only
+// accepts a partner that lies inside its own segment.
+template <class Op>
+__device__ __forceinline__ float wave_seg_scan_fwd(float v, int dist) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(v, off, 64);
+        if (dist >= off) v = Op::apply(u, v);
+    }
+    return v;
+}
+// Same, towards lower lanes; `dist` = lanes between this lane and the last lane of its segment.
+template <class Op>
+__device__ __forceinline__ float wave_seg_scan_bwd(float v, int dist) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_down(v, off, 64);
+        if (dist >= off) v = Op::apply(v, u);
+    }
+    return v;
+}
+
+// distance from `lane` back to the closest set bit of `heads` at or below it; if there is
+// none the segment started in an earlier chunk: returns lane (distance to lane 0) and sets
+// `open` (the carry of the previous chunk applies).
+__device__ __forceinline__ int dist_to_head(unsigned long long heads, int lane, bool &open) {
+    const unsigned long long m = heads & lanes_le(lane);
+    open = (m == 0ull);
+    return open ? lane : lane - (63 - __clzll((long long)m));
+}
+// distance from `lane` forward to the closest set bit of `tails` at or above it; none => the
+// segment continues into the next chunk (`open`), distance to lane 63.
+__device__ __forceinline__ int dist_to_tail(unsigned long long tails, int lane, bool &open) {
+    const unsigned long long m = tails & ~lanes_lt(lane);
+    open = (m == 0ull);
+    return open ? 63 - lane : (__ffsll((long long)m) - 1) - lane;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int src) { return __shfl(v, src, 64); }
+
+// ----------------------------------------------------------------------------------------
+// Snapped tiling of a key-grouped array (DESIGN.md "segment-snapped wave tiles").
+//
+// The flat sample array is cut into nominal tiles of `tile` elements, one wave each.  Each
+// wave then moves both of its boundaries forward to the next segment head (first element of
+// a ray), so every ray lies wholly inside one wave's range: no carry ever crosses waves, no
+// inter-workgroup communication, no atomics, bit-reproducible.  A wave whose nominal tile
+// holds no head owns nothing (the ray that covers it belongs to an earlier wave).
+// ----------------------------------------------------------------------------------------
+
+// first position p in [from, limit) with keys[p] != keys[p-1] (position 0 counts as a head);
+// returns `limit` if there is none.  Wave-uniform result; all 64 lanes must call.
+__device__ __forceinline__ int64_t find_head(const int64_t *__restrict__ keys, int64_t from, int64_t limit) {
+    if (from <= 0) return 0 < limit ? 0 : limit;
+    const int lane = lane_id();
+    for (int64_t base = from; base < limit; base += 64) {
+        const int64_t i = base + lane;
+        bool h = false;
+        if (i < limit) h = keys[i] != keys[i - 1];
+        const unsigned long long b = __ballot(h);
+        if (b) return base + (__ffsll((long long)b) - 1);
+    }
+    return limit;
+}
+
+struct TileRange {
+    int64_t begin, end;
+};
+
+// range owned by wave `w` for nominal tile size `tile` over n elements
+__device__ __forceinline__ TileRange snapped_tile(const int64_t *__restrict__ keys, int64_t n, int64_t w, int64_t tile) {
+    TileRange r;
+    const int64_t nb = w * tile;
+    int64_t ne = nb + tile;
+    if (ne > n) ne = n;
+    if (nb >= n) { r.begin = r.end = n; return r; }
+    r.begin = find_head(keys, nb, ne);
+    if (r.begin >= ne) { r.begin = r.end = n; return r; }   // no head in the nominal tile
+    r.end = (ne >= n) ? n : find_head(keys, ne, n);
+    return r;
+}
+
+// nominal tile size: multiples of 64, small enough to give every SIMD of the chip a few waves
+// on mid-size inputs, large enough (<= 2048) to amortise the boundary search on big ones.
+inline int64_t pick_tile(int64_t n) {
+    const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
+    int64_t t = ceil_div(ceil_div(n, target_waves), 64) * 64;
+    if (t < 256) t = 256;
+    if (t > 2048) t = 2048;
+    return t;
+}
+
+}  // namespace nfa

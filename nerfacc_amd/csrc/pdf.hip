@@ -1,0 +1,136 @@
+// pdf.hip — inverse-cdf importance sampling and per-ray searchsorted for gfx950.
+//
+// Replaces nerfacc/cuda/csrc/pdf.cu (importance_sampling_kernel :98-167,
+// compute_intervels_kernel :169-241, searchsorted_kernel :245-286) behind
+// include/nerfacc_hip.h.  One lane per output value; each lane binary-searches its own ray's
+// (<= a few hundred) edges, which sit in L1/L2 after the first touch.  The two reference
+// kernels of importance_sampling are fused into one launch: a lane computes its sample and
+// re-derives its left neighbour's (same cached edges) to form the interval edge between them.
+#include "common.hpp"
+
+namespace nfa {
+namespace {
+
+__device__ __forceinline__ int64_t upper_bound_f(const float *__restrict__ v, int64_t lo, int64_t hi, float x) {
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (!(v[mid] > x)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void ray_span(const nfa_ray_segments &s, int64_t ray, int64_t &base, int64_t &last) {
+    if (s.chunk_starts) { base = s.chunk_starts[ray]; last = base + s.chunk_cnts[ray] - 1; }
+    else { base = ray * s.n_edges_per_ray; last = base + s.n_edges_per_ray - 1; }
+}
+
+// sample `sid` of `n_out` on one ray: pdf.cu:126-165
+__device__ __forceinline__ float draw_sample(const float *__restrict__ vals, const float *__restrict__ cdfs,
+                                             int64_t base, int64_t last, int64_t sid, int64_t n_out, float bias) {
+    const float u0 = cdfs[base], u1 = cdfs[last];
+    const float du = (u1 - u0) / (float)n_out;
+    const float u = u0 + ((float)sid + bias) * du;
+    const int64_t p = upper_bound_f(cdfs, base, last, u);
+    const int64_t p0 = clamp64(p - 1, base, last), p1 = clamp64(p, base, last);
+    const float ul = cdfs[p0], uh = cdfs[p1], tl = vals[p0], th = vals[p1];
+    if (uh - ul < 1e-10f) return (tl + th) * 0.5f;
+    return (u - ul) * ((th - tl) / (uh - ul)) + tl;
+}
+
+__global__ __launch_bounds__(kBlock) void importance_sampling_kernel(
+    nfa_ray_segments seg, const float *__restrict__ cdfs, int64_t n_out, const float *__restrict__ jitter,
+    float *__restrict__ out_edges, float *__restrict__ out_mids)
+{
+    const int64_t total = seg.n_rays * n_out;
+    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * kBlock) {
+        const int64_t ray = tid / n_out, sid = tid - ray * n_out;
+        int64_t base, last;
+        ray_span(seg, ray, base, last);
+        float *edges = out_edges + ray * (n_out + 1);
+        if (last < base) {                       // a ray without edges: nothing to invert
+            out_mids[tid] = 0.0f;
+            edges[sid] = 0.0f;
+            if (sid == n_out - 1) edges[n_out] = 0.0f;
+            continue;
+        }
+        const float bias = jitter ? jitter[ray] : 0.5f;
+        const float t = draw_sample(seg.vals, cdfs, base, last, sid, n_out, bias);
+        out_mids[tid] = t;
+        const float tmin = seg.vals[base], tmax = seg.vals[last];
+        // pdf.cu:207-239: edges are midpoints of neighbouring samples, ends mirrored + clamped
+        if (sid == 0) {
+            const float t_next = (n_out > 1) ? draw_sample(seg.vals, cdfs, base, last, 1, n_out, bias) : t;
+            edges[0] = fmaxf(t - (t_next - t) * 0.5f, tmin);
+            if (n_out == 1) edges[1] = fminf(t, tmax);
+        } else {
+            const float t_prev = draw_sample(seg.vals, cdfs, base, last, sid - 1, n_out, bias);
+            edges[sid] = (t + t_prev) * 0.5f;
+            if (sid == n_out - 1) edges[sid + 1] = fminf(t + (t - t_prev) * 0.5f, tmax);
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t chunk_of(const int64_t *__restrict__ starts, int64_t n_chunks, int64_t item) {
+    int64_t lo = 0, hi = n_chunks;               // pdf.cu:65-80: last chunk with start <= item
+    while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (!(starts[m] > item)) lo = m + 1; else hi = m; }
+    return lo - 1;
+}
+
+__global__ __launch_bounds__(kBlock) void searchsorted_kernel(
+    nfa_ray_segments query, nfa_ray_segments key, int64_t *__restrict__ ids_left, int64_t *__restrict__ ids_right)
+{
+    const bool q_batched = query.chunk_starts == nullptr;
+    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < query.n_edges; tid += (int64_t)gridDim.x * kBlock) {
+        int64_t ray;
+        if (q_batched) ray = tid / query.n_edges_per_ray;
+        else if (query.ray_indices) ray = query.ray_indices[tid];
+        else ray = chunk_of(query.chunk_starts, query.n_rays, tid);
+        int64_t base, last;
+        ray_span(key, ray, base, last);
+        const int64_t p = upper_bound_f(key.vals, base, last, query.vals[tid]);
+        const int64_t l = clamp64(p - 1, base, last), r = clamp64(p, base, last);
+        ids_left[tid] = q_batched ? l - base : l;
+        ids_right[tid] = q_batched ? r - base : r;
+    }
+}
+
+int check_segments(const nfa_ray_segments *s, const char *who) {
+    NFA_REQUIRE(s != nullptr, "%s: segments is NULL", who);
+    NFA_REQUIRE(s->n_rays >= 0 && s->n_edges >= 0, "%s: negative size", who);
+    if (s->n_edges > 0) NFA_REQUIRE(s->vals != nullptr, "%s: vals is NULL", who);
+    if (s->chunk_starts) NFA_REQUIRE(s->chunk_cnts != nullptr, "%s: chunk_starts without chunk_cnts", who);
+    else NFA_REQUIRE(s->n_edges_per_ray >= 0 && s->n_rays * s->n_edges_per_ray == s->n_edges, "%s: batched shape mismatch", who);
+    return NFA_OK;
+}
+
+}  // namespace
+}  // namespace nfa
+
+using namespace nfa;
+
+NFA_EXPORT int nfa_importance_sampling(const nfa_ray_segments *segments, const float *cdfs, int64_t n_intervals,
+                                       const float *jitter, float *out_edges, float *out_mids, void *stream)
+{
+    if (int rc = check_segments(segments, "importance_sampling")) return rc;
+    NFA_REQUIRE(n_intervals >= 0, "importance_sampling: n_intervals < 0");
+    if (segments->n_rays == 0 || n_intervals == 0) return NFA_OK;
+    NFA_REQUIRE(cdfs && out_edges && out_mids, "importance_sampling: NULL pointer");
+    hipLaunchKernelGGL(importance_sampling_kernel, dim3(blocks_for(segments->n_rays * n_intervals)), dim3(kBlock), 0,
+                       (hipStream_t)stream, *segments, cdfs, n_intervals, jitter, out_edges, out_mids);
+    return check_launch("importance_sampling_kernel");
+}
+
+NFA_EXPORT int nfa_searchsorted(const nfa_ray_segments *query, const nfa_ray_segments *key,
+                                int64_t *ids_left, int64_t *ids_right, void *stream)
+{
+    if (int rc = check_segments(query, "searchsorted(query)")) return rc;
+    if (int rc = check_segments(key, "searchsorted(key)")) return rc;
+    if (query->n_edges == 0) return NFA_OK;
+    NFA_REQUIRE(ids_left && ids_right, "searchsorted: NULL output");
+    NFA_REQUIRE(key->n_edges > 0, "searchsorted: empty key");
+    hipLaunchKernelGGL(searchsorted_kernel, dim3(blocks_for(query->n_edges)), dim3(kBlock), 0, (hipStream_t)stream,
+                       *query, *key, ids_left, ids_right);
+    return check_launch("searchsorted_kernel");
+}

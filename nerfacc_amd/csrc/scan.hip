@@ -1,0 +1,223 @@
+// scan.hip — per-ray (segmented) inclusive/exclusive sum and product scans for gfx950.
+//
+// Replaces nerfacc/cuda/csrc/scan.cu + include/utils_scan.cuh (chunked by packed_info) and
+// scan_cub.cu (keyed by ray index, cub::DeviceScan::*ByKey) behind include/nerfacc_hip.h.
+//
+// MI355X mapping
+//   keyed:   segment-snapped wave tiles (common.hpp): each wave owns a range of whole rays,
+//            walks it in 64-element chunks, ballot()s the segment heads, runs a 6-step
+//            segmented shuffle scan and carries one register across chunks.  Single pass,
+//            8+4 bytes read and 4 written per element, no LDS, no atomics, no inter-workgroup
+//            traffic, results independent of scheduling.
+//   chunked: a row (ray) per 16-lane quarter wave — arbitrary (start,count) rows, as the
+//            reference allows — four rows per wave, 16-wide shuffle scans with a carry.
+#include "common.hpp"
+
+namespace nfa {
+namespace {
+
+// ----------------------------------------------------------------------------------------
+// keyed
+// ----------------------------------------------------------------------------------------
+// Optional fusions for the product backward (scan.cu:199-210): v = in * mul before the scan,
+// result / max(div, 1e-10) after it.
+template <class Op, bool INCL, bool REV>
+__global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
+    const int64_t *__restrict__ keys, const float *__restrict__ in, const float *__restrict__ mul,
+    const float *__restrict__ div, float *__restrict__ out, int64_t n, int64_t tile)
+{
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const TileRange tr = snapped_tile(keys, n, w, tile);
+    if (tr.begin >= tr.end) return;
+    const int lane = lane_id();
+    const float ident = Op::identity();
+    float carry = ident;
+    int64_t edge_key = 0;          // key just outside the current chunk on the incoming side
+    const int64_t len = tr.end - tr.begin;
+    const int64_t n_chunks = (len + 63) >> 6;
+
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t pos = tr.begin + (REV ? (n_chunks - 1 - c) : c) * 64;
+        const int64_t i = pos + lane;
+        const bool active = i < tr.end;
+        int64_t key = 0;
+        float v = ident;
+        if (active) {
+            key = keys[i];
+            v = in[i];
+            if (mul) v *= mul[i];
+        }
+        float incl, excl;
+        if (!REV) {
+            int64_t pk = __shfl_up(key, 1, 64);
+            bool head = !active || key != pk;
+            if (lane == 0) head = (c == 0) || key != edge_key;
+            const unsigned long long heads = __ballot(head);
+            bool open;
+            const int dist = dist_to_head(heads, lane, open);
+            incl = wave_seg_scan_fwd<Op>(v, dist);
+            if (open) incl = Op::apply(carry, incl);
+            excl = __shfl_up(incl, 1, 64);
+            if (head) excl = ident;
+            else if (lane == 0) excl = carry;
+            carry = readlane_f(incl, 63);
+            edge_key = __shfl(key, 63, 64);
+        } else {
+            int64_t nk = __shfl_down(key, 1, 64);
+            bool tail = !active || (i + 1 >= tr.end) || key != nk;
+            if (lane == 63 && active && i + 1 < tr.end) tail = key != edge_key;
+            const unsigned long long tails = __ballot(tail);
+            bool open;
+            const int dist = dist_to_tail(tails, lane, open);
+            incl = wave_seg_scan_bwd<Op>(v, dist);
+            if (open) incl = Op::apply(incl, carry);
+            excl = __shfl_down(incl, 1, 64);
+            if (tail) excl = ident;
+            else if (lane == 63) excl = carry;
+            carry = readlane_f(incl, 0);
+            edge_key = __shfl(key, 0, 64);
+        }
+        if (active) {
+            float r = INCL ? incl : excl;
+            if (div) r = r / fmaxf(div[i], 1e-10f);
+            out[i] = r;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// chunked by (start, count): 16 lanes per row
+// ----------------------------------------------------------------------------------------
+template <class Op, bool INCL>
+__global__ __launch_bounds__(kBlock) void scan_packed_kernel(
+    const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts, int64_t n_rows,
+    const float *__restrict__ in, const float *__restrict__ mul, const float *__restrict__ div,
+    float *__restrict__ out, int reverse, int normalize)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t rows_per_block = kBlock / 16;
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < n_rows;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        const int64_t start = starts[row], cnt = cnts[row];
+        if (cnt <= 0) continue;
+        float carry = Op::identity();
+        for (int64_t c = 0; c < cnt; c += 16) {
+            const int64_t k = c + sub;
+            const bool active = k < cnt;
+            const int64_t i = reverse ? (start + cnt - 1 - k) : (start + k);
+            float v = Op::identity();
+            if (active) { v = in[i]; if (mul) v *= mul[i]; }
+            float incl = v;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float u = __shfl_up(incl, off, 16);
+                if (sub >= off) incl = Op::apply(u, incl);
+            }
+            incl = Op::apply(carry, incl);
+            float excl = __shfl_up(incl, 1, 16);
+            if (sub == 0) excl = carry;
+            carry = __shfl(incl, 15, 16);
+            if (active) {
+                float r = INCL ? incl : excl;
+                if (div) r = r / fmaxf(div[i], 1e-10f);
+                out[i] = r;
+            }
+        }
+        if (normalize) {  // utils_scan.cuh:101-109 / 228-236: divide by the row total
+            const float den = fmaxf(carry, 1e-10f);
+            for (int64_t c = 0; c < cnt; c += 16) {
+                const int64_t k = c + sub;
+                if (k >= cnt) continue;
+                if (!INCL && k == 0) continue;
+                const int64_t i = reverse ? (start + cnt - 1 - k) : (start + k);
+                out[i] = out[i] / den;
+            }
+        }
+    }
+}
+
+template <class Op, bool INCL>
+void launch_keyed(const int64_t *keys, const float *in, const float *mul, const float *div, float *out,
+                  int64_t n, bool reverse, hipStream_t s) {
+    const int64_t tile = pick_tile(n);
+    const int64_t waves = ceil_div(n, tile);
+    const unsigned nb = (unsigned)ceil_div(waves, kWavesPerBlock);
+    if (reverse)
+        hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, true>), dim3(nb), dim3(kBlock), 0, s, keys, in, mul, div, out, n, tile);
+    else
+        hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, false>), dim3(nb), dim3(kBlock), 0, s, keys, in, mul, div, out, n, tile);
+}
+
+template <class Op, bool INCL>
+void launch_packed(const int64_t *starts, const int64_t *cnts, int64_t n_rows, const float *in,
+                   const float *mul, const float *div, float *out, int reverse, int normalize, hipStream_t s) {
+    const unsigned nb = blocks_for(n_rows * 16);
+    hipLaunchKernelGGL((scan_packed_kernel<Op, INCL>), dim3(nb), dim3(kBlock), 0, s, starts, cnts, n_rows, in, mul, div, out,
+                       reverse, normalize);
+}
+
+}  // namespace
+}  // namespace nfa
+
+using namespace nfa;
+
+NFA_EXPORT int nfa_scan_keyed(const int64_t *keys, const float *inputs, float *outputs, int64_t n,
+                              int32_t op, int32_t inclusive, int32_t reverse, void *stream)
+{
+    NFA_REQUIRE(n >= 0, "scan_keyed: n < 0");
+    NFA_REQUIRE(op == NFA_OP_SUM || op == NFA_OP_PROD, "scan_keyed: bad op %d", op);
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(keys && inputs && outputs, "scan_keyed: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (op == NFA_OP_SUM) {
+        if (inclusive) launch_keyed<OpSum, true>(keys, inputs, nullptr, nullptr, outputs, n, reverse, s);
+        else launch_keyed<OpSum, false>(keys, inputs, nullptr, nullptr, outputs, n, reverse, s);
+    } else {
+        if (inclusive) launch_keyed<OpProd, true>(keys, inputs, nullptr, nullptr, outputs, n, reverse, s);
+        else launch_keyed<OpProd, false>(keys, inputs, nullptr, nullptr, outputs, n, reverse, s);
+    }
+    return check_launch("scan_keyed_kernel");
+}
+
+NFA_EXPORT int nfa_scan_packed(const int64_t *chunk_starts, const int64_t *chunk_cnts, int64_t n_rays,
+                               const float *inputs, float *outputs, int64_t n,
+                               int32_t op, int32_t inclusive, int32_t reverse, int32_t normalize, void *stream)
+{
+    NFA_REQUIRE(n >= 0 && n_rays >= 0, "scan_packed: negative size");
+    NFA_REQUIRE(op == NFA_OP_SUM || op == NFA_OP_PROD, "scan_packed: bad op %d", op);
+    NFA_REQUIRE(!(normalize && op == NFA_OP_PROD), "scan_packed: normalize is only defined for sums");
+    NFA_REQUIRE(!(normalize && reverse), "scan_packed: backward does not support normalize (scan.cu:25-26)");
+    if (n == 0 || n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(chunk_starts && chunk_cnts && inputs && outputs, "scan_packed: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (op == NFA_OP_SUM) {
+        if (inclusive) launch_packed<OpSum, true>(chunk_starts, chunk_cnts, n_rays, inputs, nullptr, nullptr, outputs, reverse, normalize, s);
+        else launch_packed<OpSum, false>(chunk_starts, chunk_cnts, n_rays, inputs, nullptr, nullptr, outputs, reverse, normalize, s);
+    } else {
+        if (inclusive) launch_packed<OpProd, true>(chunk_starts, chunk_cnts, n_rays, inputs, nullptr, nullptr, outputs, reverse, 0, s);
+        else launch_packed<OpProd, false>(chunk_starts, chunk_cnts, n_rays, inputs, nullptr, nullptr, outputs, reverse, 0, s);
+    }
+    return check_launch("scan_packed_kernel");
+}
+
+NFA_EXPORT int nfa_prod_backward(const int64_t *keys, const int64_t *chunk_starts, const int64_t *chunk_cnts,
+                                 int64_t n_rays, const float *inputs, const float *outputs,
+                                 const float *grad_outputs, float *grad_inputs, int64_t n, int32_t inclusive,
+                                 void *stream)
+{
+    NFA_REQUIRE(n >= 0, "prod_backward: n < 0");
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(inputs && outputs && grad_outputs && grad_inputs, "prod_backward: NULL pointer");
+    NFA_REQUIRE((keys != nullptr) != (chunk_starts != nullptr && chunk_cnts != nullptr),
+                "prod_backward: give either keys or (chunk_starts, chunk_cnts)");
+    hipStream_t s = (hipStream_t)stream;
+    if (keys) {
+        if (inclusive) launch_keyed<OpSum, true>(keys, grad_outputs, outputs, inputs, grad_inputs, n, true, s);
+        else launch_keyed<OpSum, false>(keys, grad_outputs, outputs, inputs, grad_inputs, n, true, s);
+    } else {
+        if (n_rays == 0) return NFA_OK;
+        if (inclusive) launch_packed<OpSum, true>(chunk_starts, chunk_cnts, n_rays, grad_outputs, outputs, inputs, grad_inputs, 1, 0, s);
+        else launch_packed<OpSum, false>(chunk_starts, chunk_cnts, n_rays, grad_outputs, outputs, inputs, grad_inputs, 1, 0, s);
+    }
+    return check_launch("prod_backward");
+}

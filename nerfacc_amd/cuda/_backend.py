@@ -1,0 +1,675 @@
+"""ctypes binding of libnerfacc_hip.so — the module object that plays the role of the
+reference's compiled extension ``nerfacc.csrc`` / ``nerfacc_cuda``
+(nerfacc/cuda/_backend.py:51-86, nerfacc/cuda/csrc/nerfacc.cpp:126-163).
+
+``_C`` exposes the same 21 names with the same argument order and meaning as the pybind
+module, taking torch tensors; under each name it validates like the reference's CHECK_INPUT
+(device + contiguity, utils_cuda.cuh:12-17), allocates the outputs from the torch caching
+allocator and enqueues the HIP kernels on the current torch stream through the C ABI
+declared in include/nerfacc_hip.h.  PyTorch is plumbing here (memory, streams); all
+arithmetic is in the shared library.
+
+There is deliberately NO fallback: if the library is missing or a tensor is not on a HIP
+device the call raises.  Build with ``python -m nerfacc_amd.build`` (hipcc, a few seconds).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import weakref
+from ctypes import c_float, c_int32, c_int64, c_void_p
+from typing import List, Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libnerfacc_hip.so")
+
+NFA_OP_SUM, NFA_OP_PROD = 0, 1
+
+
+class _TraverseArgs(ctypes.Structure):
+    """struct nfa_traverse_args (include/nerfacc_hip.h)."""
+
+    _fields_ = [
+        ("n_rays", c_int64), ("rays_o", c_void_p), ("rays_d", c_void_p), ("rays_mask", c_void_p),
+        ("n_grids", c_int32), ("res", c_int32 * 3), ("bricks", c_void_p), ("aabbs", c_void_p),
+        ("hits", c_void_p), ("t_sorted", c_void_p), ("t_indices", c_void_p),
+        ("near_planes", c_void_p), ("far_planes", c_void_p),
+        ("step_size", c_float), ("cone_angle", c_float), ("traverse_steps_limit", c_int32),
+        ("iv_cnts", c_void_p), ("iv_starts", c_void_p), ("sm_cnts", c_void_p), ("sm_starts", c_void_p),
+        ("totals", c_void_p),
+        ("iv_vals", c_void_p), ("iv_ray_indices", c_void_p), ("iv_is_left", c_void_p), ("iv_is_right", c_void_p),
+        ("sm_vals", c_void_p), ("sm_ray_indices", c_void_p), ("sm_is_valid", c_void_p),
+        ("t_starts", c_void_p), ("t_ends", c_void_p), ("terminate_planes", c_void_p),
+    ]
+
+
+class _RaySegments(ctypes.Structure):
+    """struct nfa_ray_segments (include/nerfacc_hip.h)."""
+
+    _fields_ = [
+        ("vals", c_void_p), ("chunk_starts", c_void_p), ("chunk_cnts", c_void_p), ("ray_indices", c_void_p),
+        ("n_edges", c_int64), ("n_rays", c_int64), ("n_edges_per_ray", c_int64),
+    ]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "nfa_version": (ctypes.c_char_p, []),
+    "nfa_last_error": (ctypes.c_char_p, []),
+    "nfa_ray_aabb_intersect": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "nfa_packed_grid_words": (c_int64, [c_int32] * 4),
+    "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
+    "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
+    "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P]),
+    "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
+    "nfa_pack_info": (ctypes.c_int, [_P, c_int64, c_int64, _P, _P]),
+    "nfa_unpack_info": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, _P]),
+    "nfa_scan_packed": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
+    "nfa_scan_keyed": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    "nfa_prod_backward": (ctypes.c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P]),
+    "nfa_render_weight_from_density_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "nfa_render_weight_from_density_bwd": (ctypes.c_int, [_P] * 9 + [c_int64, _P, _P]),
+    "nfa_visibility_workspace_bytes": (c_int64, [c_int64]),
+    "nfa_visibility_compact": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "nfa_accumulate_along_rays": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P]),
+    "nfa_accumulate_along_rays_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "nfa_rendering_fwd": (ctypes.c_int, [_P] * 5 + [c_int64, c_int64, _P, c_int32] + [_P] * 7),
+    "nfa_rendering_bwd": (ctypes.c_int, [_P] * 10 + [c_int64, c_int64, _P, c_int32] + [_P] * 9),
+    "nfa_importance_sampling": (ctypes.c_int, [ctypes.POINTER(_RaySegments), _P, c_int64, _P, _P, _P, _P]),
+    "nfa_searchsorted": (ctypes.c_int, [ctypes.POINTER(_RaySegments), ctypes.POINTER(_RaySegments), _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the C-ABI library and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"nerfacc_amd: {LIB_PATH} not found. Build the HIP library first: "
+                "`python -m nerfacc_amd.build` (needs hipcc; there is no CPU fallback)."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError => the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("nerfacc_amd: " + load_library().nfa_last_error().decode())
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(ref: torch.Tensor):
+    return torch.cuda.current_stream(ref.device).cuda_stream
+
+
+def _check_input(t: torch.Tensor, name: str, dtype=None) -> None:
+    # CHECK_INPUT of the reference (utils_cuda.cuh:12-17) + the dtype the kernels hard-code
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (nerfacc_amd has no CPU kernels)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+
+
+class _Guard:
+    """OptionalCUDAGuard(device_of(t)) of the reference (utils_cuda.cuh:23-24)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, t: torch.Tensor):
+        self.ctx = None
+        if t.device.index is not None and t.device.index != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+class RaySegmentsSpec:
+    """Mirror of the pybind class RaySegmentsSpec (nerfacc.cpp:128-137, data_spec.hpp:6-14):
+    seven optional tensors with default construction and read/write attributes."""
+
+    __slots__ = ("vals", "is_left", "is_right", "is_valid", "chunk_starts", "chunk_cnts", "ray_indices")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+    def check(self) -> None:  # data_spec.hpp:15-51
+        _check_input(self.vals, "vals", torch.float32)
+        if self.vals.dim() > 1:
+            return
+        for k in ("chunk_starts", "chunk_cnts"):
+            v = getattr(self, k)
+            if v is None:
+                raise RuntimeError(f"flattened RaySegmentsSpec needs {k}")
+            _check_input(v, k, torch.int64)
+            if v.dim() != 1:
+                raise RuntimeError(f"{k} must be 1-D")
+        if self.chunk_starts.numel() != self.chunk_cnts.numel():
+            raise RuntimeError("chunk_starts and chunk_cnts differ in length")
+        for k, dt in (("ray_indices", torch.int64), ("is_left", torch.bool), ("is_right", torch.bool), ("is_valid", torch.bool)):
+            v = getattr(self, k)
+            if v is not None:
+                _check_input(v, k, dt)
+                if v.dim() != 1 or v.numel() != self.vals.numel():
+                    raise RuntimeError(f"{k} must be 1-D with as many elements as vals")
+
+    def _view(self) -> _RaySegments:
+        s = _RaySegments()
+        s.vals = _ptr(self.vals)
+        s.n_edges = self.vals.numel()
+        if self.vals.dim() > 1:
+            s.n_edges_per_ray = self.vals.shape[-1]
+            s.n_rays = self.vals.numel() // max(self.vals.shape[-1], 1)
+        else:
+            s.chunk_starts = _ptr(self.chunk_starts)
+            s.chunk_cnts = _ptr(self.chunk_cnts)
+            s.ray_indices = _ptr(self.ray_indices)
+            s.n_rays = self.chunk_cnts.numel()
+        return s
+
+
+# --------------------------------------------------------------------------------------
+# occupancy bricks: packed once per distinct `binaries` tensor state
+# --------------------------------------------------------------------------------------
+_brick_cache = {"ref": None, "version": None, "bricks": None}
+
+
+def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
+    """bool [G, rx, ry, rz] -> uint64-as-int64 bricks (nfa_pack_binaries), memoised on the
+    tensor object + its in-place version counter so that a grid that has not changed since
+    the last call is not repacked (OccGridEstimator changes it every 16 steps)."""
+    _check_input(binaries, "binaries", torch.bool)
+    if binaries.dim() != 4:
+        raise RuntimeError("binaries must have shape [n_grids, resx, resy, resz]")
+    c = _brick_cache
+    if c["ref"] is not None and c["ref"]() is binaries and c["version"] == binaries._version:
+        return c["bricks"]
+    L = load_library()
+    G, rx, ry, rz = binaries.shape
+    words = L.nfa_packed_grid_words(G, rx, ry, rz)
+    bricks = torch.empty(words, dtype=torch.int64, device=binaries.device)
+    with _Guard(binaries):
+        _check(L.nfa_pack_binaries(_ptr(binaries), G, rx, ry, rz, _ptr(bricks), _stream(binaries)))
+    c["ref"], c["version"], c["bricks"] = weakref.ref(binaries), binaries._version, bricks
+    return bricks
+
+
+def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits,
+                   near_planes, far_planes, step_size, cone_angle, limit) -> _TraverseArgs:
+    _check_input(rays_o, "rays_o", torch.float32)
+    _check_input(rays_d, "rays_d", torch.float32)
+    _check_input(aabbs, "aabbs", torch.float32)
+    _check_input(near_planes, "near_planes", torch.float32)
+    _check_input(far_planes, "far_planes", torch.float32)
+    n_rays = rays_o.shape[0]
+    G = binaries.shape[0]
+    if rays_o.shape != (n_rays, 3) or rays_d.shape != (n_rays, 3):
+        raise RuntimeError("rays_o / rays_d must have shape [n_rays, 3]")
+    if aabbs.shape != (G, 6):
+        raise RuntimeError("aabbs must have shape [n_grids, 6]")
+    if near_planes.numel() != n_rays or far_planes.numel() != n_rays:
+        raise RuntimeError("near_planes / far_planes must have n_rays elements")
+    a = _TraverseArgs()
+    a.n_rays = n_rays
+    a.rays_o, a.rays_d = _ptr(rays_o), _ptr(rays_d)
+    if rays_mask is not None:
+        _check_input(rays_mask, "rays_mask", torch.bool)
+        a.rays_mask = _ptr(rays_mask)
+    a.n_grids = G
+    a.res[0], a.res[1], a.res[2] = binaries.shape[1], binaries.shape[2], binaries.shape[3]
+    a.bricks = _ptr(packed_bricks(binaries))
+    a.aabbs = _ptr(aabbs)
+    if t_sorted is not None:
+        _check_input(t_sorted, "t_sorted", torch.float32)
+        _check_input(t_indices, "t_indices", torch.int64)
+        _check_input(hits, "hits", torch.bool)
+        if t_sorted.shape != (n_rays, 2 * G) or t_indices.shape != (n_rays, 2 * G) or hits.shape != (n_rays, G):
+            raise RuntimeError("t_sorted/t_indices must be [n_rays, 2*n_grids], hits [n_rays, n_grids]")
+        a.t_sorted, a.t_indices, a.hits = _ptr(t_sorted), _ptr(t_indices), _ptr(hits)
+    a.near_planes, a.far_planes = _ptr(near_planes), _ptr(far_planes)
+    a.step_size, a.cone_angle, a.traverse_steps_limit = step_size, cone_angle, limit
+    return a
+
+
+class _C:
+    """Namespace with the names of the reference's compiled module."""
+
+    RaySegmentsSpec = RaySegmentsSpec
+
+    # ---------------------------------------------------------------- misc
+    @staticmethod
+    def is_cub_available() -> bool:
+        # scan-by-key is implemented natively (scan.hip), so the keyed path is always there
+        # (reference: scan_cub.cu:58-64 returns whether CUB >= 1.15 was compiled in)
+        load_library()
+        return True
+
+    # ---------------------------------------------------------------- grid
+    @staticmethod
+    def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane: float, far_plane: float, miss_value: float):
+        """nerfacc.cpp:63-69 -> [t_mins, t_maxs, hits], each [n_rays, n_aabbs]."""
+        for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (aabbs, "aabbs")):
+            _check_input(t, n, torch.float32)
+        R, G = rays_o.shape[0], aabbs.shape[0]
+        t_mins = torch.empty((R, G), dtype=torch.float32, device=rays_o.device)
+        t_maxs = torch.empty_like(t_mins)
+        hits = torch.empty((R, G), dtype=torch.bool, device=rays_o.device)
+        with _Guard(rays_o):
+            _check(load_library().nfa_ray_aabb_intersect(
+                _ptr(rays_o), _ptr(rays_d), R, _ptr(aabbs), G, near_plane, far_plane, miss_value,
+                _ptr(t_mins), _ptr(t_maxs), _ptr(hits), _stream(rays_o)))
+        return [t_mins, t_maxs, hits]
+
+    @staticmethod
+    def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits,
+                       near_planes, far_planes, step_size: float, cone_angle: float,
+                       compute_intervals: bool, compute_samples: bool, compute_terminate_planes: bool,
+                       traverse_steps_limit: int, over_allocate: bool):
+        """nerfacc.cpp:71-98 / grid.cu:320-474: returns (intervals, samples, terminate_planes).
+
+        Two-pass mode: count -> offsets (device) -> ONE 16-byte readback -> allocate -> fill.
+        As in the reference the two-pass mode ignores rays_mask (grid.cu:418,450)."""
+        if over_allocate and traverse_steps_limit <= 0:
+            raise RuntimeError("traverse_steps_limit must be > 0 when over_allocate is true")  # grid.cu:345
+        L = load_library()
+        _check_input(rays_o, "rays_o", torch.float32)
+        dev = rays_o.device
+        R = rays_o.shape[0]
+        i64 = dict(dtype=torch.int64, device=dev)
+        intervals, samples = RaySegmentsSpec(), RaySegmentsSpec()
+        terminate = torch.empty((R,), dtype=torch.float32, device=dev) if compute_terminate_planes else None
+        with _Guard(rays_o):
+            stream = _stream(rays_o)
+            a = _traverse_args(rays_o, rays_d, rays_mask if over_allocate else None, binaries, aabbs,
+                               t_sorted, t_indices, hits, near_planes, far_planes, step_size, cone_angle,
+                               int(traverse_steps_limit))
+            if over_allocate:
+                # grid.cu:364-404: fixed-size slots, single pass, then starts from actual counts
+                maskl = rays_mask.to(torch.int64)
+                iv_cnts = maskl * (2 * traverse_steps_limit)
+                sm_cnts = maskl * traverse_steps_limit
+                iv_starts, sm_starts = torch.empty_like(iv_cnts), torch.empty_like(sm_cnts)
+                totals = torch.empty(2, **i64)
+                _check(L.nfa_exclusive_sum_i64(_ptr(iv_cnts), R, _ptr(iv_starts), totals.data_ptr(), stream))
+                _check(L.nfa_exclusive_sum_i64(_ptr(sm_cnts), R, _ptr(sm_starts), totals.data_ptr() + 8, stream))
+                n_edges, n_samples = totals.tolist()
+            else:
+                iv_cnts = torch.empty(R, **i64) if compute_intervals else None
+                iv_starts = torch.empty(R, **i64) if compute_intervals else None
+                sm_cnts, sm_starts = torch.empty(R, **i64), torch.empty(R, **i64)
+                totals = torch.empty(2, **i64)
+                ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
+                a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
+                a.sm_cnts, a.sm_starts, a.totals = _ptr(sm_cnts), _ptr(sm_starts), _ptr(totals)
+                _check(L.nfa_traverse_count(ctypes.byref(a), _ptr(ws), stream))
+                n_edges, n_samples = totals.tolist()   # the one host sync (data_spec.hpp:91)
+            a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
+            a.sm_cnts, a.sm_starts = _ptr(sm_cnts), _ptr(sm_starts)
+            if compute_intervals:
+                alloc = torch.zeros if over_allocate else torch.empty
+                intervals.vals = alloc(n_edges, dtype=torch.float32, device=dev)
+                intervals.ray_indices = alloc(n_edges, **i64)
+                flags = torch.zeros((2, n_edges), dtype=torch.bool, device=dev)
+                intervals.is_left, intervals.is_right = flags[0], flags[1]
+                a.iv_vals, a.iv_ray_indices = _ptr(intervals.vals), _ptr(intervals.ray_indices)
+                a.iv_is_left, a.iv_is_right = _ptr(intervals.is_left), _ptr(intervals.is_right)
+            if compute_samples:
+                alloc = torch.zeros if over_allocate else torch.empty
+                samples.vals = alloc(n_samples, dtype=torch.float32, device=dev)
+                samples.ray_indices = alloc(n_samples, **i64)
+                samples.is_valid = (torch.zeros if over_allocate else torch.empty)(n_samples, dtype=torch.bool, device=dev)
+                a.sm_vals, a.sm_ray_indices, a.sm_is_valid = _ptr(samples.vals), _ptr(samples.ray_indices), _ptr(samples.is_valid)
+            a.terminate_planes = _ptr(terminate)
+            if R > 0 and (compute_intervals or compute_samples or compute_terminate_planes):
+                _check(L.nfa_traverse_fill(ctypes.byref(a), 0 if over_allocate else 1, 1 if over_allocate else 0, stream))
+            if over_allocate:
+                _check(L.nfa_exclusive_sum_i64(_ptr(iv_cnts), R, _ptr(iv_starts), None, stream))
+                _check(L.nfa_exclusive_sum_i64(_ptr(sm_cnts), R, _ptr(sm_starts), None, stream))
+        if compute_intervals:
+            intervals.chunk_cnts, intervals.chunk_starts = iv_cnts, iv_starts
+        if compute_samples:
+            samples.chunk_cnts, samples.chunk_starts = sm_cnts, sm_starts
+        return intervals, samples, terminate
+
+    # ---------------------------------------------------------------- scans
+    @staticmethod
+    def _packed(chunk_starts, chunk_cnts, inputs, op, inclusive, reverse, normalize):
+        _check_input(chunk_starts, "chunk_starts", torch.int64)
+        _check_input(chunk_cnts, "chunk_cnts", torch.int64)
+        _check_input(inputs, "inputs", torch.float32)
+        if chunk_starts.dim() != 1 or chunk_cnts.dim() != 1 or inputs.dim() != 1:
+            raise RuntimeError("chunk_starts, chunk_cnts and inputs must be 1-D")
+        if chunk_starts.shape[0] != chunk_cnts.shape[0]:
+            raise RuntimeError("chunk_starts and chunk_cnts differ in length")
+        out = torch.empty_like(inputs)
+        with _Guard(inputs):
+            _check(load_library().nfa_scan_packed(_ptr(chunk_starts), _ptr(chunk_cnts), chunk_cnts.shape[0], _ptr(inputs),
+                                                  _ptr(out), inputs.shape[0], op, int(inclusive), int(reverse),
+                                                  int(normalize), _stream(inputs)))
+        return out
+
+    @staticmethod
+    def _keyed(indices, inputs, op, inclusive, reverse):
+        _check_input(indices, "indices", torch.int64)
+        _check_input(inputs, "inputs", torch.float32)
+        if indices.dim() != 1 or inputs.dim() != 1 or indices.shape[0] != inputs.shape[0]:
+            raise RuntimeError("indices and inputs must be 1-D with the same length")
+        out = torch.empty_like(inputs)
+        with _Guard(inputs):
+            _check(load_library().nfa_scan_keyed(_ptr(indices), _ptr(inputs), _ptr(out), inputs.shape[0], op,
+                                                 int(inclusive), int(reverse), _stream(inputs)))
+        return out
+
+    @staticmethod
+    def _prod_bwd(indices, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, inclusive):
+        for t, n in ((inputs, "inputs"), (outputs, "outputs"), (grad_outputs, "grad_outputs")):
+            _check_input(t, n, torch.float32)
+        gin = torch.empty_like(grad_outputs)
+        n_rays = 0 if chunk_cnts is None else chunk_cnts.shape[0]
+        with _Guard(inputs):
+            _check(load_library().nfa_prod_backward(_ptr(indices), _ptr(chunk_starts), _ptr(chunk_cnts), n_rays,
+                                                    _ptr(inputs), _ptr(outputs), _ptr(grad_outputs), _ptr(gin),
+                                                    inputs.shape[0], int(inclusive), _stream(inputs)))
+        return gin
+
+    @staticmethod
+    def inclusive_sum(chunk_starts, chunk_cnts, inputs, normalize: bool, backward: bool):
+        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, True, backward, normalize)
+
+    @staticmethod
+    def exclusive_sum(chunk_starts, chunk_cnts, inputs, normalize: bool, backward: bool):
+        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, False, backward, normalize)
+
+    @staticmethod
+    def inclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
+        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, True, False, False)
+
+    @staticmethod
+    def exclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
+        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, False, False, False)
+
+    @staticmethod
+    def inclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
+        _check_input(chunk_starts, "chunk_starts", torch.int64)
+        _check_input(chunk_cnts, "chunk_cnts", torch.int64)
+        return _C._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, True)
+
+    @staticmethod
+    def exclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
+        _check_input(chunk_starts, "chunk_starts", torch.int64)
+        _check_input(chunk_cnts, "chunk_cnts", torch.int64)
+        return _C._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, False)
+
+    @staticmethod
+    def inclusive_sum_cub(indices, inputs, backward: bool):
+        return _C._keyed(indices, inputs, NFA_OP_SUM, True, backward)
+
+    @staticmethod
+    def exclusive_sum_cub(indices, inputs, backward: bool):
+        return _C._keyed(indices, inputs, NFA_OP_SUM, False, backward)
+
+    @staticmethod
+    def inclusive_prod_cub_forward(indices, inputs):
+        return _C._keyed(indices, inputs, NFA_OP_PROD, True, False)
+
+    @staticmethod
+    def exclusive_prod_cub_forward(indices, inputs):
+        return _C._keyed(indices, inputs, NFA_OP_PROD, False, False)
+
+    @staticmethod
+    def inclusive_prod_cub_backward(indices, inputs, outputs, grad_outputs):
+        _check_input(indices, "indices", torch.int64)
+        return _C._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, True)
+
+    @staticmethod
+    def exclusive_prod_cub_backward(indices, inputs, outputs, grad_outputs):
+        _check_input(indices, "indices", torch.int64)
+        return _C._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, False)
+
+    # ---------------------------------------------------------------- pdf
+    @staticmethod
+    def importance_sampling(ray_segments: RaySegmentsSpec, cdfs, n_intervels_per_ray, stratified: bool):
+        """nerfacc.cpp:100-112.  Only the int overload exists here: the Tensor-count overload
+        of the reference allocates zero elements (pdf.cu:324) and cannot have callers."""
+        if isinstance(n_intervels_per_ray, torch.Tensor):
+            raise NotImplementedError(
+                "importance_sampling with a per-ray Tensor count is broken in the reference "
+                "(pdf.cu:324 allocates 0 elements) and is not provided; pass an int.")
+        ray_segments.check()
+        _check_input(cdfs, "cdfs", torch.float32)
+        if cdfs.numel() != ray_segments.vals.numel():
+            raise RuntimeError("cdfs and ray_segments.vals must have the same number of elements")
+        n = int(n_intervels_per_ray)
+        view = ray_segments._view()
+        if ray_segments.vals.dim() > 1:
+            lead = list(ray_segments.vals.shape[:-1])
+        else:
+            lead = [int(view.n_rays)]
+        dev = cdfs.device
+        samples, intervals = RaySegmentsSpec(), RaySegmentsSpec()
+        samples.vals = torch.empty(lead + [n], dtype=torch.float32, device=dev)
+        intervals.vals = torch.empty(lead + [n + 1], dtype=torch.float32, device=dev)
+        jitter = None
+        if stratified:
+            # one uniform per ray from torch's generator (the reference draws it with Philox
+            # inside the kernel, pdf.cu:138-144: same distribution, different stream)
+            jitter = torch.rand(int(view.n_rays), dtype=torch.float32, device=dev)
+        with _Guard(cdfs):
+            _check(load_library().nfa_importance_sampling(ctypes.byref(view), _ptr(cdfs), n, _ptr(jitter),
+                                                          _ptr(intervals.vals), _ptr(samples.vals), _stream(cdfs)))
+        return [intervals, samples]
+
+    @staticmethod
+    def searchsorted(query: RaySegmentsSpec, key: RaySegmentsSpec):
+        """nerfacc.cpp:114-117 -> [ids_left, ids_right] shaped like query.vals."""
+        query.check()
+        key.check()
+        ids_left = torch.empty(query.vals.shape, dtype=torch.int64, device=query.vals.device)
+        ids_right = torch.empty_like(ids_left)
+        q, k = query._view(), key._view()
+        with _Guard(query.vals):
+            _check(load_library().nfa_searchsorted(ctypes.byref(q), ctypes.byref(k), _ptr(ids_left), _ptr(ids_right),
+                                                   _stream(query.vals)))
+        return [ids_left, ids_right]
+
+    # ---------------------------------------------------------------- camera (out of scope)
+    @staticmethod
+    def opencv_lens_undistortion(*args, **kwargs):
+        raise NotImplementedError("camera undistortion (camera.cu) is outside the OccGrid hot path and not built")
+
+    @staticmethod
+    def opencv_lens_undistortion_fisheye(*args, **kwargs):
+        raise NotImplementedError("camera undistortion (camera.cu) is outside the OccGrid hot path and not built")
+
+    # ================================================================ fused entry points
+    # (no counterpart in the reference's extension: there these are chains of ATen ops)
+    @staticmethod
+    def sample_occgrid(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float,
+                       cone_angle: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """traverse_grids + the two is_left/is_right compactions of occ_grid.py:164-177 in
+        one count pass and one fill pass: returns (ray_indices, t_starts, t_ends, packed_info).
+        Ray/AABB tests and the per-ray event sort run inside the kernel."""
+        L = load_library()
+        _check_input(rays_o, "rays_o", torch.float32)
+        dev = rays_o.device
+        R = rays_o.shape[0]
+        i64 = dict(dtype=torch.int64, device=dev)
+        with _Guard(rays_o):
+            stream = _stream(rays_o)
+            a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, None, None, None, near_planes, far_planes,
+                               step_size, cone_angle, -1)
+            packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
+            totals = torch.empty(2, **i64)
+            ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
+            a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
+            _check(L.nfa_traverse_count(ctypes.byref(a), _ptr(ws), stream))
+            n = totals[1].item()
+            ray_indices = torch.empty(n, **i64)
+            ts = torch.empty((2, n), dtype=torch.float32, device=dev)
+            a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
+            if n > 0:
+                _check(L.nfa_traverse_fill(ctypes.byref(a), 1, 0, stream))
+        return ray_indices, ts[0], ts[1], packed.t()
+
+    @staticmethod
+    def pack_info(ray_indices, n_rays: int):
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        out = torch.empty((n_rays, 2), dtype=torch.int64, device=ray_indices.device)
+        with _Guard(ray_indices):
+            _check(load_library().nfa_pack_info(_ptr(ray_indices), ray_indices.shape[0], n_rays, _ptr(out), _stream(ray_indices)))
+        return out
+
+    @staticmethod
+    def unpack_info(chunk_starts, chunk_cnts, n: int):
+        _check_input(chunk_starts, "chunk_starts", torch.int64)
+        _check_input(chunk_cnts, "chunk_cnts", torch.int64)
+        out = torch.empty(n, dtype=torch.int64, device=chunk_starts.device)
+        with _Guard(chunk_starts):
+            _check(load_library().nfa_unpack_info(_ptr(chunk_starts), _ptr(chunk_cnts), chunk_cnts.shape[0], _ptr(out), n,
+                                                  _stream(chunk_starts)))
+        return out
+
+    @staticmethod
+    def render_weight_from_density_fwd(ray_indices, t_starts, t_ends, sigmas, prefix_trans=None):
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        for t, n in ((t_starts, "t_starts"), (t_ends, "t_ends"), (sigmas, "sigmas")):
+            _check_input(t, n, torch.float32)
+        if prefix_trans is not None:
+            _check_input(prefix_trans, "prefix_trans", torch.float32)
+        n = sigmas.shape[0]
+        out = torch.empty((3, n), dtype=torch.float32, device=sigmas.device)
+        with _Guard(sigmas):
+            _check(load_library().nfa_render_weight_from_density_fwd(
+                _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(prefix_trans), n,
+                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream(sigmas)))
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def render_weight_from_density_bwd(ray_indices, t_starts, t_ends, sigmas, trans, alphas, g_w, g_T, g_a):
+        n = sigmas.shape[0]
+        g = torch.empty_like(sigmas)
+        for t, nm in ((g_w, "g_weights"), (g_T, "g_trans"), (g_a, "g_alphas")):
+            if t is not None:
+                _check_input(t, nm, torch.float32)
+        with _Guard(sigmas):
+            _check(load_library().nfa_render_weight_from_density_bwd(
+                _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(trans), _ptr(alphas),
+                _ptr(g_w), _ptr(g_T), _ptr(g_a), n, _ptr(g), _stream(sigmas)))
+        return g
+
+    @staticmethod
+    def visibility_compact(ray_indices, t_starts, t_ends, dens, from_alpha: bool, early_stop_eps: float,
+                           alpha_thre: float, want_mask: bool = False):
+        """returns (ray_indices', t_starts', t_ends', mask or None); ONE host sync (the count)."""
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        for t, nm in ((t_starts, "t_starts"), (t_ends, "t_ends"), (dens, "sigmas/alphas")):
+            _check_input(t, nm, torch.float32)
+        L = load_library()
+        n = dens.shape[0]
+        dev = dens.device
+        o_idx = torch.empty(n, dtype=torch.int64, device=dev)
+        o_t = torch.empty((2, n), dtype=torch.float32, device=dev)
+        mask = torch.empty(n, dtype=torch.bool, device=dev) if want_mask else None
+        n_out = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(L.nfa_visibility_workspace_bytes(n), 16), dtype=torch.uint8, device=dev)
+        with _Guard(dens):
+            _check(L.nfa_visibility_compact(_ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n,
+                                            early_stop_eps, alpha_thre, _ptr(o_idx), o_t[0].data_ptr(), o_t[1].data_ptr(),
+                                            _ptr(mask), _ptr(n_out), _ptr(ws), _stream(dens)))
+        k = n_out.item()
+        return o_idx[:k], o_t[0, :k], o_t[1, :k], mask
+
+    @staticmethod
+    def accumulate_along_rays(ray_indices, weights, values, n_rays: int, outputs=None):
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        _check_input(weights, "weights", torch.float32)
+        D = 1
+        if values is not None:
+            _check_input(values, "values", torch.float32)
+            D = values.shape[-1]
+        if outputs is None:
+            outputs = torch.zeros((n_rays, D), dtype=torch.float32, device=weights.device)
+        else:
+            _check_input(outputs, "outputs", torch.float32)
+        with _Guard(weights):
+            _check(load_library().nfa_accumulate_along_rays(_ptr(ray_indices), _ptr(weights), _ptr(values), weights.shape[0], D,
+                                                            outputs.shape[0], _ptr(outputs), _stream(weights)))
+        return outputs
+
+    @staticmethod
+    def accumulate_along_rays_bwd(ray_indices, weights, values, g_out, need_w: bool, need_v: bool):
+        _check_input(g_out, "g_outputs", torch.float32)
+        D = g_out.shape[-1]
+        g_w = torch.empty_like(weights) if need_w else None
+        g_v = torch.empty_like(values) if (need_v and values is not None) else None
+        with _Guard(weights):
+            _check(load_library().nfa_accumulate_along_rays_bwd(_ptr(ray_indices), _ptr(weights), _ptr(values), _ptr(g_out),
+                                                                weights.shape[0], D, _ptr(g_w), _ptr(g_v), _stream(weights)))
+        return g_w, g_v
+
+    @staticmethod
+    def rendering_fwd(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays: int, bkgd, expected_depths: bool):
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        for t, nm in ((t_starts, "t_starts"), (t_ends, "t_ends"), (sigmas, "sigmas"), (rgbs, "rgbs")):
+            _check_input(t, nm, torch.float32)
+        if bkgd is not None:
+            _check_input(bkgd, "render_bkgd", torch.float32)
+        n = sigmas.shape[0]
+        dev = sigmas.device
+        per_sample = torch.empty((3, n), dtype=torch.float32, device=dev)
+        colors = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+        od = torch.empty((2, n_rays, 1), dtype=torch.float32, device=dev)
+        with _Guard(sigmas):
+            _check(load_library().nfa_rendering_fwd(
+                _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(rgbs), n, n_rays, _ptr(bkgd),
+                int(expected_depths), per_sample[0].data_ptr(), per_sample[1].data_ptr(), per_sample[2].data_ptr(),
+                _ptr(colors), od[0].data_ptr(), od[1].data_ptr(), _stream(sigmas)))
+        return colors, od[0], od[1], per_sample[0], per_sample[1], per_sample[2]
+
+    @staticmethod
+    def rendering_bwd(ray_indices, t_starts, t_ends, sigmas, rgbs, weights, trans, alphas, opacities, depths,
+                      n_rays: int, bkgd, expected_depths: bool, g_colors, g_opac, g_depth, g_w, g_T, g_a,
+                      need_sigma: bool = True, need_rgb: bool = True):
+        for t, nm in ((g_colors, "g_colors"), (g_opac, "g_opacities"), (g_depth, "g_depths"), (g_w, "g_weights"),
+                      (g_T, "g_trans"), (g_a, "g_alphas")):
+            if t is not None:
+                _check_input(t, nm, torch.float32)
+        g_sig = torch.empty_like(sigmas) if need_sigma else None
+        g_rgb = torch.empty_like(rgbs) if need_rgb else None
+        with _Guard(sigmas):
+            _check(load_library().nfa_rendering_bwd(
+                _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(rgbs), _ptr(weights), _ptr(trans),
+                _ptr(alphas), _ptr(opacities), _ptr(depths), sigmas.shape[0], n_rays, _ptr(bkgd), int(expected_depths),
+                _ptr(g_colors), _ptr(g_opac), _ptr(g_depth), _ptr(g_w), _ptr(g_T), _ptr(g_a), _ptr(g_sig), _ptr(g_rgb),
+                _stream(sigmas)))
+        return g_sig, g_rgb
+
+
+__all__ = ["_C", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]

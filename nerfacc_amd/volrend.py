@@ -1,0 +1,294 @@
+"""Volumetric rendering — nerfacc/volrend.py, fused for MI355X.
+
+Public functions, argument names and return values match the reference.  What differs is
+underneath: where the reference chains ~10 ATen kernels and a scan per call (and 3 atomics
+based `index_add_` per `rendering`), the flattened (ray_indices / packed_info) paths here are
+single HIP kernels with hand-written backward kernels (render.hip):
+
+  render_weight_from_density / render_transmittance_from_density  -> 1 kernel fwd, 1 bwd
+  rendering (rgb_sigma_fn)                                         -> 1 kernel fwd, 1 bwd
+  accumulate_along_rays                                            -> 1 kernel fwd, 1 bwd
+
+Batched inputs ([n_rays, n_samples], no ray_indices) stay plain differentiable torch code,
+as in the reference.  Gradients flow to sigmas / rgbs / alphas / weights / values; like the
+reference's `rendering`, nothing here is differentiable w.r.t. t_starts, t_ends or indices
+on the flattened paths.
+"""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import cuda as _C
+from .scan import exclusive_prod, exclusive_sum
+
+
+def _flat_indices(ref: Tensor, packed_info: Optional[Tensor], ray_indices: Optional[Tensor]) -> Tensor:
+    """ray index per sample for the flattened layout, expanding packed_info when needed."""
+    if ray_indices is not None:
+        return ray_indices.contiguous()
+    starts, cnts = packed_info.unbind(dim=-1)
+    return _C.unpack_info(starts.contiguous(), cnts.contiguous(), ref.shape[0])
+
+
+# ----------------------------------------------------------------------------------------
+# autograd wrappers around the fused kernels
+# ----------------------------------------------------------------------------------------
+class _WeightFromDensity(torch.autograd.Function):
+    """(weights, trans, alphas) from (t_starts, t_ends, sigmas) keyed by ray_indices."""
+
+    @staticmethod
+    def forward(ctx, ray_indices, t_starts, t_ends, sigmas, prefix_trans):
+        t_starts, t_ends, sigmas = t_starts.contiguous(), t_ends.contiguous(), sigmas.contiguous()
+        if prefix_trans is not None:
+            prefix_trans = prefix_trans.contiguous()
+        w, T, a = _C.render_weight_from_density_fwd(ray_indices, t_starts, t_ends, sigmas, prefix_trans)
+        if ctx.needs_input_grad[3]:
+            ctx.save_for_backward(ray_indices, t_starts, t_ends, sigmas, T, a)
+        return w, T, a
+
+    @staticmethod
+    def backward(ctx, g_w, g_T, g_a):
+        ray_indices, t_starts, t_ends, sigmas, T, a = ctx.saved_tensors
+        g = [None if x is None else x.contiguous() for x in (g_w, g_T, g_a)]
+        g_sig = _C.render_weight_from_density_bwd(ray_indices, t_starts, t_ends, sigmas, T, a, *g)
+        return None, None, None, g_sig, None
+
+
+class _Accumulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray_indices, weights, values, n_rays):
+        weights = weights.contiguous()
+        values = None if values is None else values.contiguous()
+        out = _C.accumulate_along_rays(ray_indices, weights, values, n_rays)
+        ctx.save_for_backward(ray_indices, weights, values)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ray_indices, weights, values = ctx.saved_tensors
+        need_w, need_v = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_w, g_v = _C.accumulate_along_rays_bwd(ray_indices, weights, values, g_out.contiguous(), need_w, need_v)
+        return None, g_w, g_v, None
+
+
+class _Rendering(torch.autograd.Function):
+    """colors, opacities, depths, weights, trans, alphas from sigmas & rgbs in one kernel."""
+
+    @staticmethod
+    def forward(ctx, ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, render_bkgd, expected_depths):
+        t_starts, t_ends = t_starts.contiguous(), t_ends.contiguous()
+        sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+        bk = None if render_bkgd is None else render_bkgd.detach().to(torch.float32).contiguous()
+        colors, opac, depth, w, T, a = _C.rendering_fwd(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, bk,
+                                                        expected_depths)
+        ctx.n_rays, ctx.expected_depths = n_rays, expected_depths
+        ctx.has_bkgd = bk is not None
+        saved = [ray_indices, t_starts, t_ends, sigmas, rgbs, w, T, a, opac, depth]
+        if bk is not None:
+            saved.append(bk)
+        ctx.save_for_backward(*saved)
+        return colors, opac, depth, w, T, a
+
+    @staticmethod
+    def backward(ctx, g_colors, g_opac, g_depth, g_w, g_T, g_a):
+        saved = ctx.saved_tensors
+        ray_indices, t_starts, t_ends, sigmas, rgbs, w, T, a, opac, depth = saved[:10]
+        bk = saved[10] if ctx.has_bkgd else None
+        g = [None if x is None else x.contiguous() for x in (g_colors, g_opac, g_depth, g_w, g_T, g_a)]
+        g_sig, g_rgb = _C.rendering_bwd(ray_indices, t_starts, t_ends, sigmas, rgbs, w, T, a, opac, depth,
+                                        ctx.n_rays, bk, ctx.expected_depths, *g,
+                                        need_sigma=ctx.needs_input_grad[3], need_rgb=ctx.needs_input_grad[4])
+        return None, None, None, g_sig, g_rgb, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
+# public API
+# ----------------------------------------------------------------------------------------
+def rendering(
+    t_starts: Tensor, t_ends: Tensor, ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None,
+    rgb_sigma_fn: Optional[Callable] = None, rgb_alpha_fn: Optional[Callable] = None,
+    render_bkgd: Optional[Tensor] = None, expected_depths: bool = True,
+) -> Tuple[Tensor, Tensor, Tensor, Dict]:
+    """Composite colours, opacities and depths along rays (volrend.py:15-164).
+
+    Exactly one of `rgb_sigma_fn(t_starts, t_ends, ray_indices) -> (rgbs[...,3], sigmas[...])`
+    or `rgb_alpha_fn(...) -> (rgbs, alphas)` queries the radiance field (with gradients).
+    Flattened inputs need `ray_indices` and `n_rays`; batched inputs are (n_rays, n_samples).
+    Returns colors (n_rays, 3), opacities (n_rays, 1), depths (n_rays, 1) and the extras dict
+    {"weights", "alphas", "trans", "rgbs"[, "sigmas"]}.
+    """
+    if ray_indices is not None:
+        assert t_starts.shape == t_ends.shape == ray_indices.shape, \
+            "Since nerfacc 0.5.0, t_starts, t_ends and ray_indices must have the same shape (N,). "
+    if rgb_sigma_fn is None and rgb_alpha_fn is None:
+        raise ValueError("At least one of `rgb_sigma_fn` and `rgb_alpha_fn` should be specified.")
+
+    if rgb_sigma_fn is not None:
+        rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+        assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+        assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+        if ray_indices is not None:
+            assert n_rays is not None, "n_rays must be provided"
+            colors, opacities, depths, weights, trans, alphas = _Rendering.apply(
+                ray_indices.contiguous(), t_starts, t_ends, sigmas, rgbs, int(n_rays), render_bkgd, bool(expected_depths))
+            extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+            if render_bkgd is not None and render_bkgd.requires_grad:
+                # rare: keep the background differentiable like the reference's torch expression
+                colors = colors + (render_bkgd - render_bkgd.detach()) * (1.0 - opacities.detach())
+            return colors, opacities, depths, extras
+        weights, trans, alphas = render_weight_from_density(t_starts, t_ends, sigmas, ray_indices=ray_indices, n_rays=n_rays)
+        extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+    else:
+        rgbs, alphas = rgb_alpha_fn(t_starts, t_ends, ray_indices)
+        assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+        assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
+        weights, trans = render_weight_from_alpha(alphas, ray_indices=ray_indices, n_rays=n_rays)
+        extras = {"weights": weights, "trans": trans, "rgbs": rgbs, "alphas": alphas}
+
+    colors = accumulate_along_rays(weights, values=rgbs, ray_indices=ray_indices, n_rays=n_rays)
+    opacities = accumulate_along_rays(weights, values=None, ray_indices=ray_indices, n_rays=n_rays)
+    depths = accumulate_along_rays(weights, values=(t_starts + t_ends)[..., None] / 2.0, ray_indices=ray_indices,
+                                   n_rays=n_rays)
+    if expected_depths:
+        depths = depths / opacities.clamp_min(torch.finfo(rgbs.dtype).eps)
+    if render_bkgd is not None:
+        colors = colors + render_bkgd * (1.0 - opacities)
+    return colors, opacities, depths, extras
+
+
+def render_transmittance_from_alpha(
+    alphas: Tensor, packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+    n_rays: Optional[int] = None, prefix_trans: Optional[Tensor] = None,
+) -> Tensor:
+    """T_i = prod_{j<i} (1 - alpha_j) per ray (volrend.py:167-216).
+
+        >>> alphas = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], device="cuda")
+        >>> ray_indices = torch.tensor([0, 0, 0, 1, 1, 2, 2], device="cuda")
+        >>> render_transmittance_from_alpha(alphas, ray_indices=ray_indices)
+        tensor([1.0, 0.6, 0.12, 1.0, 0.2, 1.0, 1.0])
+    """
+    trans = exclusive_prod(1 - alphas, packed_info=packed_info, indices=ray_indices)
+    if prefix_trans is not None:
+        trans = trans * prefix_trans
+    return trans
+
+
+def render_transmittance_from_density(
+    t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+    ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None, prefix_trans: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor]:
+    """T_i = exp(-sum_{j<i} sigma_j delta_j) and alpha_i = 1 - exp(-sigma_i delta_i)
+    (volrend.py:219-278).  Returns (trans, alphas)."""
+    if packed_info is None and ray_indices is None:
+        sigmas_dt = sigmas * (t_ends - t_starts)
+        alphas = 1.0 - torch.exp(-sigmas_dt)
+        trans = torch.exp(-exclusive_sum(sigmas_dt))
+        if prefix_trans is not None:
+            trans = trans * prefix_trans
+        return trans, alphas
+    idx = _flat_indices(sigmas, packed_info, ray_indices)
+    _, trans, alphas = _WeightFromDensity.apply(idx, t_starts, t_ends, sigmas, prefix_trans)
+    return trans, alphas
+
+
+def render_weight_from_alpha(
+    alphas: Tensor, packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+    n_rays: Optional[int] = None, prefix_trans: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor]:
+    """w_i = T_i alpha_i with T from :func:`render_transmittance_from_alpha` (volrend.py:281-323).
+    Returns (weights, trans)."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, ray_indices, n_rays, prefix_trans)
+    return trans * alphas, trans
+
+
+def render_weight_from_density(
+    t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+    ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None, prefix_trans: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """w_i = T_i (1 - exp(-sigma_i delta_i)) (volrend.py:326-376).  Returns (weights, trans, alphas).
+
+        >>> t_starts = torch.arange(7., device="cuda"); t_ends = t_starts + 1
+        >>> sigmas = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], device="cuda")
+        >>> ray_indices = torch.tensor([0, 0, 0, 1, 1, 2, 2], device="cuda")
+        >>> render_weight_from_density(t_starts, t_ends, sigmas, ray_indices=ray_indices)[0]
+        weights: [0.33, 0.37, 0.03, 0.55, 0.04, 0.00, 0.59]
+    """
+    if packed_info is None and ray_indices is None:
+        trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, prefix_trans=prefix_trans)
+        return trans * alphas, trans, alphas
+    idx = _flat_indices(sigmas, packed_info, ray_indices)
+    return _WeightFromDensity.apply(idx, t_starts, t_ends, sigmas, prefix_trans)
+
+
+@torch.no_grad()
+def render_visibility_from_alpha(
+    alphas: Tensor, packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+    n_rays: Optional[int] = None, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
+    prefix_trans: Optional[Tensor] = None,
+) -> Tensor:
+    """Boolean mask of samples with T >= early_stop_eps and (if alpha_thre > 0) alpha >= alpha_thre
+    (volrend.py:379-432)."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, ray_indices, n_rays, prefix_trans)
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+@torch.no_grad()
+def render_visibility_from_density(
+    t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+    ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None, early_stop_eps: float = 1e-4,
+    alpha_thre: float = 0.0, prefix_trans: Optional[Tensor] = None,
+) -> Tensor:
+    """Same as :func:`render_visibility_from_alpha` with alpha/T derived from densities
+    (volrend.py:435-494)."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, ray_indices, n_rays,
+                                                      prefix_trans)
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+def accumulate_along_rays(
+    weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+    n_rays: Optional[int] = None,
+) -> Tensor:
+    """out[r] = sum over the samples of ray r of weights * values (values=None: just weights)
+    (volrend.py:497-561).  Flattened: weights (N,), values (N, D), ray_indices (N,), n_rays;
+    batched: weights (n_rays, n_samples), values (n_rays, n_samples, D).  Returns (n_rays, D).
+    Differentiable w.r.t. weights and values.  For ray-sorted indices the result is
+    bit-reproducible (per-ray sums are formed inside one wave in a fixed order), unlike the
+    reference's atomic `index_add_`."""
+    if values is not None:
+        assert values.dim() == weights.dim() + 1
+        assert weights.shape == values.shape[:-1]
+    if ray_indices is not None:
+        assert n_rays is not None, "n_rays must be provided"
+        assert weights.dim() == 1, "weights must be flattened"
+        # flattened layout = HIP kernel, always (device tensors only; raises otherwise)
+        return _Accumulate.apply(ray_indices.contiguous(), weights, values, int(n_rays))
+    src = weights[..., None] if values is None else weights[..., None] * values
+    return torch.sum(src, dim=-2)
+
+
+def accumulate_along_rays_(
+    weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+    outputs: Optional[Tensor] = None,
+) -> None:
+    """In-place :func:`accumulate_along_rays`: adds into `outputs` (n_rays, D) (volrend.py:564-587)."""
+    if values is not None:
+        assert values.dim() == weights.dim() + 1
+        assert weights.shape == values.shape[:-1]
+    if ray_indices is not None:
+        assert weights.dim() == 1, "weights must be flattened"
+        D = 1 if values is None else values.shape[-1]
+        assert outputs.dim() == 2 and outputs.shape[-1] == D, "outputs must be of shape (n_rays, D)"
+        with torch.no_grad():
+            _C.accumulate_along_rays(ray_indices.contiguous(), weights.contiguous(),
+                                     None if values is None else values.contiguous(), outputs.shape[0], outputs)
+    else:
+        src = weights[..., None] if values is None else weights[..., None] * values
+        outputs.add_(src.sum(dim=-2))

@@ -1,0 +1,134 @@
+"""OccGridEstimator on the GPU: fused sampling vs the oracle pipeline and the reference's tests."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_utils import DEV, lego_like, n, scene, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _estimator(aabb, binaries):
+    from nerfacc_amd import OccGridEstimator
+
+    est = OccGridEstimator(roi_aabb=t(aabb), resolution=list(binaries.shape[1:]), levels=binaries.shape[0]).to(DEV)
+    est.binaries = t(binaries)
+    return est
+
+
+def test_sampling_with_min_max_distances():
+    # reference: tests/test_grid.py:163-204
+    torch.manual_seed(42)
+    R = 64
+    rays_o = torch.rand((R, 3), device=DEV) * 2 - 1.0
+    rays_d = torch.rand((R, 3), device=DEV)
+    rays_d = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    binaries = torch.rand((4, 32, 32, 32), device=DEV) > 0.5
+    t_min = torch.rand((R,), device=DEV)
+    t_max = t_min + torch.rand((R,), device=DEV)
+    est = _estimator(np.array([-1, -1, -1, 1, 1, 1], np.float32), n(binaries))
+    ri, ts, te = est.sampling(rays_o, rays_d, near_plane=0.15, far_plane=0.85, t_min=t_min, t_max=t_max, render_step_size=0.01)
+    assert ri.numel() > 0
+    assert (ts >= (t_min[ri] - 0.005)).all() and (te <= (t_max[ri] + 0.005)).all()
+    # and bit-exact vs the oracle
+    r_ri, r_ts, r_te, _ = oracle.sampling(n(rays_o), n(rays_d), n(binaries), n(est.aabbs), 0.15, 0.85, n(t_min), n(t_max), 0.01)
+    assert np.array_equal(n(ri), r_ri) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
+
+
+def test_mark_invisible_cells_known_answer():
+    # reference: tests/test_grid.py:207-233
+    from nerfacc_amd import OccGridEstimator
+
+    est = OccGridEstimator(roi_aabb=torch.tensor([-1.0, -1, -1, 1, 1, 1]), resolution=32, levels=4).to(DEV)
+    K = torch.tensor([[[100.0, 0, 50.0], [0, 100.0, 50.0], [0, 0, 1]]], device=DEV)
+    pose = torch.tensor([[[-1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 2.5]]], device=DEV)
+    est.mark_invisible_cells(K, pose, 100, 100)
+    assert (est.occs == -1).sum() == 77660 and (est.occs == 0).sum() == 53412
+
+
+@pytest.mark.parametrize("stratified", [False, True])
+def test_fused_sampling_vs_oracle_with_visibility(stratified):
+    """Lego-like 128^3 scene (configs[1] geometry): traversal part bit-exact; the visibility
+    filter may only differ where T or alpha sits within float error of its threshold."""
+    o, d, aabb, occ = lego_like(3, 2048)
+    est = _estimator(aabb[0], occ)
+    O, D = t(o), t(d)
+
+    def sigma_of(ts, te, ri, xp):
+        mid = (ts + te) * 0.5
+        return 25.0 * (xp.sin(7.0 * mid) * 0.5 + 0.5)
+
+    torch.manual_seed(5)
+    ri, ts, te = est.sampling(O, D, sigma_fn=lambda a, b, r: sigma_of(a, b, r, torch), render_step_size=5e-3,
+                              stratified=stratified, alpha_thre=0.0)
+    torch.manual_seed(5)
+    jit = n(torch.rand(2048, device=DEV)) if stratified else None
+    cache = {}
+
+    def np_sigma(a, b, r):
+        cache["in"] = (a, b, r)
+        return sigma_of(a, b, r, np).astype(np.float32)
+
+    r_ri, r_ts, r_te, _ = oracle.sampling(o, d, occ, aabb, render_step_size=5e-3, sigmas_fn=np_sigma, jitter=jit)
+    # unfiltered samples are bit-exact (checked through the no-filter path)
+    torch.manual_seed(5)
+    ri0, ts0, te0 = est.sampling(O, D, render_step_size=5e-3, stratified=stratified)
+    a0, b0, r0 = cache["in"]
+    assert np.array_equal(n(ri0), r0) and np.array_equal(n(ts0), a0) and np.array_equal(n(te0), b0)
+    assert len(r0) > 50000 and 0 < len(r_ri) < len(r0)
+    # filtered: identical except threshold ties
+    got = set(zip(n(ri).tolist(), n(ts).tolist()))
+    want = set(zip(r_ri.tolist(), r_ts.tolist()))
+    assert len(got ^ want) <= max(2, len(want) // 20000), (len(got), len(want), len(got ^ want))
+    assert (ri[1:] >= ri[:-1]).all()
+
+
+def test_alpha_fn_and_alpha_thre_paths():
+    o, d, aabb, occ = lego_like(4, 512, res=64)
+    est = _estimator(aabb[0], occ)
+    est.occs.fill_(0.5)   # so that min(alpha_thre, occs.mean()) keeps alpha_thre
+    O, D = t(o), t(d)
+    sig = lambda a, b, r: 30.0 * torch.ones_like(a)
+    alp = lambda a, b, r: 1.0 - torch.exp(-30.0 * (b - a))
+    x = est.sampling(O, D, sigma_fn=sig, render_step_size=1e-2, alpha_thre=1e-2)
+    y = est.sampling(O, D, alpha_fn=alp, render_step_size=1e-2, alpha_thre=1e-2)
+    assert abs(x[0].numel() - y[0].numel()) <= 2 and x[0].numel() > 0
+    z = est.sampling(O, D, sigma_fn=sig, render_step_size=1e-2, alpha_thre=0.9)   # alpha ~0.26 < 0.9: all dropped
+    assert z[0].numel() == 0
+
+
+def test_update_every_n_steps_and_state_dict_roundtrip():
+    from nerfacc_amd import OccGridEstimator
+
+    torch.manual_seed(0)
+    est = OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=32, levels=1).to(DEV)
+    est.train()
+    occ_fn = lambda x: (x.norm(dim=-1, keepdim=True) < 1.0).float() * 0.5
+    for step in range(0, 48):
+        est.update_every_n_steps(step, occ_fn)
+    frac = est.binaries.float().mean().item()
+    assert 0.05 < frac < 0.35            # a radius-1 ball in a 3^3 box is ~15.5 %
+    sd = est.state_dict()
+    assert set(sd) == {"resolution", "aabbs", "occs", "binaries"}    # occ_grid.py:67-83 persistence
+    est2 = OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=32, levels=1).to(DEV)
+    est2.load_state_dict(sd)
+    assert torch.equal(est2.binaries, est.binaries)
+    est.eval()
+    with pytest.raises(RuntimeError):
+        est.update_every_n_steps(0, occ_fn)
+
+
+def test_distortion_loss_matches_dense_formula():
+    from nerfacc_amd import distortion
+
+    torch.manual_seed(0)
+    R, S = 50, 20
+    t0 = torch.sort(torch.rand(R, S + 1, device=DEV), -1)[0]
+    w = torch.rand(R, S, device=DEV)
+    ts, te = t0[:, :-1], t0[:, 1:]
+    ri = torch.arange(R, device=DEV).repeat_interleave(S)
+    got = distortion(w.flatten(), ts.flatten(), te.flatten(), ri, R)[:, 0]
+    m = 0.5 * (ts + te)
+    dense = (w[:, :, None] * w[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum((1, 2)) + ((te - ts) * w**2).sum(-1) / 3
+    assert torch.allclose(got, dense, atol=1e-4, rtol=1e-4)

@@ -1,0 +1,155 @@
+"""HIP traversal / ray-AABB kernels vs the CPU oracle: bit-exact (integer AND float outputs,
+both sides use the same op order and fmaf sites).  Calls go through the public API, i.e.
+through the C ABI of libnerfacc_hip.so."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_utils import DEV, lego_like, n, scene, t
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ray_aabb_intersect_bit_exact_and_vs_twin(golden):
+    from nerfacc_amd.grid import _ray_aabb_intersect, ray_aabb_intersect
+
+    o, d, boxes = golden["k1_rays_o"], golden["k1_rays_d"], golden["k1_aabbs"]
+    tmin, tmax, hits = ray_aabb_intersect(t(o), t(d), t(boxes))
+    r_tmin, r_tmax, r_hits = oracle.ray_aabb_intersect(o, d, boxes)
+    assert np.array_equal(n(hits), r_hits)
+    assert np.array_equal(n(tmin), r_tmin) and np.array_equal(n(tmax), r_tmax)
+    # reference: tests/test_grid.py:23-27 (kernel vs pure-torch twin)
+    a, b, c = _ray_aabb_intersect(t(o), t(d), t(boxes))
+    assert torch.allclose(tmin, a) and torch.allclose(tmax, b) and (hits == c).all()
+    np.testing.assert_allclose(n(tmin), golden["k1_tmin"], rtol=1e-5)
+    # near/far/miss arguments
+    tmin, tmax, hits = ray_aabb_intersect(t(o), t(d), t(boxes), 0.1, 0.7, -1.0)
+    r = oracle.ray_aabb_intersect(o, d, boxes, 0.1, 0.7, -1.0)
+    assert np.array_equal(n(tmin), r[0]) and np.array_equal(n(tmax), r[1]) and np.array_equal(n(hits), r[2])
+
+
+def _compare(iv, sm, term, r_iv, r_sm, r_term):
+    assert np.array_equal(n(sm.packed_info), r_sm["packed_info"])
+    assert np.array_equal(n(iv.packed_info), r_iv["packed_info"])
+    assert np.array_equal(n(sm.ray_indices), r_sm["ray_indices"])
+    assert np.array_equal(n(iv.ray_indices), r_iv["ray_indices"])
+    assert np.array_equal(n(iv.is_left), r_iv["is_left"]) and np.array_equal(n(iv.is_right), r_iv["is_right"])
+    assert np.array_equal(n(iv.vals), r_iv["vals"])          # float, bit-exact
+    assert np.array_equal(n(sm.vals), r_sm["vals"])
+    assert np.array_equal(n(sm.is_valid), r_sm["is_valid"])
+    # rays without samples are skipped by the fill pass (grid.cu:103-106), so their
+    # terminate_planes entry is never written — in the reference as well: compare the rest
+    live = r_sm["packed_info"][:, 1] > 0
+    assert np.array_equal(n(term)[live], r_term[live])
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                               # tests/test_grid.py:38-68 configuration
+    dict(step_size=0.02, cone_angle=0.004),
+    dict(step_size=-1.0),                                 # one interval per occupied voxel
+    dict(step_size=5e-3, near=0.3, far=2.5),
+    dict(step_size=1e-2, traverse_steps_limit=37),
+])
+@pytest.mark.parametrize("levels,res", [(4, 32), (1, 64), (2, (20, 33, 7))])
+def test_traverse_grids_bit_exact(kw, levels, res):
+    from nerfacc_amd.grid import traverse_grids
+
+    kw = dict(kw)
+    res3 = (res,) * 3 if isinstance(res, int) else res
+    o, d, aabbs, _ = scene(42 + levels, n_rays=300, levels=levels, res=8)
+    binaries = np.random.default_rng(levels).random((levels,) + res3) < 0.4
+    near, far = kw.pop("near", None), kw.pop("far", None)
+    extra = {}
+    if near is not None:
+        rng = np.random.default_rng(0)
+        extra["near_planes"] = (near * rng.random(300)).astype(np.float32)
+        extra["far_planes"] = (far * (0.5 + rng.random(300))).astype(np.float32)
+    r_iv, r_sm, r_term = oracle.traverse_grids(o, d, binaries, aabbs, **extra, **kw)
+    g_extra = {k: t(v) for k, v in extra.items()}
+    iv, sm, term = traverse_grids(t(o), t(d), t(binaries), t(aabbs), **g_extra, **kw)
+    assert r_sm["vals"].shape[0] > 50
+    _compare(iv, sm, term, r_iv, r_sm, r_term)
+    # same result when the caller supplies the sorted intersections (grid.py:156-162)
+    from nerfacc_amd.grid import ray_aabb_intersect
+
+    tmin, tmax, hits = ray_aabb_intersect(t(o), t(d), t(aabbs))
+    ts, ti = torch.sort(torch.cat([tmin, tmax], -1), dim=-1, stable=True)
+    iv2, sm2, term2 = traverse_grids(t(o), t(d), t(binaries), t(aabbs), **g_extra, **kw, t_sorted=ts, t_indices=ti, hits=hits)
+    _compare(iv2, sm2, term2, r_iv, r_sm, r_term)
+
+
+def test_traverse_lego_like_128_bit_exact_and_invariants():
+    from nerfacc_amd.grid import _query, traverse_grids
+
+    o, d, aabb, occ = lego_like(0, 4096)
+    r_iv, r_sm, r_term = oracle.traverse_grids(o, d, occ, aabb, step_size=5e-3)
+    iv, sm, term = traverse_grids(t(o), t(d), t(occ), t(aabb), step_size=5e-3)
+    assert r_sm["vals"].shape[0] > 100000
+    _compare(iv, sm, term, r_iv, r_sm, r_term)
+    # reference property (tests/test_grid.py:57-68): every sample midpoint is in an occupied cell
+    ts_, te_ = iv.vals[iv.is_left], iv.vals[iv.is_right]
+    pos = t(o)[sm.ray_indices] + t(d)[sm.ray_indices] * ((ts_ + te_)[:, None] / 2.0)
+    occs, sel = _query(pos, t(occ), t(aabb[0]))
+    assert sel.all() and occs.float().mean() > 0.9999
+
+
+def test_traverse_test_mode_over_allocate():
+    # reference: tests/test_grid.py:71-131
+    from nerfacc_amd.grid import traverse_grids
+    from nerfacc_amd.volrend import accumulate_along_rays
+
+    o, d, aabbs, binaries = scene(42, n_rays=10)
+    O, D, A, B = t(o), t(d), t(aabbs), t(binaries)
+    iv, sm, _ = traverse_grids(O, D, B, A)
+    acc_s = accumulate_along_rays(iv.vals[iv.is_left], None, sm.ray_indices, 10)
+    acc_e = accumulate_along_rays(iv.vals[iv.is_right], None, sm.ray_indices, 10)
+    a_s, a_e, near, mask = 0.0, 0.0, None, None
+    r_near, r_mask = None, None
+    for it in range(2):
+        iv2, sm2, near = traverse_grids(O, D, B, A, near_planes=near, traverse_steps_limit=4000, over_allocate=True,
+                                        rays_mask=mask)
+        r_iv2, r_sm2, r_near = oracle.traverse_grids(o, d, binaries, aabbs, near_planes=r_near, traverse_steps_limit=4000,
+                                                     over_allocate=True, rays_mask=r_mask)
+        assert np.array_equal(n(sm2.packed_info), r_sm2["packed_info"])
+        assert np.array_equal(n(iv2.vals), r_iv2["vals"]) and np.array_equal(n(sm2.is_valid), r_sm2["is_valid"])
+        assert np.array_equal(n(iv2.is_left), r_iv2["is_left"]) and np.array_equal(n(iv2.is_right), r_iv2["is_right"])
+        mask = sm2.packed_info[:, 1] == 4000
+        r_mask = r_sm2["packed_info"][:, 1] == 4000
+        if it == 0:
+            assert np.array_equal(n(near), r_near)
+        ri2 = sm2.ray_indices[sm2.is_valid]
+        a_s = a_s + accumulate_along_rays(iv2.vals[iv2.is_left], None, ri2, 10)
+        a_e = a_e + accumulate_along_rays(iv2.vals[iv2.is_right], None, ri2, 10)
+    assert (~mask).all()
+    assert torch.allclose(a_s, acc_s, atol=1e-1) and torch.allclose(a_e, acc_e, atol=1e-1)
+
+
+def test_traverse_near_far_single_cell():
+    # reference: tests/test_grid.py:134-160
+    from nerfacc_amd.grid import traverse_grids
+
+    o = torch.tensor([[-1.0, 0.0, 0.0]], device=DEV)
+    d = torch.tensor([[1.0, 0.01, 0.01]], device=DEV)
+    d = d / d.norm(dim=-1, keepdim=True)
+    iv, sm, _ = traverse_grids(o, d, torch.ones((1, 1, 1, 1), dtype=torch.bool, device=DEV),
+                               torch.tensor([[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]], device=DEV),
+                               step_size=0.05, near_planes=torch.tensor([1.2], device=DEV),
+                               far_planes=torch.tensor([1.5], device=DEV))
+    assert iv.vals.numel() > 0
+    assert (iv.vals >= 1.2 - 0.025).all() and (iv.vals <= 1.5 + 0.025).all()
+
+
+def test_traverse_empty_inputs_and_errors():
+    from nerfacc_amd.grid import traverse_grids
+
+    B = torch.zeros((1, 8, 8, 8), dtype=torch.bool, device=DEV)
+    A = torch.tensor([[0.0, 0, 0, 1, 1, 1]], device=DEV)
+    iv, sm, term = traverse_grids(torch.rand(5, 3, device=DEV), torch.ones(5, 3, device=DEV) / 3**0.5, B, A)
+    assert iv.vals.numel() == 0 and sm.vals.numel() == 0 and (sm.packed_info == 0).all()
+    iv, sm, term = traverse_grids(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV), B, A)
+    assert sm.vals.numel() == 0 and sm.packed_info.shape == (0, 2)
+    with pytest.raises(RuntimeError):   # CPU tensors are rejected, there is no fallback
+        traverse_grids(torch.rand(5, 3), torch.rand(5, 3), B.cpu(), A.cpu())
+    with pytest.raises(AssertionError):
+        traverse_grids(torch.rand(5, 3, device=DEV), torch.rand(5, 3, device=DEV), B, A, over_allocate=True)

@@ -1,0 +1,96 @@
+"""pdf.hip vs the reference's pure-torch twins (tests/test_pdf.py) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_utils import DEV, n, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _intervals(n_rays, n_samples, seed=42):
+    from nerfacc_amd.data_specs import RayIntervals
+
+    torch.manual_seed(seed)
+    vals = torch.sort(torch.rand((n_rays, n_samples + 1), device=DEV), -1)[0]
+    return RayIntervals(vals=vals)
+
+
+def test_searchsorted():
+    # reference: tests/test_pdf.py:45-62
+    from nerfacc_amd.pdf import searchsorted
+
+    query, key = _intervals(10, 100, 1), _intervals(10, 100, 2)
+    ids_left, ids_right = searchsorted(key, query)
+    ref = torch.clamp(torch.searchsorted(key.vals, query.vals, right=True), 0, key.vals.shape[-1] - 1)
+    assert torch.equal(ids_right, ref)
+    assert torch.equal(ids_left, torch.clamp(ref - 1, min=0))
+    l, r = oracle.searchsorted(n(key.vals), n(query.vals))
+    assert np.array_equal(n(ids_left), l) and np.array_equal(n(ids_right), r)
+
+
+def test_importance_sampling_vs_twin_and_oracle(golden):
+    # reference: tests/test_pdf.py:65-94 (atol 1e-4)
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.pdf import _sample_from_weighted, importance_sampling
+
+    intervals = _intervals(5, 100)
+    cdfs = torch.sort(torch.rand_like(intervals.vals), -1)[0]
+    new_iv, samples = importance_sampling(intervals, cdfs, 100, False)
+    for i in range(5):
+        e, m = _sample_from_weighted(intervals.vals[i:i + 1], cdfs[i:i + 1, 1:] - cdfs[i:i + 1, :-1], 100, False,
+                                     intervals.vals[i].min(), intervals.vals[i].max())
+        assert torch.allclose(new_iv.vals[i:i + 1], e, atol=1e-4)
+        assert torch.allclose(samples.vals[i:i + 1], m, atol=1e-4)
+    re, rm = oracle.importance_sampling(n(intervals.vals), n(cdfs), 100)
+    np.testing.assert_allclose(n(new_iv.vals), re, atol=1e-6)
+    np.testing.assert_allclose(n(samples.vals), rm, atol=1e-6)
+    # golden from the reference's twin
+    g = golden
+    iv2, s2 = importance_sampling(RayIntervals(vals=t(g["p_vals"])), t(g["p_cdfs"]), 100)
+    np.testing.assert_allclose(n(iv2.vals), g["p_edges"], atol=1e-4)
+    np.testing.assert_allclose(n(s2.vals), g["p_mids"], atol=1e-4)
+    # stratified: still sorted, inside the ray's range
+    iv3, s3 = importance_sampling(intervals, cdfs, 64, True)
+    assert (s3.vals[:, 1:] >= s3.vals[:, :-1]).all()
+    assert (iv3.vals >= intervals.vals.min(-1, keepdim=True)[0] - 1e-6).all()
+    with pytest.raises(NotImplementedError):
+        importance_sampling(intervals, cdfs, torch.full((5,), 10, device=DEV), False)
+
+
+def test_flattened_docstring_examples():
+    # reference: nerfacc/pdf.py:40-56, 108-120
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.pdf import importance_sampling, searchsorted
+
+    seq = RayIntervals(vals=torch.tensor([0.0, 1.0, 0.0, 1.0, 2.0], device=DEV),
+                       packed_info=torch.tensor([[0, 2], [2, 3]], device=DEV))
+    q = RayIntervals(vals=torch.tensor([0.5, 1.5, 2.5], device=DEV), packed_info=torch.tensor([[0, 1], [1, 2]], device=DEV))
+    l, r = searchsorted(seq, q)
+    assert l.tolist() == [0, 3, 3] and r.tolist() == [1, 4, 4]
+    iv, s = importance_sampling(seq, torch.tensor([0.0, 0.5, 0.0, 0.5, 1.0], device=DEV), 2)
+    assert torch.allclose(iv.vals, torch.tensor([[0.0, 0.5, 1.0], [0.0, 1.0, 2.0]], device=DEV))
+    assert torch.allclose(s.vals, torch.tensor([[0.25, 0.75], [0.5, 1.5]], device=DEV))
+
+
+def test_pdf_loss_and_propnet_sampling():
+    # reference: tests/test_pdf.py:97-127
+    from nerfacc_amd.estimators.prop_net import PropNetEstimator, _lossfun_outer, _pdf_loss
+    from nerfacc_amd.pdf import importance_sampling
+
+    intervals = _intervals(5, 100)
+    cdfs = torch.sort(torch.rand_like(intervals.vals), -1)[0]
+    iv2, _ = importance_sampling(intervals, cdfs, 10, False)
+    cdfs2 = torch.sort(torch.rand_like(iv2.vals), -1)[0]
+    loss = _pdf_loss(intervals, cdfs, iv2, cdfs2)
+    loss2 = _lossfun_outer(intervals.vals, cdfs[:, 1:] - cdfs[:, :-1], iv2.vals, cdfs2[:, 1:] - cdfs2[:, :-1])
+    assert torch.allclose(loss, loss2, atol=1e-4)
+    # config-3 shapes (train_ngp_nerf_prop.py:66,92-93): 4096 rays, 256 -> 96 -> 48
+    est = PropNetEstimator().to(DEV)
+    fn = lambda a, b: torch.exp(-(0.5 * (a + b) - 2.0) ** 2) * 3.0
+    ts, te = est.sampling([fn, fn], [256, 96], 48, n_rays=4096, near_plane=0.2, far_plane=1e3, requires_grad=True)
+    assert ts.shape == te.shape == (4096, 48)
+    assert (te >= ts).all() and (ts[:, 1:] >= ts[:, :-1] - 1e-6).all() and (ts >= 0.2 - 1e-4).all()
+    trans = torch.rand(4096, 48, device=DEV).cumsum(-1).neg().exp()
+    assert est.compute_loss(trans).ndim == 0

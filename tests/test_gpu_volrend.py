@@ -1,0 +1,254 @@
+"""Fused rendering kernels vs (a) the reference's hand-computed answers, (b) golden outputs
+of the reference's batched torch path, (c) the CPU oracle on ragged inputs.
+Tolerance: 1e-5 absolute on weights / colours (BASELINE.json north_star), written per assert."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import flatten_rows
+from gpu_utils import DEV, n, ragged, t
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def _ri():
+    return torch.tensor([0, 2, 2, 2, 2], dtype=torch.int64, device=DEV)
+
+
+def test_render_visibility_known():
+    # reference: tests/test_rendering.py:11-34
+    from nerfacc_amd.volrend import render_visibility_from_alpha
+
+    alphas = torch.tensor([0.4, 0.3, 0.8, 0.8, 0.5], device=DEV)
+    vis = render_visibility_from_alpha(alphas, ray_indices=_ri(), early_stop_eps=0.03, alpha_thre=0.0)
+    assert vis.tolist() == [True, True, True, True, False]
+    vis = render_visibility_from_alpha(alphas, ray_indices=_ri(), early_stop_eps=0.05, alpha_thre=0.35)
+    assert vis.tolist() == [True, False, True, True, False]
+
+
+def test_render_weight_from_alpha_and_density_known():
+    # reference: tests/test_rendering.py:41-83
+    from nerfacc_amd.volrend import render_weight_from_alpha, render_weight_from_density
+
+    alphas = torch.tensor([0.4, 0.3, 0.8, 0.8, 0.5], device=DEV)
+    w, _ = render_weight_from_alpha(alphas, ray_indices=_ri(), n_rays=3)
+    assert torch.allclose(w, torch.tensor([0.4, 0.3, 0.56, 0.112, 0.014], device=DEV))
+    torch.manual_seed(0)
+    sig = torch.rand(5, device=DEV)
+    ts, te = torch.rand(5, device=DEV), torch.rand(5, device=DEV) + 1.0
+    a = 1.0 - torch.exp(-sig * (te - ts))
+    w1, _, _ = render_weight_from_density(ts, te, sig, ray_indices=_ri(), n_rays=3)
+    w2, _ = render_weight_from_alpha(a, ray_indices=_ri(), n_rays=3)
+    assert torch.allclose(w1, w2)
+
+
+def test_accumulate_known():
+    # reference: tests/test_rendering.py:87-106
+    from nerfacc_amd.volrend import accumulate_along_rays
+
+    w = torch.tensor([0.4, 0.3, 0.8, 0.8, 0.5], device=DEV)
+    v = torch.rand((5, 2), device=DEV)
+    out = accumulate_along_rays(w, values=v, ray_indices=_ri(), n_rays=3)
+    assert out.shape == (3, 2)
+    assert torch.allclose(out[0], w[0, None] * v[0])
+    assert (out[1] == 0).all()
+    assert torch.allclose(out[2], (w[1:, None] * v[1:]).sum(0))
+
+
+def test_grads_known_six_paths():
+    # reference: tests/test_rendering.py:109-193
+    from nerfacc_amd.volrend import render_transmittance_from_density, render_weight_from_alpha, render_weight_from_density
+
+    packed = torch.tensor([[0, 1], [1, 0], [1, 4]], dtype=torch.long, device=DEV)
+    sig = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1], device=DEV, requires_grad=True)
+    ts = torch.rand_like(sig)
+    te = ts + 1.0
+    w_ref = torch.tensor([0.3297, 0.5507, 0.0428, 0.2239, 0.0174], device=DEV)
+    g_ref = torch.tensor([0.6703, 0.1653, 0.1653, 0.1653, 0.1653], device=DEV)
+
+    def check(w):
+        w.sum().backward()
+        g = sig.grad.clone()
+        sig.grad.zero_()
+        assert torch.allclose(w_ref, w, atol=1e-4) and torch.allclose(g_ref, g, atol=1e-4)
+
+    for kw in (dict(ray_indices=_ri()), dict(packed_info=packed)):
+        T, _ = render_transmittance_from_density(ts, te, sig, n_rays=3, **kw)
+        check(T * (1.0 - torch.exp(-sig * (te - ts))))
+        check(render_weight_from_density(ts, te, sig, n_rays=3, **kw)[0])
+        check(render_weight_from_alpha(1.0 - torch.exp(-sig * (te - ts)), n_rays=3, **kw)[0])
+
+
+def test_rendering_smoke_and_alpha_fn():
+    # reference: tests/test_rendering.py:196-218
+    from nerfacc_amd.volrend import rendering
+
+    sig = torch.rand(5, device=DEV)
+    ts, te = torch.rand_like(sig), torch.rand_like(sig) + 1.0
+    c, o, d, ex = rendering(ts, te, ray_indices=_ri(), n_rays=3,
+                            rgb_sigma_fn=lambda a, b, r: (torch.stack([a] * 3, -1), a))
+    assert c.shape == (3, 3) and o.shape == (3, 1) and d.shape == (3, 1)
+    assert set(ex) == {"weights", "alphas", "trans", "sigmas", "rgbs"}
+    c2, o2, d2, ex2 = rendering(ts, te, ray_indices=_ri(), n_rays=3,
+                                rgb_alpha_fn=lambda a, b, r: (torch.stack([a] * 3, -1), ex["alphas"]))
+    assert torch.allclose(c, c2, atol=ATOL) and torch.allclose(o, o2, atol=ATOL) and torch.allclose(d, d2, atol=1e-4)
+    with pytest.raises(ValueError):
+        rendering(ts, te, ray_indices=_ri(), n_rays=3)
+
+
+def test_docstring_examples():
+    from nerfacc_amd import pack_info
+    from nerfacc_amd.volrend import render_transmittance_from_alpha, render_visibility_from_density, render_weight_from_density
+
+    ri = torch.tensor([0, 0, 0, 1, 1, 2, 2], device=DEV)
+    al = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], device=DEV)
+    assert torch.allclose(render_transmittance_from_alpha(al, ray_indices=ri),
+                          torch.tensor([1.0, 0.6, 0.12, 1.0, 0.2, 1.0, 1.0], device=DEV))
+    ts = torch.arange(7.0, device=DEV)
+    w, T, a = render_weight_from_density(ts, ts + 1, al, ray_indices=ri)
+    assert torch.allclose(w, torch.tensor([0.33, 0.37, 0.03, 0.55, 0.04, 0.00, 0.59], device=DEV), atol=5e-3)
+    vis = render_visibility_from_density(ts, ts + 1, al, ray_indices=ri, early_stop_eps=0.3, alpha_thre=0.2)
+    assert vis.tolist() == [True, True, False, True, False, False, True]
+    assert pack_info(torch.tensor([0, 0, 1, 1, 1, 2, 2, 2, 2], device=DEV), n_rays=3).tolist() == [[0, 2], [2, 3], [5, 4]]
+    assert pack_info(_ri(), n_rays=3).tolist() == [[0, 1], [1, 0], [1, 4]]          # tests/test_pack.py:11-18
+
+
+def test_flat_kernels_vs_reference_batched_golden(golden):
+    """the reference's batched torch path (run on CPU, tests/golden) == our flattened kernels"""
+    from nerfacc_amd.volrend import accumulate_along_rays, render_weight_from_alpha, render_weight_from_density, rendering
+
+    g = golden
+    ts_, ri_, pk_ = flatten_rows(g["v_ts"])
+    R = g["v_ts"].shape[0]
+    ts, te, ri, pk = t(ts_), t(g["v_te"].ravel()), t(ri_), t(pk_)
+    for kw in (dict(ray_indices=ri), dict(packed_info=pk)):
+        sig = t(g["v_sig"].ravel()).requires_grad_(True)
+        w, T, a = render_weight_from_density(ts, te, sig, **kw)
+        np.testing.assert_allclose(n(w), g["v_w"].ravel(), atol=ATOL)
+        np.testing.assert_allclose(n(T), g["v_T"].ravel(), atol=ATOL)
+        np.testing.assert_allclose(n(a), g["v_a"].ravel(), atol=ATOL)
+        (w * t(g["v_gw"].ravel()) + T * t(g["v_gT"].ravel()) + a * t(g["v_ga"].ravel())).sum().backward()
+        np.testing.assert_allclose(n(sig.grad), g["v_gsig"].ravel(), atol=5e-5, rtol=1e-4)
+    wa, Ta = render_weight_from_alpha(t(g["a_al"].ravel()), ray_indices=ri)
+    np.testing.assert_allclose(n(wa), g["a_w"].ravel(), atol=ATOL)
+    # fused rendering + its backward vs autograd of the reference
+    sig = t(g["v_sig"].ravel()).requires_grad_(True)
+    rgb = t(g["r_rgb"].reshape(-1, 3)).requires_grad_(True)
+    col, opa, dep, _ = rendering(ts, te, ri, R, rgb_sigma_fn=lambda a_, b_, c_: (rgb, sig), render_bkgd=t(g["r_bk"]))
+    np.testing.assert_allclose(n(col), g["r_col"], atol=ATOL)
+    np.testing.assert_allclose(n(opa), g["r_opa"], atol=ATOL)
+    np.testing.assert_allclose(n(dep), g["r_dep"], atol=5e-5)
+    (col * t(g["r_gc"])).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(n(sig.grad), g["r_gsig_c"].ravel(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(n(rgb.grad), g["r_grgb_c"].reshape(-1, 3), atol=ATOL)
+    sig.grad = None
+    rgb.grad = None
+    ((col * t(g["r_gc"])).sum() + (opa * t(g["r_go"])).sum() + (dep * t(g["r_gd"])).sum()).backward()
+    np.testing.assert_allclose(n(sig.grad), g["r_gsig_all"].ravel(), atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(n(rgb.grad), g["r_grgb_all"].reshape(-1, 3), atol=ATOL)
+    # accumulate (reference CPU index_add_)
+    out3 = accumulate_along_rays(t(g["acc_w"]), t(g["acc_v"]), t(g["acc_idx"]), 40)
+    out1 = accumulate_along_rays(t(g["acc_w"]), None, t(g["acc_idx"]), 40)
+    np.testing.assert_allclose(n(out3), g["acc_out3"], atol=ATOL)
+    np.testing.assert_allclose(n(out1), g["acc_out1"], atol=ATOL)
+
+
+@pytest.mark.parametrize("n_rays,max_len,seed", [(1, 1, 0), (7, 5, 1), (500, 90, 2), (3000, 700, 3), (3, 5000, 4), (70000, 12, 5)])
+def test_ragged_vs_oracle_fwd_bwd(n_rays, max_len, seed):
+    """ragged rays incl. empty ones, rays longer than a wave tile, many tiny rays"""
+    from nerfacc_amd.volrend import accumulate_along_rays, render_weight_from_density, rendering
+
+    rng = np.random.default_rng(seed)
+    ri_, pk_ = ragged(rng, n_rays, max_len)
+    N = ri_.shape[0]
+    if N == 0:
+        ri_, pk_ = np.zeros(1, np.int64), np.array([[0, 1]] + [[1, 0]] * (n_rays - 1), np.int64)
+        N = 1
+    dt = (rng.random(N) * 0.02 + 1e-3).astype(np.float32)
+    ts_ = (rng.random(N) * 5).astype(np.float32)
+    te_ = ts_ + dt
+    sig_ = (rng.random(N) * 40 * (rng.random(N) > 0.3)).astype(np.float32)
+    rgb_ = rng.random((N, 3)).astype(np.float32)
+    pre_ = rng.random(N).astype(np.float32)
+    ts, te, ri = t(ts_), t(te_), t(ri_)
+    # weights fwd (+prefix_trans) / bwd
+    sig = t(sig_).requires_grad_(True)
+    w, T, a = render_weight_from_density(ts, te, sig, ray_indices=ri, prefix_trans=t(pre_))
+    rw, rT, ra = oracle.render_weight_from_density(ts_, te_, sig_, ri_, pre_)
+    for x, y in ((w, rw), (T, rT), (a, ra)):
+        np.testing.assert_allclose(n(x), y, atol=ATOL)
+    gw_, gT_, ga_ = (rng.standard_normal(N).astype(np.float32) for _ in range(3))
+    (w * t(gw_) + T * t(gT_) + a * t(ga_)).sum().backward()
+    rg = oracle.render_weight_from_density_bwd(ts_, te_, sig_, ri_, gw_, gT_, ga_, pre_)
+    np.testing.assert_allclose(n(sig.grad), rg, atol=2e-4, rtol=2e-4)
+    # fused rendering fwd
+    bk = np.array([1.0, 0.5, 0.25], np.float32)
+    col, opa, dep, ex = rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda *_: (t(rgb_), t(sig_)), render_bkgd=t(bk))
+    rc, ro, rd, rex = oracle.rendering(ts_, te_, ri_, n_rays, sig_, rgb_, bk)
+    np.testing.assert_allclose(n(col), rc, atol=2e-5)
+    np.testing.assert_allclose(n(opa), ro, atol=2e-5)
+    np.testing.assert_allclose(n(dep), rd, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(n(ex["weights"]), rex["weights"], atol=ATOL)
+    # accumulate D = 1, 3, 6 (two launches for 6)
+    for D in (None, 3, 6):
+        v_ = None if D is None else rng.random((N, D)).astype(np.float32)
+        out = accumulate_along_rays(t(rw), None if v_ is None else t(v_), ri, n_rays)
+        np.testing.assert_allclose(n(out), oracle.accumulate_along_rays(rw, v_, ri_, n_rays), atol=2e-5, rtol=1e-5)
+
+
+def test_accumulate_backward_and_inplace():
+    from nerfacc_amd.volrend import accumulate_along_rays, accumulate_along_rays_
+
+    rng = np.random.default_rng(0)
+    ri_, _ = ragged(rng, 200, 30)
+    N = ri_.shape[0]
+    w = t(rng.random(N).astype(np.float32)).requires_grad_(True)
+    v = t(rng.random((N, 3)).astype(np.float32)).requires_grad_(True)
+    go = t(rng.standard_normal((200, 3)).astype(np.float32))
+    (accumulate_along_rays(w, v, t(ri_), 200) * go).sum().backward()
+    w2, v2 = w.detach().clone().requires_grad_(True), v.detach().clone().requires_grad_(True)
+    ref = torch.zeros(200, 3, device=DEV).index_add(0, t(ri_), w2[:, None] * v2)
+    (ref * go).sum().backward()
+    assert torch.allclose(w.grad, w2.grad, atol=1e-5) and torch.allclose(v.grad, v2.grad, atol=1e-6)
+    out = torch.ones(200, 3, device=DEV)
+    accumulate_along_rays_(w.detach(), v.detach(), t(ri_), out)
+    assert torch.allclose(out, ref.detach() + 1, atol=1e-5)
+    # determinism: bitwise identical when repeated
+    a = accumulate_along_rays(w.detach(), v.detach(), t(ri_), 200)
+    b = accumulate_along_rays(w.detach(), v.detach(), t(ri_), 200)
+    assert torch.equal(a, b)
+
+
+def test_large_n_properties():
+    """BASELINE-scale N (2^22 samples): size-independent properties instead of the oracle:
+    weights sum to opacity = 1 - prod(1-alpha) per ray; T non-increasing within a ray;
+    linearity of accumulate; idempotent determinism."""
+    from nerfacc_amd import pack_info
+    from nerfacc_amd.volrend import accumulate_along_rays, render_weight_from_density
+
+    g = torch.Generator(device=DEV).manual_seed(1)
+    R = 40000
+    cnts = torch.randint(0, 210, (R,), device=DEV, generator=g)
+    ri = torch.repeat_interleave(torch.arange(R, device=DEV), cnts)
+    N = ri.shape[0]
+    assert N > 2**21
+    ts = torch.rand(N, device=DEV, generator=g) * 4
+    te = ts + 5e-3
+    sig = torch.rand(N, device=DEV, generator=g) * 30
+    w, T, a = render_weight_from_density(ts, te, sig, ray_indices=ri)
+    opac = accumulate_along_rays(w, None, ri, R)[:, 0]
+    log_rem = torch.zeros(R, device=DEV, dtype=torch.float64).index_add_(0, ri, (-(sig * (te - ts))).double())
+    assert torch.allclose(opac.double(), 1.0 - torch.exp(log_rem), atol=2e-5)
+    same = ri[1:] == ri[:-1]
+    assert (T[1:][same] <= T[:-1][same] + 1e-7).all()
+    heads = torch.ones(N, dtype=torch.bool, device=DEV)
+    heads[1:] = ~same
+    assert (T[heads] == 1.0).all()
+    v = torch.rand(N, 3, device=DEV, generator=g)
+    lhs = accumulate_along_rays(w, 2 * v + 1, ri, R)
+    rhs = 2 * accumulate_along_rays(w, v, ri, R) + opac[:, None]
+    assert torch.allclose(lhs, rhs, atol=1e-5)
+    assert torch.equal(render_weight_from_density(ts, te, sig, ray_indices=ri)[0], w)
+    assert torch.equal(pack_info(ri, R)[:, 1], cnts)
