@@ -1,0 +1,340 @@
+"""bench.py — training rays/s + samples/s of the OccGrid sampling + rendering hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
+torch.distributed.run, one rank per GPU (RCCL).  W untimed steps, exactly K timed steps between
+barrier + synchronize, max over ranks, ONE JSON line from rank 0.
+
+Workload = BASELINE.json configs[1] (Instant-NGP + OccGridEstimator on nerf_synthetic/lego,
+examples/train_ngp_nerf_occ.py) with the two things that do not exist on this machine
+replaced and said so in the output (`data`, `config.workload`):
+  * dataset  -> procedural "lego-like" scene (union of boxes inside +-1.0 of the +-1.5 aabb),
+    100 cameras on a radius-4 sphere, 800x800, focal 1111.1 (nerf_synthetic.py:46-48,68-69),
+    white background; target pixels are rendered from the frozen initial field;
+  * tiny-cuda-nn hash-grid field -> a torch-native dense voxel field (128^3 density + colour
+    grids, trilinear `grid_sample`), 8.4 M parameters.
+Everything else follows the script: 128^3 occupancy grid on aabb +-1.5 refreshed every 16
+steps, render_step_size 5e-3, stratified sampling, early_stop_eps 1e-4, alpha_thre 0,
+rays/iter adapted so that ~2^18 samples are rendered per iteration
+(train_ngp_nerf_occ.py:58-78,166-203), Adam(lr 1e-2, eps 1e-15), grad scaler 2^10,
+smooth-L1 loss.  A step = update_every_n_steps + sampling (traversal, sigma_fn, visibility
+filter) + rendering forward + backward + optimizer step.
+
+Multi-GPU: each rank draws its own rays (weak scaling: per-GPU work is fixed),
+one flat all-reduce of the field gradients + one 16-byte all-reduce of the step's counts.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import nerfacc_amd as nerfacc  # noqa: E402
+from nerfacc_amd import sharding  # noqa: E402
+from nerfacc_amd.cuda import _backend  # noqa: E402
+
+AABB = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
+RENDER_STEP = 5e-3
+TARGET_SAMPLES = 1 << 18
+INIT_RAYS = 1024
+GRID_RES = 128
+HBM_PEAK_GBS = 8000.0
+
+
+# ------------------------------------------------------------------------------------------
+# procedural scene + torch-native field (stand-ins for nerf_synthetic/lego and tiny-cuda-nn)
+# ------------------------------------------------------------------------------------------
+def lego_like_density(x: torch.Tensor) -> torch.Tensor:
+    """analytic occupancy of a bulldozer-ish union of boxes; x [..., 3] in world units -> bool"""
+    def box(c, h):
+        c = torch.tensor(c, device=x.device)
+        h = torch.tensor(h, device=x.device)
+        return ((x - c).abs() <= h).all(-1)
+
+    body = box([0.0, 0.0, -0.25], [0.75, 0.45, 0.2])
+    cabin = box([-0.25, 0.0, 0.2], [0.3, 0.35, 0.25]) & ~box([-0.25, 0.0, 0.25], [0.22, 0.4, 0.12])
+    plate = box([0.0, 0.0, -0.55], [0.95, 0.7, 0.06])
+    arm = box([0.65, 0.0, 0.1], [0.35, 0.08, 0.08]) | box([0.95, 0.0, -0.1], [0.06, 0.4, 0.25])
+    studs = (torch.sin(x[..., 0] * 24.0) * torch.sin(x[..., 1] * 24.0) > 0.5) & box([0.0, 0.0, -0.45], [0.9, 0.65, 0.05])
+    return body | cabin | plate | arm | studs
+
+
+class DenseGridField(torch.nn.Module):
+    """sigma = exp(density_grid(x)), rgb = sigmoid(colour_grid(x)); trilinear lookups."""
+
+    def __init__(self, aabb, res=128):
+        super().__init__()
+        self.register_buffer("aabb", torch.tensor(aabb, dtype=torch.float32))
+        g = (torch.arange(res, dtype=torch.float32) + 0.5) / res
+        lo, hi = self.aabb[:3], self.aabb[3:]
+        X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
+        pts = torch.stack([X, Y, Z], -1) * (hi - lo) + lo
+        occ = lego_like_density(pts)
+        dens = torch.where(occ, math.log(50.0), math.log(1e-4)).float()
+        gen = torch.Generator().manual_seed(42)
+        col = torch.randn((3, res, res, res), generator=gen) * 0.5 + (pts.permute(3, 0, 1, 2) * 1.5)
+        self.density = torch.nn.Parameter(dens[None, None].contiguous())
+        self.color = torch.nn.Parameter(col[None].contiguous())
+
+    def _lookup(self, grid, x):
+        lo, hi = self.aabb[:3], self.aabb[3:]
+        u = ((x - lo) / (hi - lo)) * 2.0 - 1.0
+        u = u[:, [2, 1, 0]].view(1, 1, 1, -1, 3)        # grid_sample wants (z, y, x) for a [X, Y, Z] volume
+        out = F.grid_sample(grid, u, mode="bilinear", padding_mode="border", align_corners=False)
+        return out.view(grid.shape[1], -1).t()
+
+    def query_density(self, x):
+        return torch.exp(self._lookup(self.density, x))
+
+    def forward(self, x, dirs=None):
+        return torch.sigmoid(self._lookup(self.color, x)), self.query_density(x)
+
+
+def make_ray_pool(n_pool: int, seed: int, device) -> tuple:
+    """random pixels of 100 cameras on a radius-4 sphere looking at the origin (OpenGL camera,
+    800x800, focal 1111.1)."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    n_cams, W, focal = 100, 800, 0.5 * 800 / math.tan(0.5 * 0.6911112070083618)
+    cam_pos = torch.randn((n_cams, 3), generator=gen)
+    cam_pos[:, 2] = cam_pos[:, 2].abs() * 0.7 + 0.2                 # upper hemisphere like the dataset
+    cam_pos = 4.0 * cam_pos / cam_pos.norm(dim=-1, keepdim=True)
+    fwd = -cam_pos / cam_pos.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm(dim=-1, keepdim=True)
+    true_up = torch.linalg.cross(right, fwd)
+    cam = torch.randint(0, n_cams, (n_pool,), generator=gen)
+    px = torch.randint(0, W, (n_pool, 2), generator=gen).float() + 0.5
+    dx, dy = (px[:, 0] - W / 2) / focal, -(px[:, 1] - W / 2) / focal
+    d = fwd[cam] + dx[:, None] * right[cam] + dy[:, None] * true_up[cam]
+    d = d / d.norm(dim=-1, keepdim=True)
+    return cam_pos[cam].contiguous().to(device), d.contiguous().to(device)
+
+
+def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
+    """examples/utils.py:54-167 (render_image_with_occgrid), one chunk."""
+    def sigma_fn(t_starts, t_ends, ray_indices):
+        if t_starts.shape[0] == 0:
+            return torch.empty((0,), device=t_starts.device)
+        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+        return field.query_density(pos).squeeze(-1)
+
+    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+        if t_starts.shape[0] == 0:
+            return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
+        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+        rgb, sigma = field(pos, rays_d[ray_indices])
+        return rgb, sigma.squeeze(-1)
+
+    ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
+                                                 render_step_size=RENDER_STEP, stratified=training, cone_angle=0.0,
+                                                 alpha_thre=0.0)
+    rgb, opacity, depth, _ = nerfacc.rendering(t_starts, t_ends, ray_indices, n_rays=rays_o.shape[0],
+                                               rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
+    return rgb, opacity, depth, t_starts.shape[0]
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (single-threaded C port of the reference algorithm) on a bounded
+# sample of the same workload.  Only this function touches oracle/.
+# ------------------------------------------------------------------------------------------
+def cpu_baseline(field, est, pool_o, pool_d, n_rays=16384, budget_s=20.0):
+    import oracle
+
+    o = pool_o[:n_rays].cpu().numpy()
+    d = pool_d[:n_rays].cpu().numpy()
+    binaries = est.binaries.cpu().numpy()
+    aabbs = est.aabbs.cpu().numpy()
+    field_cpu = DenseGridField(AABB, GRID_RES)
+    field_cpu.load_state_dict({k: v.cpu() for k, v in field.state_dict().items()})
+
+    def once():
+        t_field = 0.0
+        t0 = time.perf_counter()
+        iv, sm, _ = oracle.traverse_grids(o, d, binaries, aabbs, np.zeros(n_rays, np.float32),
+                                          np.full(n_rays, 1e10, np.float32), RENDER_STEP, 0.0)
+        ts, te, ri = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], sm["ray_indices"]
+        tf = time.perf_counter()
+        with torch.no_grad():
+            pos = torch.from_numpy(o[ri] + d[ri] * ((ts + te)[:, None] / 2.0))
+            sig = field_cpu.query_density(pos).squeeze(-1).numpy()
+        t_field += time.perf_counter() - tf
+        _, T, a = oracle.render_weight_from_density(ts, te, sig, ri)
+        keep = oracle.visibility(T, a, 1e-4, 0.0)
+        ri, ts, te = ri[keep], ts[keep], te[keep]
+        tf = time.perf_counter()
+        with torch.no_grad():
+            pos = torch.from_numpy(o[ri] + d[ri] * ((ts + te)[:, None] / 2.0))
+            rgb, sig = field_cpu(pos)
+            rgb, sig = rgb.numpy(), sig.squeeze(-1).numpy()
+        t_field += time.perf_counter() - tf
+        col, opa, dep, ex = oracle.rendering(ts, te, ri, n_rays, sig, rgb, np.ones(3, np.float32))
+        gw = np.ascontiguousarray((rgb * col[ri]).sum(-1).astype(np.float32))      # stand-in for dL/dw
+        oracle.render_weight_from_density_bwd(ts, te, sig, ri, g_w=gw)
+        return time.perf_counter() - t0 - t_field, ri.shape[0]
+
+    once()
+    times, n_s = [], 0
+    t_begin = time.perf_counter()
+    while len(times) < 10 and time.perf_counter() - t_begin < budget_s:
+        dt, n_s = once()
+        times.append(dt)
+    med = float(np.median(times))
+    return {
+        "value": n_rays / med, "unit": "rays/s", "cores": 1, "kind": "port",
+        "samples_per_sec": n_s / med,
+        "sample": f"{n_rays} rays of the same pool/grid: oracle traversal + visibility + rendering fwd + weight bwd, "
+                  f"single thread, median of {len(times)}; radiance-field evaluation (torch CPU) excluded",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", type=int, default=1 << 21)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_size}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    torch.manual_seed(42)
+    field = DenseGridField(AABB, GRID_RES).to(device)
+    teacher = DenseGridField(AABB, GRID_RES).to(device).eval()
+    est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=GRID_RES, levels=1).to(device)
+    optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6)
+    loss_scale = 2.0**10
+    bkgd = torch.ones(3, device=device)
+
+    def occ_eval_fn(x):
+        return field.query_density(x) * RENDER_STEP
+
+    est.train()
+    with sharding.synchronized_rng(1234, device):
+        for _ in range(4):                       # bring the grid to its steady state before timing
+            est._update(step=0, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+
+    pool_o, pool_d = make_ray_pool(args.pool, seed=42 + rank, device=device)
+    est.eval()
+    with torch.no_grad():                        # target pixels from the frozen initial field
+        pool_rgb = torch.empty((args.pool, 3), device=device)
+        for i in range(0, args.pool, 1 << 16):
+            rgb, _, _, _ = render_rays(teacher, est, pool_o[i:i + (1 << 16)], pool_d[i:i + (1 << 16)], bkgd, False)
+            pool_rgb[i:i + (1 << 16)] = rgb
+    est.train()
+    torch.manual_seed(1000 + rank)
+
+    state = {"num_rays": INIT_RAYS, "step": 0}
+    stats = {"rays": 0, "samples": 0, "candidates": 0}
+
+    def train_step():
+        step = state["step"]
+        n = state["num_rays"]
+        idx = torch.randint(0, args.pool, (n,), device=device)
+        rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
+        if step % 16 == 0:
+            with sharding.synchronized_rng(5000 + step, device):
+                est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+        rgb, acc, depth, n_samples = render_rays(field, est, rays_o, rays_d, bkgd, True)
+        g_samples, g_rays = sharding.allreduce_counts(n_samples, n, device)
+        if g_samples > 0:
+            # train_ngp_nerf_occ.py:187-194, on the global counts so all ranks stay in step
+            state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
+        if n_samples > 0:
+            loss = F.smooth_l1_loss(rgb, pixels)
+            optimizer.zero_grad()
+            (loss * loss_scale).backward()
+            sharding.allreduce_gradients(field.parameters())
+            optimizer.step()
+        stats["rays"] += n
+        stats["samples"] += n_samples
+        state["step"] += 1
+
+    for _ in range(args.warmup):
+        train_step()
+
+    timer = _backend.KernelTimer(names=("traverse_fill",))
+    _backend.set_kernel_timer(timer)
+    stats.update(rays=0, samples=0)
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step()
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _backend.set_kernel_timer(None)
+
+    tot = torch.tensor([elapsed, float(stats["rays"]), float(stats["samples"])], dtype=torch.float64, device=device)
+    if world_size > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = mx[0].item()
+    total_rays, total_samples = tot[1].item(), tot[2].item()
+
+    if rank == 0:
+        # roofline of the dominant kernel of OUR path: traverse_fill_kernel (one launch per step).
+        # algorithmic bytes per launch: 16 B per emitted sample (ray_indices i64 +
+        # t_starts + t_ends) + 48 B per ray (o, d, near, far, start, count) + the bit-packed grid once.
+        n_launch, ms = timer.summary().get("traverse_fill", (0, 0.0))
+        rays_per_launch = stats["rays"] / max(args.steps, 1)
+        # candidates before the visibility filter are what the kernel writes; measure one batch
+        with torch.no_grad():
+            idx = torch.randint(0, args.pool, (int(rays_per_launch),), device=device)
+            cand = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
+        alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + GRID_RES**3 / 8
+        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out = {
+            "metric": "training rays/sec (+ samples/sec), NGP+OccGrid Lego 800x800",
+            "value": total_rays / elapsed,
+            "unit": "rays/s",
+            "samples_per_sec": total_samples / elapsed,
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1] lego stand-in: procedural lego-like scene, 100 cams 800x800, 128^3 OccGrid on aabb +-1.5, "
+                            "render_step 5e-3, ~2^18 rendered samples/iter/GPU, torch dense-grid field (tiny-cuda-nn absent)",
+                "rays_per_iter_per_gpu": rays_per_launch,
+                "samples_per_iter_per_gpu": stats["samples"] / max(args.steps, 1),
+                "candidate_samples_per_iter": cand,
+                "parallelism": f"rays sharded over {world_size} GPU(s), 1 flat grad all-reduce/step",
+            },
+            "roofline": {
+                "kernel": "traverse_fill_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": ms, "launches": n_launch, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "latency/divergence-bound by construction (16 B per sample, grid L2-resident): see DESIGN.md",
+            },
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(field, est, pool_o, pool_d)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

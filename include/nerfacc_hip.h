@@ -54,10 +54,12 @@ int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
                            const float *aabbs, int64_t n_aabbs, float near_plane, float far_plane,
                            float miss_value, float *t_mins, float *t_maxs, uint8_t *hits, void *stream);
 
-/* Bit-packed occupancy bricks.  The traversal kernels do not read the 1-byte-per-voxel
- * `binaries` tensor (occ_grid.py:72-75) directly: it is first packed into 4x4x4 bricks, one
- * uint64 per brick (bit = (x&3)*16 + (y&3)*4 + (z&3)), bricks x-major like the voxels.
- * nfa_packed_grid_words: number of uint64 words for [n_grids, rx, ry, rz]. */
+/* Packed occupancy.  The traversal kernels do not read the 1-byte-per-voxel `binaries` tensor
+ * (occ_grid.py:72-75) directly: it is first packed into 4x4x4 bricks, one uint64 per brick
+ * (bit = (x&3)*16 + (y&3)*4 + (z&3)), bricks x-major like the voxels, followed in the same
+ * buffer by a bitmap of the non-empty bricks, its rank prefix and the compacted non-empty
+ * bricks (the form the kernels stage into LDS).
+ * nfa_packed_grid_words: size of that buffer in uint64 words for [n_grids, rx, ry, rz]. */
 int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t rz);
 int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
                       uint64_t *bricks, void *stream);
@@ -92,7 +94,7 @@ typedef struct nfa_traverse_args {
      * iv_* describe interval edges (RaySegmentsSpec intervals), sm_* samples. iv pair nullable. */
     int64_t *iv_cnts, *iv_starts; /* [n_rays] */
     int64_t *sm_cnts, *sm_starts; /* [n_rays] */
-    int64_t *totals;            /* [2] = {n_edges, n_samples}; device-visible (pinned host ok) */
+    int64_t *totals;            /* [4] = {n_edges, n_samples, n_overflow_rays, 0}; device memory */
     /* fill outputs, each nullable (grid.cu:219-255) */
     float *iv_vals; int64_t *iv_ray_indices; uint8_t *iv_is_left; uint8_t *iv_is_right; /* [n_edges]; masks pre-zeroed */
     float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;                      /* [n_samples] */
@@ -101,14 +103,24 @@ typedef struct nfa_traverse_args {
     float *terminate_planes;    /* [n_rays] nullable */
 } nfa_traverse_args;
 
-/* pass 1 (grid.cu:413): per-ray counts, then their exclusive sums and the two totals.
+/* pass 1 (grid.cu:413): per-ray counts, then their exclusive sums and the totals; also writes
+ * terminate_planes when given.  Besides counting, pass 1 records each ray's samples as
+ * run-length records (lattice start, length) in `workspace`, which lets pass 2 emit them
+ * without touching the grid again.  totals[2] counts the rays whose runs did not fit (they are
+ * re-traversed by pass 2).
  * workspace: nfa_traverse_workspace_bytes(n_rays) bytes of device scratch. */
 int64_t nfa_traverse_workspace_bytes(int64_t n_rays);
 int nfa_traverse_count(const nfa_traverse_args *args, void *workspace, void *stream);
 /* pass 2 (grid.cu:445 / the single over-allocated pass :375): write edges / samples at
- * iv_starts / sm_starts.  `skip_empty`: skip rays whose stored count is 0 (grid.cu:103-106).
- * `rewrite_counts`: store the actual per-ray counts back (over-allocated mode, grid.cu:277-280). */
-int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t rewrite_counts, void *stream);
+ * iv_starts / sm_starts.
+ * workspace != NULL: the workspace nfa_traverse_count filled for the SAME args, with
+ *   n_samples = totals[1] and n_overflow = totals[2] as read back by the caller; one lane per
+ *   output sample (skip_empty / rewrite_counts must be 1 / 0, no rays_mask).
+ * workspace == NULL: the grid is traversed again, one lane per ray (n_samples / n_overflow
+ *   ignored).  `skip_empty`: skip rays whose stored count is 0 (grid.cu:103-106).
+ *   `rewrite_counts`: store the actual per-ray counts back (over-allocated mode, grid.cu:277-280). */
+int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t rewrite_counts,
+                      const void *workspace, int64_t n_samples, int64_t n_overflow, void *stream);
 
 /* chunk_starts = cumsum(cnts) - cnts, total -> *total (data_spec.hpp:86-106). total nullable. */
 int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream);

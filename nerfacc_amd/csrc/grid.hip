@@ -6,16 +6,25 @@
 // sample counts agree bit for bit (this file is compiled with -ffp-contract=off).
 //
 // MI355X mapping (DESIGN.md section "traversal"):
-//   * the 1-byte-per-voxel grid is repacked into 4x4x4 bricks of one uint64 (8x smaller:
-//     128^3 -> 256 KiB, L2-resident on every XCD); a ray keeps its current brick in two
-//     VGPRs, so a global load happens once per brick crossed instead of once per voxel;
-//   * one lane per ray, 256-thread workgroups, rays block-contiguous so that the per-ray
-//     counts of a wave are 64 consecutive int64 (coalesced) and a wave's samples form one
-//     contiguous output range;
-//   * counting and packing: pass 1 block-reduces its counts (wave shuffles + LDS), a second
-//     tiny kernel turns block sums into every ray's offset (exclusive sum) and the totals;
-//     pass 2 re-walks and writes.  One 16-byte readback per traverse_grids call.
+//   * occupancy: the 1-byte-per-voxel grid is repacked into 4x4x4 bricks of one uint64, plus a
+//     bitmap of non-empty bricks, its rank prefix and the compacted non-empty bricks.  A
+//     NeRF-like 128^3 grid is then ~4 KiB + 4 KiB + ~10-30 KiB and is staged into LDS by every
+//     workgroup, so the voxel walk never waits on global memory;
+//   * pass 1, one lane per ray: the DDA loop only walks voxels and appends occupied<->empty
+//     transitions to a per-lane LDS list.  All lattice arithmetic happens afterwards, once
+//     per transition, with the exact closed forms of lattice.hpp — under SIMT a rare
+//     expensive branch inside the voxel loop would be paid by the whole wave at almost every
+//     step, and a nested per-voxel lattice loop (the reference's shape) costs the slowest
+//     lane's trip count at every voxel;
+//   * pass 1 records every ray's samples as run-length records; block sums + a tiny second
+//     kernel give offsets and totals (one 32-byte readback per traverse_grids call);
+//   * pass 2, one lane per OUTPUT SAMPLE: binary-search the ray, pick the run, jump to the
+//     lattice point in closed form, store — fully coalesced, no grid access, no divergence.
+#include <mutex>
+#include <unordered_map>
+
 #include "common.hpp"
+#include "lattice.hpp"
 
 namespace nfa {
 
@@ -102,12 +111,23 @@ __device__ __forceinline__ bool dda_advance(Dda &s) {
     s.cz += s.sz; s.tz += s.dz; return s.cz != s.oz;
 }
 
-// grid.cu:157-161 / 199-203 (with the t + dt == t escape, see oracle)
+// grid.cu:157-161 / 199-203: advance the marching lattice, t += dt with dt fixed, until the
+// midpoint t + dt/2 reaches `target` (with the t + dt == t escape, see oracle).  The adds are
+// inherently sequential (bit-exact parity needs the same rounding chain), so the cost is in
+// the loop control: eight predicated steps per branch keep the wave out of divergent
+// short-trip loops.
 __device__ __forceinline__ float lattice_skip(float t, float dt, float target) {
-    while (t + dt * 0.5f < target) {
-        const float nt = t + dt;
-        if (nt == t) return target;
-        t = nt;
+    const float h = dt * 0.5f;
+    while (t + h < target) {
+        bool stuck = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool go = t + h < target;
+            const float nt = t + dt;
+            stuck = stuck || (go && nt == t);
+            t = go ? nt : t;
+        }
+        if (stuck) return target;
     }
     return t;
 }
@@ -133,39 +153,112 @@ __global__ __launch_bounds__(kBlock) void ray_aabb_kernel(
     }
 }
 
+
 // ----------------------------------------------------------------------------------------
-// brick packing: one wave-lane per brick; each lane gathers its 4x4x4 voxels (16 loads of
-// 4 contiguous bytes along z).  Runs once per grid update, 2 MiB read at 128^3.
+// occupancy packing.  Buffer layout (uint64 words), n_bricks = G * nbx * nby * nbz,
+// n_words = ceil(n_bricks / 32):
+//   [0, n_bricks)                       dense bricks (bit = (x&3)*16 + (y&3)*4 + (z&3))
+//   [n_bricks, +4)                      header: {n_compact, 0, 0, 0}
+//   then coarse[n_words] u32 (1 bit per brick), prefix[n_words] u32 (non-empty bricks before
+//   the word), each padded to 8 bytes, then compact[n_bricks] (the non-empty bricks in order).
 // ----------------------------------------------------------------------------------------
+struct PackedLayout {
+    int64_t n_bricks, n_words, off_header, off_coarse, off_prefix, off_compact, total_words;
+};
+__host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int ry, int rz) {
+    PackedLayout L;
+    L.n_bricks = (int64_t)n_grids * ((rx + 3) / 4) * ((ry + 3) / 4) * ((rz + 3) / 4);
+    L.n_words = (L.n_bricks + 31) / 32;
+    L.off_header = L.n_bricks;
+    L.off_coarse = L.off_header + 4;
+    L.off_prefix = L.off_coarse + (L.n_words + 1) / 2;
+    L.off_compact = L.off_prefix + (L.n_words + 1) / 2;
+    L.total_words = L.off_compact + L.n_bricks;
+    return L;
+}
+
+// one lane per brick: gather its 4x4x4 voxels (16 loads of 4 contiguous bytes along z); the
+// wave's ballot of "non-empty" is the coarse bitmap (two u32 words per wave).
 __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
     const uint8_t *__restrict__ binaries, int n_grids, int rx, int ry, int rz,
-    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks)
+    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse)
 {
     const int64_t per_grid = (int64_t)nbx * nby * nbz;
     const int64_t total = per_grid * n_grids;
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < total; b += (int64_t)gridDim.x * kBlock) {
-        const int64_t g = b / per_grid;
-        int64_t rem = b - g * per_grid;
-        const int bx = (int)(rem / ((int64_t)nby * nbz));
-        rem -= (int64_t)bx * nby * nbz;
-        const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
-        const uint8_t *grid = binaries + g * (int64_t)rx * ry * rz;
+    const int64_t rounded = (total + 63) / 64 * 64;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < rounded; b += (int64_t)gridDim.x * kBlock) {
         uint64_t bits = 0;
+        if (b < total) {
+            const int64_t g = b / per_grid;
+            int64_t rem = b - g * per_grid;
+            const int bx = (int)(rem / ((int64_t)nby * nbz));
+            rem -= (int64_t)bx * nby * nbz;
+            const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
+            const uint8_t *grid = binaries + g * (int64_t)rx * ry * rz;
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const int x = bx * 4 + dx;
+            for (int dx = 0; dx < 4; ++dx) {
+                const int x = bx * 4 + dx;
 #pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-                const int y = by * 4 + dy;
-                if (x >= rx || y >= ry) continue;
-                const uint8_t *row = grid + ((int64_t)x * ry + y) * rz + bz * 4;
+                for (int dy = 0; dy < 4; ++dy) {
+                    const int y = by * 4 + dy;
+                    if (x >= rx || y >= ry) continue;
+                    const uint8_t *row = grid + ((int64_t)x * ry + y) * rz + bz * 4;
 #pragma unroll
-                for (int dz = 0; dz < 4; ++dz) {
-                    if (bz * 4 + dz < rz && row[dz]) bits |= 1ull << (dx * 16 + dy * 4 + dz);
+                    for (int dz = 0; dz < 4; ++dz)
+                        if (bz * 4 + dz < rz && row[dz]) bits |= 1ull << (dx * 16 + dy * 4 + dz);
                 }
             }
+            bricks[b] = bits;
         }
-        bricks[b] = bits;
+        const unsigned long long any = __ballot(bits != 0ull);
+        const int lane = lane_id();
+        const int64_t w = b >> 5;                       // coarse word of this lane's brick
+        if ((lane & 31) == 0 && (b < total))
+            coarse[w] = (uint32_t)(lane ? (any >> 32) : any);
+    }
+}
+
+// rank prefix over the coarse words (single workgroup; n_words is 1024 for 128^3)
+__global__ __launch_bounds__(1024) void rank_bricks_kernel(const uint32_t *__restrict__ coarse, int64_t n_words,
+                                                           uint32_t *__restrict__ prefix, int64_t *__restrict__ header)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < n_words; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < n_words ? (uint32_t)__popc(coarse[i]) : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; if (w < wave) woff += x; tot += x; }
+        const uint32_t carry = carry_s;
+        if (i < n_words) prefix[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { header[0] = carry_s; header[1] = 0; header[2] = 0; header[3] = 0; }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_bricks_kernel(const uint64_t *__restrict__ bricks, int64_t n_bricks,
+                                                                const uint32_t *__restrict__ coarse,
+                                                                const uint32_t *__restrict__ prefix,
+                                                                uint64_t *__restrict__ compact)
+{
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < n_bricks; b += (int64_t)gridDim.x * kBlock) {
+        const uint64_t bits = bricks[b];
+        if (!bits) continue;
+        const uint32_t w = coarse[b >> 5];
+        compact[prefix[b >> 5] + __popc(w & ((1u << (b & 31)) - 1u))] = bits;
     }
 }
 
@@ -173,21 +266,67 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
 // K2: traversal
 // ----------------------------------------------------------------------------------------
 struct GridView {
-    const uint64_t *__restrict__ bricks;
+    const uint64_t *__restrict__ bricks;     // dense, global
+    const uint32_t *__restrict__ coarse;     // global copies of the sparse form
+    const uint32_t *__restrict__ prefix;
+    const uint64_t *__restrict__ compact;
+    const int64_t *__restrict__ header;
     int res[3];
     int nbx, nby, nbz;
-    int64_t bricks_per_grid;
+    int bricks_per_grid;
+    int n_words;
+    int lds_words;        // coarse/prefix words staged in LDS (0 = the sparse form stays global)
+    int lds_compact_cap;  // compact bricks staged in LDS
+};
+
+// per-workgroup LDS image of the sparse occupancy
+struct OccLds {
+    const uint32_t *coarse;
+    const uint32_t *prefix;
+    const uint64_t *compact;
+    int cap;
 };
 
 struct BrickCache {
-    int64_t id;
+    int id;
     uint64_t bits;
 };
 
-__device__ __forceinline__ bool occupied(const GridView &g, BrickCache &c, int level, int x, int y, int z) {
-    const int64_t id = (((int64_t)(x >> 2) * g.nby + (y >> 2)) * g.nbz + (z >> 2)) + level * g.bricks_per_grid;
-    if (id != c.id) { c.bits = g.bricks[id]; c.id = id; }
+// occupancy of voxel (x,y,z) through the sparse form; the brick is re-resolved only when the
+// voxel walk enters another brick.
+__device__ __forceinline__ bool occupied(const GridView &g, const OccLds &l, BrickCache &c, int level, int x, int y, int z) {
+    const int id = ((x >> 2) * g.nby + (y >> 2)) * g.nbz + (z >> 2) + level * g.bricks_per_grid;
+    if (id != c.id) {
+        c.id = id;
+        const uint32_t w = l.coarse[id >> 5];
+        const uint32_t bit = 1u << (id & 31);
+        uint64_t bits = 0;
+        if (w & bit) {
+            const int k = (int)l.prefix[id >> 5] + __popc(w & (bit - 1u));
+            bits = (k < l.cap) ? l.compact[k] : g.compact[k];
+        }
+        c.bits = bits;
+    }
     return (c.bits >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull;
+}
+
+// stage the sparse occupancy into LDS (all threads of the block; ends with a barrier)
+__device__ __forceinline__ OccLds stage_occupancy(const GridView &g, char *smem) {
+    OccLds l;
+    if (g.lds_words == 0) {
+        l.coarse = g.coarse; l.prefix = g.prefix; l.compact = g.compact; l.cap = 0x7fffffff;
+        return l;
+    }
+    uint32_t *lc = (uint32_t *)smem;
+    uint32_t *lp = lc + ((g.lds_words + 3) & ~3);
+    uint64_t *lb = (uint64_t *)(lp + ((g.lds_words + 3) & ~3));
+    for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) { lc[i] = g.coarse[i]; lp[i] = g.prefix[i]; }
+    int n_compact = (int)g.header[0];
+    if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
+    for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
+    __syncthreads();
+    l.coarse = lc; l.prefix = lp; l.compact = lb; l.cap = n_compact;
+    return l;
 }
 
 // sorted ray/grid events: either the caller's arrays or computed in-kernel
@@ -211,19 +350,30 @@ struct Events<true> {
 
 template <>
 struct Events<false> {
-    // grid.py:156-162 done per ray in registers/scratch: slab test against every level with
-    // near = -inf, far = +inf, miss = +inf, then an ascending stable sort of the 2G times.
+    // grid.py:156-162 done per ray: slab test against every level with near = -inf,
+    // far = +inf, miss = +inf, then an ascending stable sort of the 2G times.  One level
+    // (the Lego configuration) needs no sort and stays in registers.
     float t[2 * NFA_MAX_GRID_LEVELS];
     int id[2 * NFA_MAX_GRID_LEVELS];
     bool hit[NFA_MAX_GRID_LEVELS];
+    float t0_1, t1_1;
+    bool hit_1, single;
     __device__ __forceinline__ void init(const nfa_traverse_args &a, int64_t, const float *o, const float *inv) {
         const int G = a.n_grids;
+        single = (G == 1);
+        if (single) {
+            t0_1 = t1_1 = INFINITY;
+            float x0 = 0.f, x1 = 0.f;
+            hit_1 = slab_test(o, inv, a.aabbs, -INFINITY, INFINITY, x0, x1);
+            if (hit_1) { t0_1 = x0; t1_1 = x1; }
+            return;
+        }
         for (int g = 0; g < G; ++g) {
-            float t0 = 0.f, t1 = 0.f;
-            const bool h = slab_test(o, inv, a.aabbs + 6 * g, -INFINITY, INFINITY, t0, t1);
+            float x0 = 0.f, x1 = 0.f;
+            const bool h = slab_test(o, inv, a.aabbs + 6 * g, -INFINITY, INFINITY, x0, x1);
             hit[g] = h;
-            t[g] = h ? t0 : INFINITY;
-            t[G + g] = h ? t1 : INFINITY;
+            t[g] = h ? x0 : INFINITY;
+            t[G + g] = h ? x1 : INFINITY;
             id[g] = g;
             id[G + g] = G + g;
         }
@@ -236,16 +386,105 @@ struct Events<false> {
             id[j + 1] = iv;
         }
     }
-    __device__ __forceinline__ bool hits(int level) const { return hit[level]; }
-    __device__ __forceinline__ float time(int i) const { return t[i]; }
-    __device__ __forceinline__ int index(int i) const { return id[i]; }
+    __device__ __forceinline__ bool hits(int level) const { return single ? hit_1 : hit[level]; }
+    __device__ __forceinline__ float time(int i) const { return single ? (i == 0 ? t0_1 : t1_1) : t[i]; }
+    __device__ __forceinline__ int index(int i) const { return single ? i : id[i]; }
 };
 
-// One ray of grid.cu:95-281.  FILL=false counts, FILL=true writes at the given offsets.
-template <bool FILL, bool PRECOMPUTED>
-__device__ __forceinline__ void traverse_ray(
-    const nfa_traverse_args &a, const GridView &gv, int64_t r,
-    int64_t iv_base, int64_t sm_base, int64_t &n_iv_out, int64_t &n_sm_out, float &t_term)
+// resolve the grid level and clipped [seg_lo, seg_hi) between sorted events i and i+1
+// (grid.cu:131-150); false = nothing to traverse there
+template <class Ev>
+__device__ __forceinline__ bool segment_of(const Ev &ev, int i, int G, float near, float far, int &level, float &lo, float &hi) {
+    const int e = ev.index(i);
+    level = e % G;
+    if (!ev.hits(level)) return false;
+    if (e >= G) {                                   // leaving `level`: are we inside another grid?
+        const int e1 = ev.index(i + 1);
+        if (e1 < G) return false;
+        level = e1 % G;
+        if (!ev.hits(level)) return false;
+    }
+    lo = fmaxf(ev.time(i), near);
+    hi = fminf(ev.time(i + 1), far);
+    return lo < hi;
+}
+
+// ---- run-length records (pass 1 -> pass 2) -------------------------------------------------
+// All samples of a ray sit on its marching lattice, so a maximal run of consecutive samples is
+// described by the lattice point it starts at (the exact float) and its length.  kMaxRuns runs
+// per ray, laid out [run][ray] so a wave's lanes touch consecutive words; a ray with more runs
+// (or step_size <= 0, where edges come from voxel faces) is flagged and re-traversed in pass 2.
+constexpr int kMaxRuns = 14;
+constexpr int kRunsOverflow = 255;
+
+struct RunStore {
+    float *t0;        // [kMaxRuns][R]
+    int32_t *len;     // [kMaxRuns][R]
+    uint8_t *n_runs;  // [R]
+};
+
+struct CountSink {
+    RunStore rs;
+    int64_t r, R;
+    int64_t n_iv = 0, n_sm = 0;
+    int n_runs = 0, cur_len = 0;
+    // k consecutive samples starting at lattice point t0
+    __device__ __forceinline__ void run(float t0, int64_t k, bool continuous) {
+        if (k <= 0) return;
+        n_iv += continuous ? k : k + 1;
+        n_sm += k;
+        if (!rs.t0) return;
+        if (continuous) { cur_len += (int)k; return; }
+        close_run();
+        if (n_runs < kMaxRuns) rs.t0[(int64_t)n_runs * R + r] = t0;
+        n_runs += 1;
+        cur_len = (int)k;
+    }
+    __device__ __forceinline__ void sample(float t0, float, bool continuous) { run(t0, 1, continuous); }
+    __device__ __forceinline__ void close_run() {
+        if (n_runs >= 1 && n_runs <= kMaxRuns) rs.len[(int64_t)(n_runs - 1) * R + r] = cur_len;
+    }
+    // returns true when the ray needs the re-traversal fallback
+    __device__ __forceinline__ bool finish(bool replayable) {
+        if (!rs.t0) return false;
+        close_run();
+        const bool overflow = (n_sm > 0) && (n_runs > kMaxRuns || !replayable);
+        rs.n_runs[r] = (uint8_t)(overflow ? kRunsOverflow : n_runs);
+        return overflow;
+    }
+};
+
+struct FillSink {
+    const nfa_traverse_args &a;
+    int64_t r, iv_base, sm_base;
+    int64_t n_iv = 0, n_sm = 0;
+    __device__ __forceinline__ void sample(float t0, float t1, bool continuous) {
+        if (a.iv_vals) {
+            const int64_t k = iv_base + n_iv;
+            if (!continuous) {
+                a.iv_vals[k] = t0;      a.iv_ray_indices[k] = r;     a.iv_is_left[k] = 1;
+                a.iv_vals[k + 1] = t1;  a.iv_ray_indices[k + 1] = r; a.iv_is_right[k + 1] = 1;
+            } else {
+                a.iv_vals[k] = t1;      a.iv_ray_indices[k] = r;
+                a.iv_is_left[k - 1] = 1; a.iv_is_right[k] = 1;
+            }
+        }
+        const int64_t k = sm_base + n_sm;
+        if (a.sm_vals) a.sm_vals[k] = (t1 + t0) * 0.5f;
+        if (a.sm_ray_indices) a.sm_ray_indices[k] = r;
+        if (a.sm_is_valid) a.sm_is_valid[k] = 1;
+        if (a.t_starts) { a.t_starts[k] = t0; a.t_ends[k] = t1; }
+        n_iv += continuous ? 1 : 2;
+        n_sm += 1;
+    }
+};
+
+// ---- general walk: any step_size / cone_angle; the reference's loop shape (grid.cu:95-281).
+// Used for cone_angle != 0, step_size <= 0, the over-allocated test-time pass and as the
+// pass-2 fallback of rays whose runs did not fit.
+template <class Sink, bool PRECOMPUTED>
+__device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a, const GridView &gv, const OccLds &occ,
+                                                     int64_t r, Sink &sink, float &t_term)
 {
     const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
     const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
@@ -258,7 +497,6 @@ __device__ __forceinline__ void traverse_ray(
     Events<PRECOMPUTED> ev;
     ev.init(a, r, o, inv);
 
-    int64_t n_iv = 0, n_sm = 0;
     float t_last = near;
     bool continuous = false;
     BrickCache cache;
@@ -266,35 +504,23 @@ __device__ __forceinline__ void traverse_ray(
     cache.bits = 0;
 
     for (int i = 0; i + 1 < 2 * G; ++i) {
-        int e = ev.index(i);
-        int level = e % G;
-        if (!ev.hits(level)) continue;
-        if (e >= G) {                               // leaving `level`: are we inside another grid?
-            const int e1 = ev.index(i + 1);
-            if (e1 < G) continue;
-            level = e1 % G;
-            if (!ev.hits(level)) continue;
-        }
-        const float seg_lo = fmaxf(ev.time(i), near);
-        const float seg_hi = fminf(ev.time(i + 1), far);
-        if (seg_lo >= seg_hi) continue;
-
+        int level;
+        float seg_lo, seg_hi;
+        if (!segment_of(ev, i, G, near, far, level, seg_lo, seg_hi)) continue;
         if (!continuous) {
             if (step_size <= 0.0f) t_last = seg_lo;
             else t_last = lattice_skip(t_last, march_dt(t_last, cone, step_size), seg_lo);
         }
-
         Dda s;
         dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
-
-        while (limit <= 0 || n_sm < limit) {
+        while (limit <= 0 || sink.n_sm < limit) {
             const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-            if (!occupied(gv, cache, level, s.cx, s.cy, s.cz)) {
+            if (!occupied(gv, occ, cache, level, s.cx, s.cy, s.cz)) {
                 if (step_size <= 0.0f) t_last = t_cell;
                 else t_last = lattice_skip(t_last, march_dt(t_last, cone, step_size), t_cell);
                 continuous = false;
             } else {
-                while (limit <= 0 || n_sm < limit) {
+                while (limit <= 0 || sink.n_sm < limit) {
                     float t_next;
                     if (step_size <= 0.0f) t_next = t_cell;
                     else {
@@ -302,25 +528,7 @@ __device__ __forceinline__ void traverse_ray(
                         if (t_last + dt * 0.5f >= t_cell) break;
                         t_next = t_last + dt;
                     }
-                    if (FILL) {
-                        if (a.iv_vals) {
-                            const int64_t k = iv_base + n_iv;
-                            if (!continuous) {
-                                a.iv_vals[k] = t_last;      a.iv_ray_indices[k] = r;     a.iv_is_left[k] = 1;
-                                a.iv_vals[k + 1] = t_next;  a.iv_ray_indices[k + 1] = r; a.iv_is_right[k + 1] = 1;
-                            } else {
-                                a.iv_vals[k] = t_next;      a.iv_ray_indices[k] = r;
-                                a.iv_is_left[k - 1] = 1;    a.iv_is_right[k] = 1;
-                            }
-                        }
-                        const int64_t k = sm_base + n_sm;
-                        if (a.sm_vals) a.sm_vals[k] = (t_next + t_last) * 0.5f;
-                        if (a.sm_ray_indices) a.sm_ray_indices[k] = r;
-                        if (a.sm_is_valid) a.sm_is_valid[k] = 1;
-                        if (a.t_starts) { a.t_starts[k] = t_last; a.t_ends[k] = t_next; }
-                    }
-                    n_iv += continuous ? 1 : 2;
-                    n_sm += 1;
+                    sink.sample(t_last, t_next, continuous);
                     continuous = true;
                     t_last = t_next;
                     if (t_next >= t_cell) break;
@@ -329,8 +537,110 @@ __device__ __forceinline__ void traverse_ray(
             if (!dda_advance(s)) break;
         }
     }
-    n_iv_out = n_iv;
-    n_sm_out = n_sm;
+    t_term = t_last;
+}
+
+// ---- lattice walk: step_size > 0 and cone_angle == 0 (the training configuration) ----------
+// dt is one constant, so (a) consecutive empty voxels are ONE lattice jump to the far side of
+// the last one and consecutive occupied voxels ONE batch of samples up to the exit of the last
+// one (voxel exit times never decrease, and the reference's per-voxel conditions are monotone
+// in t), and (b) jumps and batches have the closed forms of lattice.hpp.  The voxel loop only
+// records run boundaries; they are consumed afterwards, all lanes in step.
+constexpr int kEvCap = 16;   // run boundaries buffered per lane and round
+
+template <bool PRECOMPUTED>
+__device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a, const GridView &gv, const OccLds &occ,
+                                                     float *__restrict__ ev_lds /* [kEvCap][blockDim] */,
+                                                     int64_t r, bool active, CountSink &sink, float &t_term)
+{
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {1.f, 1.f, 1.f};
+    float near = 0.f, far = 0.f;
+    if (active) {
+        o[0] = a.rays_o[3 * r]; o[1] = a.rays_o[3 * r + 1]; o[2] = a.rays_o[3 * r + 2];
+        d[0] = a.rays_d[3 * r]; d[1] = a.rays_d[3 * r + 1]; d[2] = a.rays_d[3 * r + 2];
+        near = a.near_planes[r];
+        far = a.far_planes[r];
+    }
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const float dt = march_dt(0.0f, 0.0f, a.step_size);     // = clamp(step_size, ., 1e10)
+    const int limit = a.traverse_steps_limit;
+    const int G = a.n_grids;
+    const int nthr = blockDim.x, tid = threadIdx.x;
+
+    Events<PRECOMPUTED> ev;
+    if (active) ev.init(a, r, o, inv);
+
+    float t_last = near;
+    bool continuous = false, finished = !active;
+    BrickCache cache;
+    cache.id = -1;
+    cache.bits = 0;
+
+    for (int i = 0; i + 1 < 2 * G; ++i) {
+        int level = 0;
+        float seg_lo = 0.f, seg_hi = 0.f;
+        bool seg_live = !finished && segment_of(ev, i, G, near, far, level, seg_lo, seg_hi);
+        if (seg_live && !continuous) {
+            int64_t k; bool stuck;
+            t_last = nfa_lattice_until(t_last, dt, seg_lo, &k, &stuck);
+            if (stuck) t_last = seg_lo;
+        }
+        Dda s;
+        if (seg_live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
+        bool have_run = false, run_occ = false;
+        float run_exit = 0.f;
+        while (__any(seg_live)) {
+            // ---- A: voxel walk, boundaries only
+            int n_ev = 0;
+            unsigned ev_occ = 0;
+            while (seg_live && n_ev < kEvCap - 1) {
+                const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+                const bool oc = occupied(gv, occ, cache, level, s.cx, s.cy, s.cz);
+                if (have_run && oc != run_occ) {
+                    ev_lds[n_ev * nthr + tid] = run_exit;
+                    ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+                    ++n_ev;
+                }
+                have_run = true;
+                run_occ = oc;
+                run_exit = t_cell;
+                if (!dda_advance(s)) seg_live = false;
+            }
+            if (!seg_live && have_run) {            // the segment's last run
+                ev_lds[n_ev * nthr + tid] = run_exit;
+                ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+                ++n_ev;
+                have_run = false;
+            }
+            // ---- B: lattice arithmetic, one boundary per lane per iteration
+            int n_max = n_ev;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+            for (int j = 0; j < n_max; ++j) {
+                if (j >= n_ev || finished) continue;
+                const float bound = ev_lds[j * nthr + tid];
+                int64_t k; bool stuck;
+                const float t_new = nfa_lattice_until(t_last, dt, bound, &k, &stuck);
+                if ((ev_occ >> j) & 1u) {
+                    if (limit > 0 && sink.n_sm + k >= limit) {        // grid.cu:184,208
+                        k = limit - sink.n_sm;
+                        sink.run(t_last, k, continuous);
+                        t_last = nfa_lattice_advance(t_last, dt, k, nullptr);
+                        if (k > 0) continuous = true;
+                        finished = true;
+                        seg_live = false;
+                    } else {
+                        sink.run(t_last, k, continuous);
+                        if (k > 0) continuous = true;
+                        t_last = t_new;
+                    }
+                } else {
+                    continuous = false;
+                    t_last = stuck ? bound : t_new;
+                }
+            }
+        }
+    }
     t_term = t_last;
 }
 
@@ -340,23 +650,9 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;   // valid in lane 0
 }
 
-// pass 1.  Block b owns rays [256 b, 256 b + 256).  block_sums[2 b + {0,1}] = this block's
-// {edge, sample} totals.
-template <bool PRECOMPUTED>
-__global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_args a, GridView gv,
-                                                                int64_t *__restrict__ block_sums)
-{
+// block-level reduction of the per-ray counts -> block_sums[2 b + {0,1}]
+__device__ __forceinline__ void publish_block_sums(int64_t n_iv, int64_t n_sm, int64_t *__restrict__ block_sums) {
     __shared__ int64_t part[2][kWavesPerBlock];
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    int64_t n_iv = 0, n_sm = 0;
-    if (r < a.n_rays && !(a.rays_mask && !a.rays_mask[r])) {
-        float t_term;
-        traverse_ray<false, PRECOMPUTED>(a, gv, r, 0, 0, n_iv, n_sm, t_term);
-    }
-    if (r < a.n_rays) {
-        if (a.iv_cnts) a.iv_cnts[r] = n_iv;
-        a.sm_cnts[r] = n_sm;
-    }
     const int64_t w_iv = wave_sum_i64(n_iv), w_sm = wave_sum_i64(n_sm);
     const int wave = threadIdx.x >> 6;
     if (lane_id() == 0) { part[0][wave] = w_iv; part[1][wave] = w_sm; }
@@ -367,6 +663,36 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
         block_sums[2 * blockIdx.x] = s0;
         block_sums[2 * blockIdx.x + 1] = s1;
     }
+}
+
+// pass 1.  Block b owns rays [256 b, 256 b + 256).
+template <bool PRECOMPUTED, bool LATTICE>
+__global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_args a, GridView gv,
+                                                                int64_t *__restrict__ block_sums, RunStore rs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OccLds occ = stage_occupancy(gv, smem);
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = r < a.n_rays && !(a.rays_mask && !a.rays_mask[r]);
+    CountSink sink{rs, r, a.n_rays};
+    float t_term = 0.f;
+    if (LATTICE) {
+        // the boundary lists sit behind the occupancy image in LDS
+        const int occ_bytes = gv.lds_words ? (2 * ((gv.lds_words + 3) & ~3) * 4 + gv.lds_compact_cap * 8) : 0;
+        float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));
+        traverse_ray_lattice<PRECOMPUTED>(a, gv, occ, ev_lds, r, active, sink, t_term);
+    } else if (active) {
+        traverse_ray_general<CountSink, PRECOMPUTED>(a, gv, occ, r, sink, t_term);
+    }
+    if (r < a.n_rays) {
+        if (active) {
+            if (sink.finish(a.step_size > 0.0f)) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
+            if (a.terminate_planes) a.terminate_planes[r] = t_term;
+        } else if (rs.n_runs) rs.n_runs[r] = 0;
+        if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
+        a.sm_cnts[r] = sink.n_sm;
+    }
+    publish_block_sums(sink.n_iv, sink.n_sm, block_sums);
 }
 
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
@@ -403,7 +729,6 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     __shared__ int64_t lds[kWavesPerBlock];
     __shared__ int64_t base[2];
     const int b = blockIdx.x;
-    // prefix over earlier blocks
     int64_t p0 = 0, p1 = 0;
     for (int j = threadIdx.x; j < b; j += kBlock) { p0 += block_sums[2 * j]; p1 += block_sums[2 * j + 1]; }
     int64_t t0, t1;
@@ -428,31 +753,70 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     }
 }
 
-// pass 2
+// pass 2, general form: walk the grid again and write.  Also the single pass of the
+// over-allocated test-time mode (grid.cu:375).  only_overflow: just the rays pass 1 flagged.
 template <bool PRECOMPUTED>
 __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args a, GridView gv,
-                                                               int skip_empty, int rewrite_counts)
+                                                               int skip_empty, int rewrite_counts,
+                                                               const uint8_t *__restrict__ only_overflow)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OccLds occ = stage_occupancy(gv, smem);
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= a.n_rays) return;
     if (a.rays_mask && !a.rays_mask[r]) return;
+    if (only_overflow && only_overflow[r] != kRunsOverflow) return;
     if (skip_empty) {
         if (a.iv_cnts && a.iv_cnts[r] == 0) return;
         if (a.sm_cnts[r] == 0) return;
     }
-    int64_t n_iv, n_sm;
+    FillSink sink{a, r, a.iv_starts ? a.iv_starts[r] : 0, a.sm_starts[r]};
     float t_term;
-    traverse_ray<true, PRECOMPUTED>(a, gv, r, a.iv_starts ? a.iv_starts[r] : 0, a.sm_starts[r], n_iv, n_sm, t_term);
-    if (a.terminate_planes) a.terminate_planes[r] = t_term;
+    traverse_ray_general<FillSink, PRECOMPUTED>(a, gv, occ, r, sink, t_term);
+    if (a.terminate_planes && !only_overflow) a.terminate_planes[r] = t_term;
     if (rewrite_counts) {
-        if (a.iv_cnts) a.iv_cnts[r] = n_iv;
-        a.sm_cnts[r] = n_sm;
+        if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
+        a.sm_cnts[r] = sink.n_sm;
+    }
+}
+
+// pass 2, fast form: ONE LANE PER OUTPUT SAMPLE.  sample s -> ray (binary search in the
+// exclusive offsets) -> run (<= kMaxRuns lengths) -> lattice point (closed form) -> coalesced
+// stores of ray_indices / t_starts / t_ends (+ interval edges when asked for).
+__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t n_samples)
+{
+    const float step_size = a.step_size, cone = a.cone_angle;
+    const int64_t R = a.n_rays;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n_samples; s += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = 0, hi = R;                       // last ray with sm_starts <= s
+        while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (a.sm_starts[m] <= s) lo = m + 1; else hi = m; }
+        const int64_t r = lo - 1;
+        const int n_runs = rs.n_runs[r];
+        if (n_runs == kRunsOverflow) continue;        // written by the fallback launch
+        int64_t j = s - a.sm_starts[r];
+        int q = 0, len = rs.len[r];
+        while (j >= len) { j -= len; ++q; len = rs.len[(int64_t)q * R + r]; }
+        float t0 = rs.t0[(int64_t)q * R + r];
+        if (cone == 0.0f) t0 = nfa_lattice_advance(t0, march_dt(t0, cone, step_size), j, nullptr);
+        else for (int64_t k = 0; k < j; ++k) t0 = t0 + march_dt(t0, cone, step_size);
+        const float t1 = t0 + march_dt(t0, cone, step_size);
+        if (a.sm_vals) a.sm_vals[s] = (t1 + t0) * 0.5f;
+        if (a.sm_ray_indices) a.sm_ray_indices[s] = r;
+        if (a.sm_is_valid) a.sm_is_valid[s] = 1;
+        if (a.t_starts) { a.t_starts[s] = t0; a.t_ends[s] = t1; }
+        if (a.iv_vals) {
+            // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
+            const int64_t e_right = a.iv_starts[r] + (s - a.sm_starts[r]) + q + 1;
+            a.iv_vals[e_right] = t1; a.iv_ray_indices[e_right] = r; a.iv_is_right[e_right] = 1;
+            a.iv_is_left[e_right - 1] = 1;
+            if (j == 0) { a.iv_vals[e_right - 1] = t0; a.iv_ray_indices[e_right - 1] = r; }
+        }
     }
 }
 
 // generic exclusive sum of int64 counts (data_spec.hpp:86-106), single workgroup of 1024:
-// rounds of 1024 coalesced elements with a running carry.  Used for the small per-ray count
-// arrays of the over-allocated traversal mode only.
+// rounds of 1024 coalesced elements with a running carry.  Used for the per-ray count arrays
+// of the over-allocated traversal mode and the tile counts of the visibility compaction.
 __global__ __launch_bounds__(1024) void excl_sum_i64_kernel(const int64_t *__restrict__ cnts, int64_t n,
                                                             int64_t *__restrict__ starts, int64_t *__restrict__ total)
 {
@@ -497,15 +861,65 @@ int validate_traverse(const nfa_traverse_args *a) {
     return NFA_OK;
 }
 
-GridView make_view(const nfa_traverse_args *a) {
+// LDS budget of the traversal kernels: occupancy image + boundary lists
+constexpr int kLdsBudget = 96 * 1024;
+constexpr int kEvBytes = kEvCap * kBlock * 4;
+
+GridView make_view(const nfa_traverse_args *a, int *lds_bytes) {
     GridView gv;
+    const PackedLayout L = packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]);
     gv.bricks = a->bricks;
+    gv.header = (const int64_t *)(a->bricks + L.off_header);
+    gv.coarse = (const uint32_t *)(a->bricks + L.off_coarse);
+    gv.prefix = (const uint32_t *)(a->bricks + L.off_prefix);
+    gv.compact = a->bricks + L.off_compact;
     for (int k = 0; k < 3; ++k) gv.res[k] = a->res[k];
     gv.nbx = (a->res[0] + 3) / 4;
     gv.nby = (a->res[1] + 3) / 4;
     gv.nbz = (a->res[2] + 3) / 4;
-    gv.bricks_per_grid = (int64_t)gv.nbx * gv.nby * gv.nbz;
+    gv.bricks_per_grid = gv.nbx * gv.nby * gv.nbz;
+    gv.n_words = (int)L.n_words;
+    const int64_t words_bytes = 2 * (((int64_t)L.n_words + 3) & ~3ll) * 4;
+    const int64_t room = (int64_t)kLdsBudget - kEvBytes - 16 - words_bytes;
+    if (room >= 4096) {
+        gv.lds_words = (int)L.n_words;
+        int64_t cap = room / 8;
+        if (cap > L.n_bricks) cap = L.n_bricks;
+        gv.lds_compact_cap = (int)cap;
+        *lds_bytes = (int)(((words_bytes + cap * 8 + 15) & ~15ll) + kEvBytes);
+    } else {                                      // bitmap too large for LDS: everything from L2
+        gv.lds_words = 0;
+        gv.lds_compact_cap = 0;
+        *lds_bytes = kEvBytes;
+    }
     return gv;
+}
+
+// workspace layout (bytes): [ block_sums: 2*nb int64 ][ run t0: kMaxRuns*R f32 ][ run len: kMaxRuns*R i32 ][ n_runs: R u8 ]
+inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 16 * ceil_div(n_rays > 0 ? n_rays : 1, kBlock); }
+RunStore make_runs(void *workspace, int64_t n_rays) {
+    RunStore rs;
+    uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
+    rs.t0 = (float *)p;
+    rs.len = (int32_t *)(p + (int64_t)kMaxRuns * n_rays * 4);
+    rs.n_runs = p + (int64_t)kMaxRuns * n_rays * 8;
+    return rs;
+}
+
+// raise a kernel's dynamic-LDS limit once per (kernel, size) — it is a host-side driver call
+template <class K>
+int allow_lds(K kernel, int bytes) {
+    if (bytes <= 48 * 1024) return NFA_OK;
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    int &g = granted[(const void *)kernel];
+    if (bytes > g) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return fail(NFA_ERR_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+        g = bytes;
+    }
+    return NFA_OK;
 }
 
 }  // namespace
@@ -513,7 +927,7 @@ GridView make_view(const nfa_traverse_args *a) {
 
 using namespace nfa;
 
-NFA_EXPORT const char *nfa_version(void) { return "nerfacc_hip 0.1.0 gfx950"; }
+NFA_EXPORT const char *nfa_version(void) { return "nerfacc_hip 0.3.0 gfx950"; }
 NFA_EXPORT const char *nfa_last_error(void) { return last_error_buffer(); }
 
 NFA_EXPORT int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays,
@@ -531,60 +945,98 @@ NFA_EXPORT int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, 
 
 NFA_EXPORT int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t rz) {
     if (n_grids <= 0 || rx <= 0 || ry <= 0 || rz <= 0) return 0;
-    return (int64_t)n_grids * ((rx + 3) / 4) * ((ry + 3) / 4) * ((rz + 3) / 4);
+    return packed_layout(n_grids, rx, ry, rz).total_words;
 }
 
 NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
                                  uint64_t *bricks, void *stream)
 {
-    const int64_t words = nfa_packed_grid_words(n_grids, rx, ry, rz);
-    NFA_REQUIRE(words > 0, "pack_binaries: empty grid");
+    NFA_REQUIRE(n_grids > 0 && rx > 0 && ry > 0 && rz > 0, "pack_binaries: empty grid");
     NFA_REQUIRE(binaries && bricks, "pack_binaries: NULL pointer");
-    hipLaunchKernelGGL(pack_bricks_kernel, dim3(blocks_for(words)), dim3(kBlock), 0, (hipStream_t)stream,
-                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks);
-    return check_launch("pack_bricks_kernel");
+    const PackedLayout L = packed_layout(n_grids, rx, ry, rz);
+    NFA_REQUIRE(L.n_bricks < (1ll << 31), "pack_binaries: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
+    uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
+    hipLaunchKernelGGL(pack_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse);
+    if (int rc = check_launch("pack_bricks_kernel")) return rc;
+    hipLaunchKernelGGL(rank_bricks_kernel, dim3(1), dim3(1024), 0, s, coarse, L.n_words, prefix, (int64_t *)(bricks + L.off_header));
+    if (int rc = check_launch("rank_bricks_kernel")) return rc;
+    hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+                       bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
+    return check_launch("compact_bricks_kernel");
 }
 
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
-    return 2 * (int64_t)sizeof(int64_t) * (ceil_div(n_rays > 0 ? n_rays : 1, kBlock));
+    const int64_t R = n_rays > 0 ? n_rays : 1;
+    return ws_block_sums_bytes(R) + (int64_t)kMaxRuns * R * 8 + ceil_div(R, 16) * 16;
 }
 
 NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, void *stream)
 {
     if (int rc = validate_traverse(a)) return rc;
     NFA_REQUIRE(a->totals != nullptr, "traverse_count: totals is NULL");
-    if (a->n_rays == 0) {
-        (void)hipMemsetAsync(a->totals, 0, 2 * sizeof(int64_t), (hipStream_t)stream);
-        return NFA_OK;
-    }
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s);
+    if (a->n_rays == 0) return NFA_OK;
     NFA_REQUIRE(workspace != nullptr, "traverse_count: workspace is NULL");
-    const GridView gv = make_view(a);
+    int lds = 0;
+    const GridView gv = make_view(a, &lds);
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     int64_t *block_sums = (int64_t *)workspace;
-    if (a->t_sorted)
-        hipLaunchKernelGGL(traverse_count_kernel<true>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, *a, gv, block_sums);
-    else
-        hipLaunchKernelGGL(traverse_count_kernel<false>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, *a, gv, block_sums);
+    const RunStore rs = make_runs(workspace, a->n_rays);
+    const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
+#define NFA_LAUNCH_COUNT(PRE, LAT)                                                                                   \
+    do {                                                                                                             \
+        if (int rc = allow_lds(traverse_count_kernel<PRE, LAT>, lds)) return rc;                                      \
+        hipLaunchKernelGGL((traverse_count_kernel<PRE, LAT>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    } while (0)
+    if (a->t_sorted) { if (lattice) NFA_LAUNCH_COUNT(true, true); else NFA_LAUNCH_COUNT(true, false); }
+    else             { if (lattice) NFA_LAUNCH_COUNT(false, true); else NFA_LAUNCH_COUNT(false, false); }
+#undef NFA_LAUNCH_COUNT
     if (int rc = check_launch("traverse_count_kernel")) return rc;
-    hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s,
                        a->iv_cnts, a->iv_starts, a->sm_cnts, a->sm_starts, a->n_rays, block_sums, a->totals);
     return check_launch("traverse_offsets_kernel");
 }
 
-NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty, int32_t rewrite_counts, void *stream)
+static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint8_t *only_overflow, hipStream_t s)
+{
+    int lds = 0;
+    const GridView gv = make_view(a, &lds);
+    lds -= kEvBytes;                                  // no boundary lists in the general walk
+    const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
+    if (a->t_sorted) {
+        if (int rc = allow_lds(traverse_fill_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(traverse_fill_kernel<true>, dim3(nb), dim3(kBlock), lds, s, *a, gv, skip_empty, rewrite_counts, only_overflow);
+    } else {
+        if (int rc = allow_lds(traverse_fill_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(traverse_fill_kernel<false>, dim3(nb), dim3(kBlock), lds, s, *a, gv, skip_empty, rewrite_counts, only_overflow);
+    }
+    return check_launch("traverse_fill_kernel");
+}
+
+NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty, int32_t rewrite_counts,
+                                 const void *workspace, int64_t n_samples, int64_t n_overflow, void *stream)
 {
     if (int rc = validate_traverse(a)) return rc;
     if (a->n_rays == 0) return NFA_OK;
     if (a->iv_vals) NFA_REQUIRE(a->iv_ray_indices && a->iv_is_left && a->iv_is_right && a->iv_starts,
                                 "traverse_fill: interval outputs must be given together");
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_fill: t_starts without t_ends");
-    const GridView gv = make_view(a);
-    const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    if (a->t_sorted)
-        hipLaunchKernelGGL(traverse_fill_kernel<true>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, *a, gv, skip_empty, rewrite_counts);
-    else
-        hipLaunchKernelGGL(traverse_fill_kernel<false>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, *a, gv, skip_empty, rewrite_counts);
-    return check_launch("traverse_fill_kernel");
+    hipStream_t s = (hipStream_t)stream;
+    if (!workspace) return launch_fill(a, skip_empty, rewrite_counts, nullptr, s);
+    // runs recorded by nfa_traverse_count with the same args (two-pass mode only)
+    NFA_REQUIRE(!rewrite_counts && a->rays_mask == nullptr, "traverse_fill: replay is for the two-pass mode");
+    NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
+    const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
+    if (n_samples > 0) {
+        hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples);
+        if (int rc = check_launch("traverse_emit_kernel")) return rc;
+    }
+    if (n_overflow > 0) return launch_fill(a, 1, 0, rs.n_runs, s);
+    return NFA_OK;
 }
 
 NFA_EXPORT int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream)

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
-    "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P]),
+    "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P, c_int64, c_int64, _P]),
     "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
     "nfa_pack_info": (ctypes.c_int, [_P, c_int64, c_int64, _P, _P]),
     "nfa_unpack_info": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, _P]),
@@ -86,6 +86,44 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
+
+
+class KernelTimer:
+    """Optional HIP-event timer around single-kernel C-ABI calls (bench.py's live roofline
+    measurement).  Events are recorded on the torch current stream, the stream the kernels are
+    launched on; nothing is synchronised until `summary()`."""
+
+    def __init__(self, names=("traverse_fill", "traverse_count", "rendering_fwd", "rendering_bwd", "visibility")):
+        self.names = set(names)
+        self.records = {}
+
+    def bracket(self, name, fn, *args):
+        if name not in self.names:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.records.items()}
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
+def _call(name, fn, *args):
+    if _timer is None:
+        return fn(*args)
+    return _timer.bracket(name, fn, *args)
 
 
 def load_library() -> ctypes.CDLL:
@@ -324,12 +362,13 @@ class _C:
                 iv_cnts = torch.empty(R, **i64) if compute_intervals else None
                 iv_starts = torch.empty(R, **i64) if compute_intervals else None
                 sm_cnts, sm_starts = torch.empty(R, **i64), torch.empty(R, **i64)
-                totals = torch.empty(2, **i64)
+                totals = torch.empty(4, **i64)
                 ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
                 a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
                 a.sm_cnts, a.sm_starts, a.totals = _ptr(sm_cnts), _ptr(sm_starts), _ptr(totals)
+                a.terminate_planes = _ptr(terminate)
                 _check(L.nfa_traverse_count(ctypes.byref(a), _ptr(ws), stream))
-                n_edges, n_samples = totals.tolist()   # the one host sync (data_spec.hpp:91)
+                n_edges, n_samples, n_overflow, _ = totals.tolist()   # the one host sync (data_spec.hpp:91)
             a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
             a.sm_cnts, a.sm_starts = _ptr(sm_cnts), _ptr(sm_starts)
             if compute_intervals:
@@ -347,8 +386,11 @@ class _C:
                 samples.is_valid = (torch.zeros if over_allocate else torch.empty)(n_samples, dtype=torch.bool, device=dev)
                 a.sm_vals, a.sm_ray_indices, a.sm_is_valid = _ptr(samples.vals), _ptr(samples.ray_indices), _ptr(samples.is_valid)
             a.terminate_planes = _ptr(terminate)
-            if R > 0 and (compute_intervals or compute_samples or compute_terminate_planes):
-                _check(L.nfa_traverse_fill(ctypes.byref(a), 0 if over_allocate else 1, 1 if over_allocate else 0, stream))
+            if over_allocate:
+                if R > 0:
+                    _check(L.nfa_traverse_fill(ctypes.byref(a), 0, 1, None, 0, 0, stream))
+            elif R > 0 and (compute_intervals or compute_samples) and n_samples > 0:
+                _check(L.nfa_traverse_fill(ctypes.byref(a), 1, 0, _ptr(ws), n_samples, n_overflow, stream))
             if over_allocate:
                 _check(L.nfa_exclusive_sum_i64(_ptr(iv_cnts), R, _ptr(iv_starts), None, stream))
                 _check(L.nfa_exclusive_sum_i64(_ptr(sm_cnts), R, _ptr(sm_starts), None, stream))
@@ -526,16 +568,16 @@ class _C:
             a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, None, None, None, near_planes, far_planes,
                                step_size, cone_angle, -1)
             packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
-            totals = torch.empty(2, **i64)
+            totals = torch.empty(4, **i64)
             ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
             a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
-            _check(L.nfa_traverse_count(ctypes.byref(a), _ptr(ws), stream))
-            n = totals[1].item()
+            _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
+            _, n, n_overflow, _ = totals.tolist()
             ray_indices = torch.empty(n, **i64)
             ts = torch.empty((2, n), dtype=torch.float32, device=dev)
             a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
             if n > 0:
-                _check(L.nfa_traverse_fill(ctypes.byref(a), 1, 0, stream))
+                _check(_call("traverse_fill", L.nfa_traverse_fill, ctypes.byref(a), 1, 0, _ptr(ws), n, n_overflow, stream))
         return ray_indices, ts[0], ts[1], packed.t()
 
     @staticmethod
@@ -600,7 +642,7 @@ class _C:
         n_out = torch.empty(1, dtype=torch.int64, device=dev)
         ws = torch.empty(max(L.nfa_visibility_workspace_bytes(n), 16), dtype=torch.uint8, device=dev)
         with _Guard(dens):
-            _check(L.nfa_visibility_compact(_ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n,
+            _check(_call("visibility", L.nfa_visibility_compact, _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n,
                                             early_stop_eps, alpha_thre, _ptr(o_idx), o_t[0].data_ptr(), o_t[1].data_ptr(),
                                             _ptr(mask), _ptr(n_out), _ptr(ws), _stream(dens)))
         k = n_out.item()
@@ -647,7 +689,7 @@ class _C:
         colors = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
         od = torch.empty((2, n_rays, 1), dtype=torch.float32, device=dev)
         with _Guard(sigmas):
-            _check(load_library().nfa_rendering_fwd(
+            _check(_call("rendering_fwd", load_library().nfa_rendering_fwd,
                 _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(rgbs), n, n_rays, _ptr(bkgd),
                 int(expected_depths), per_sample[0].data_ptr(), per_sample[1].data_ptr(), per_sample[2].data_ptr(),
                 _ptr(colors), od[0].data_ptr(), od[1].data_ptr(), _stream(sigmas)))
@@ -664,7 +706,7 @@ class _C:
         g_sig = torch.empty_like(sigmas) if need_sigma else None
         g_rgb = torch.empty_like(rgbs) if need_rgb else None
         with _Guard(sigmas):
-            _check(load_library().nfa_rendering_bwd(
+            _check(_call("rendering_bwd", load_library().nfa_rendering_bwd,
                 _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(rgbs), _ptr(weights), _ptr(trans),
                 _ptr(alphas), _ptr(opacities), _ptr(depths), sigmas.shape[0], n_rays, _ptr(bkgd), int(expected_depths),
                 _ptr(g_colors), _ptr(g_opac), _ptr(g_depth), _ptr(g_w), _ptr(g_T), _ptr(g_a), _ptr(g_sig), _ptr(g_rgb),
@@ -672,4 +714,4 @@ class _C:
         return g_sig, g_rgb
 
 
-__all__ = ["_C", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]
+__all__ = ["_C", "KernelTimer", "set_kernel_timer", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]
