@@ -104,11 +104,23 @@ __device__ __forceinline__ void dda_setup(Dda &s, const float o[3], const float 
     dda_axis(o[2], d[2], inv[2], box[2], box[5], res[2], tmin, tmax, t_in, t_out, s.tz, s.dz, s.sz, s.cz, s.oz);
 }
 
-// utils_grid.cuh:116-142
+// utils_grid.cuh:116-142: step along the axis whose next plane is strictly nearest (ties go
+// z, then y, then x by the strict '<' chain).  Written with selects: the three-way branch of
+// the reference makes a wave execute all three arms at almost every voxel.
 __device__ __forceinline__ bool dda_advance(Dda &s) {
-    if (s.tx < s.ty && s.tx < s.tz) { s.cx += s.sx; s.tx += s.dx; return s.cx != s.ox; }
-    if (s.ty < s.tz)                { s.cy += s.sy; s.ty += s.dy; return s.cy != s.oy; }
-    s.cz += s.sz; s.tz += s.dz; return s.cz != s.oz;
+    const bool ax = (s.tx < s.ty) && (s.tx < s.tz);
+    const bool ay = !ax && (s.ty < s.tz);
+    const bool az = !ax && !ay;
+    s.cx += ax ? s.sx : 0;
+    s.cy += ay ? s.sy : 0;
+    s.cz += az ? s.sz : 0;
+    s.tx = ax ? s.tx + s.dx : s.tx;
+    s.ty = ay ? s.ty + s.dy : s.ty;
+    s.tz = az ? s.tz + s.dz : s.tz;
+    // (bitwise on purpose: a select between the three overflow indices makes the compiler
+    //  spill them to scratch and index them, one scratch load per voxel)
+    const bool hit_x = s.cx == s.ox, hit_y = s.cy == s.oy, hit_z = s.cz == s.oz;
+    return !((ax & hit_x) | (ay & hit_y) | (az & hit_z));
 }
 
 // grid.cu:157-161 / 199-203: advance the marching lattice, t += dt with dt fixed, until the
@@ -279,62 +291,78 @@ struct GridView {
     int lds_compact_cap;  // compact bricks staged in LDS
 };
 
-// per-workgroup LDS image of the sparse occupancy
-struct OccLds {
-    const uint32_t *coarse;
-    const uint32_t *prefix;
-    const uint64_t *compact;
-    int cap;
-};
-
 struct BrickCache {
     int id;
     uint64_t bits;
 };
 
-// occupancy of voxel (x,y,z) through the sparse form; the brick is re-resolved only when the
-// voxel walk enters another brick.
-__device__ __forceinline__ bool occupied(const GridView &g, const OccLds &l, BrickCache &c, int level, int x, int y, int z) {
-    const int id = ((x >> 2) * g.nby + (y >> 2)) * g.nbz + (z >> 2) + level * g.bricks_per_grid;
+// The sparse occupancy is read either from its LDS image (LDS_OCC, arrays addressed off the
+// dynamic-LDS base so the compiler emits ds_read, not flat loads) or from global memory.
+// LDS image layout: coarse[W4] u32 | prefix[W4] u32 | compact[cap] u64, W4 = lds_words rounded to 4.
+template <bool LDS_OCC>
+struct Occ {
+    const char *smem;
+    int w4, cap;
+};
+
+template <bool LDS_OCC>
+__device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char *smem) {
+    Occ<LDS_OCC> l;
+    l.smem = smem;
+    l.w4 = (g.lds_words + 3) & ~3;
+    l.cap = 0;
+    if (LDS_OCC) {
+        uint32_t *lc = (uint32_t *)smem;
+        uint32_t *lp = lc + l.w4;
+        uint64_t *lb = (uint64_t *)(lp + l.w4);
+        for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) { lc[i] = g.coarse[i]; lp[i] = g.prefix[i]; }
+        int n_compact = (int)g.header[0];
+        if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
+        for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
+        l.cap = n_compact;
+        __syncthreads();
+    }
+    return l;
+}
+
+// occupancy of voxel (x,y,z); the brick is re-resolved only when the walk enters another brick
+template <bool LDS_OCC>
+__device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &l, BrickCache &c, int level, int x, int y, int z) {
+    // brick counts are < 2^24 (checked on the host): full-rate 24-bit multiplies
+    const int id = (int)__umul24(__umul24(x >> 2, g.nby) + (y >> 2), g.nbz) + (z >> 2) + level * g.bricks_per_grid;
     if (id != c.id) {
         c.id = id;
-        const uint32_t w = l.coarse[id >> 5];
         const uint32_t bit = 1u << (id & 31);
         uint64_t bits = 0;
-        if (w & bit) {
-            const int k = (int)l.prefix[id >> 5] + __popc(w & (bit - 1u));
-            bits = (k < l.cap) ? l.compact[k] : g.compact[k];
+        if (LDS_OCC) {
+            const uint32_t *lc = (const uint32_t *)l.smem;
+            const uint32_t w = lc[id >> 5];
+            if (w & bit) {
+                const int k = (int)lc[l.w4 + (id >> 5)] + __popc(w & (bit - 1u));
+                // unconditional ds_read (clamped) + rare global override: a select between an LDS
+                // and a global pointer would turn into a flat load
+                bits = ((const uint64_t *)(lc + 2 * l.w4))[min(k, l.cap - 1)];
+                if (k >= l.cap) bits = g.compact[k];
+            }
+        } else {
+            const uint32_t w = g.coarse[id >> 5];
+            if (w & bit) bits = g.compact[(int)g.prefix[id >> 5] + __popc(w & (bit - 1u))];
         }
         c.bits = bits;
     }
     return (c.bits >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull;
 }
 
-// stage the sparse occupancy into LDS (all threads of the block; ends with a barrier)
-__device__ __forceinline__ OccLds stage_occupancy(const GridView &g, char *smem) {
-    OccLds l;
-    if (g.lds_words == 0) {
-        l.coarse = g.coarse; l.prefix = g.prefix; l.compact = g.compact; l.cap = 0x7fffffff;
-        return l;
-    }
-    uint32_t *lc = (uint32_t *)smem;
-    uint32_t *lp = lc + ((g.lds_words + 3) & ~3);
-    uint64_t *lb = (uint64_t *)(lp + ((g.lds_words + 3) & ~3));
-    for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) { lc[i] = g.coarse[i]; lp[i] = g.prefix[i]; }
-    int n_compact = (int)g.header[0];
-    if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
-    for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
-    __syncthreads();
-    l.coarse = lc; l.prefix = lp; l.compact = lb; l.cap = n_compact;
-    return l;
-}
+// sorted ray/grid events (grid.py:156-162): EV_PRE = the caller's arrays; EV_ONE = one level,
+// slab test in registers (the Lego configuration: no sort, no arrays); EV_MANY = several levels,
+// slab tests + an insertion sort of the 2G event times in per-lane scratch.
+enum { EV_PRE = 0, EV_ONE = 1, EV_MANY = 2 };
 
-// sorted ray/grid events: either the caller's arrays or computed in-kernel
-template <bool PRECOMPUTED>
+template <int MODE>
 struct Events;
 
 template <>
-struct Events<true> {
+struct Events<EV_PRE> {
     const uint8_t *hit;
     const float *t;
     const int64_t *id;
@@ -349,25 +377,27 @@ struct Events<true> {
 };
 
 template <>
-struct Events<false> {
-    // grid.py:156-162 done per ray: slab test against every level with near = -inf,
-    // far = +inf, miss = +inf, then an ascending stable sort of the 2G times.  One level
-    // (the Lego configuration) needs no sort and stays in registers.
+struct Events<EV_ONE> {
+    float t0, t1;
+    bool hit;
+    __device__ __forceinline__ void init(const nfa_traverse_args &a, int64_t, const float *o, const float *inv) {
+        t0 = t1 = INFINITY;
+        float x0 = 0.f, x1 = 0.f;
+        hit = slab_test(o, inv, a.aabbs, -INFINITY, INFINITY, x0, x1);
+        if (hit) { t0 = x0; t1 = x1; }
+    }
+    __device__ __forceinline__ bool hits(int) const { return hit; }
+    __device__ __forceinline__ float time(int i) const { return i == 0 ? t0 : t1; }
+    __device__ __forceinline__ int index(int i) const { return i; }
+};
+
+template <>
+struct Events<EV_MANY> {
     float t[2 * NFA_MAX_GRID_LEVELS];
     int id[2 * NFA_MAX_GRID_LEVELS];
     bool hit[NFA_MAX_GRID_LEVELS];
-    float t0_1, t1_1;
-    bool hit_1, single;
     __device__ __forceinline__ void init(const nfa_traverse_args &a, int64_t, const float *o, const float *inv) {
         const int G = a.n_grids;
-        single = (G == 1);
-        if (single) {
-            t0_1 = t1_1 = INFINITY;
-            float x0 = 0.f, x1 = 0.f;
-            hit_1 = slab_test(o, inv, a.aabbs, -INFINITY, INFINITY, x0, x1);
-            if (hit_1) { t0_1 = x0; t1_1 = x1; }
-            return;
-        }
         for (int g = 0; g < G; ++g) {
             float x0 = 0.f, x1 = 0.f;
             const bool h = slab_test(o, inv, a.aabbs + 6 * g, -INFINITY, INFINITY, x0, x1);
@@ -386,9 +416,9 @@ struct Events<false> {
             id[j + 1] = iv;
         }
     }
-    __device__ __forceinline__ bool hits(int level) const { return single ? hit_1 : hit[level]; }
-    __device__ __forceinline__ float time(int i) const { return single ? (i == 0 ? t0_1 : t1_1) : t[i]; }
-    __device__ __forceinline__ int index(int i) const { return single ? i : id[i]; }
+    __device__ __forceinline__ bool hits(int level) const { return hit[level]; }
+    __device__ __forceinline__ float time(int i) const { return t[i]; }
+    __device__ __forceinline__ int index(int i) const { return id[i]; }
 };
 
 // resolve the grid level and clipped [seg_lo, seg_hi) between sorted events i and i+1
@@ -482,8 +512,8 @@ struct FillSink {
 // ---- general walk: any step_size / cone_angle; the reference's loop shape (grid.cu:95-281).
 // Used for cone_angle != 0, step_size <= 0, the over-allocated test-time pass and as the
 // pass-2 fallback of rays whose runs did not fit.
-template <class Sink, bool PRECOMPUTED>
-__device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a, const GridView &gv, const OccLds &occ,
+template <class Sink, int EV, bool LDS_OCC>
+__device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
                                                      int64_t r, Sink &sink, float &t_term)
 {
     const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
@@ -494,7 +524,7 @@ __device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a,
     const int limit = a.traverse_steps_limit;
     const int G = a.n_grids;
 
-    Events<PRECOMPUTED> ev;
+    Events<EV> ev;
     ev.init(a, r, o, inv);
 
     float t_last = near;
@@ -548,8 +578,8 @@ __device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a,
 // records run boundaries; they are consumed afterwards, all lanes in step.
 constexpr int kEvCap = 16;   // run boundaries buffered per lane and round
 
-template <bool PRECOMPUTED>
-__device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a, const GridView &gv, const OccLds &occ,
+template <int EV, bool LDS_OCC>
+__device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
                                                      float *__restrict__ ev_lds /* [kEvCap][blockDim] */,
                                                      int64_t r, bool active, CountSink &sink, float &t_term)
 {
@@ -567,7 +597,7 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
     const int G = a.n_grids;
     const int nthr = blockDim.x, tid = threadIdx.x;
 
-    Events<PRECOMPUTED> ev;
+    Events<EV> ev;
     if (active) ev.init(a, r, o, inv);
 
     float t_last = near;
@@ -666,23 +696,23 @@ __device__ __forceinline__ void publish_block_sums(int64_t n_iv, int64_t n_sm, i
 }
 
 // pass 1.  Block b owns rays [256 b, 256 b + 256).
-template <bool PRECOMPUTED, bool LATTICE>
+template <int EV, bool LATTICE, bool LDS_OCC>
 __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_args a, GridView gv,
                                                                 int64_t *__restrict__ block_sums, RunStore rs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OccLds occ = stage_occupancy(gv, smem);
+    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = r < a.n_rays && !(a.rays_mask && !a.rays_mask[r]);
     CountSink sink{rs, r, a.n_rays};
     float t_term = 0.f;
     if (LATTICE) {
         // the boundary lists sit behind the occupancy image in LDS
-        const int occ_bytes = gv.lds_words ? (2 * ((gv.lds_words + 3) & ~3) * 4 + gv.lds_compact_cap * 8) : 0;
+        const int occ_bytes = LDS_OCC ? (2 * occ.w4 * 4 + gv.lds_compact_cap * 8) : 0;
         float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));
-        traverse_ray_lattice<PRECOMPUTED>(a, gv, occ, ev_lds, r, active, sink, t_term);
+        traverse_ray_lattice<EV, LDS_OCC>(a, gv, occ, ev_lds, r, active, sink, t_term);
     } else if (active) {
-        traverse_ray_general<CountSink, PRECOMPUTED>(a, gv, occ, r, sink, t_term);
+        traverse_ray_general<CountSink, EV, LDS_OCC>(a, gv, occ, r, sink, t_term);
     }
     if (r < a.n_rays) {
         if (active) {
@@ -755,13 +785,13 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
 
 // pass 2, general form: walk the grid again and write.  Also the single pass of the
 // over-allocated test-time mode (grid.cu:375).  only_overflow: just the rays pass 1 flagged.
-template <bool PRECOMPUTED>
+template <int EV, bool LDS_OCC>
 __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args a, GridView gv,
                                                                int skip_empty, int rewrite_counts,
                                                                const uint8_t *__restrict__ only_overflow)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OccLds occ = stage_occupancy(gv, smem);
+    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= a.n_rays) return;
     if (a.rays_mask && !a.rays_mask[r]) return;
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
     }
     FillSink sink{a, r, a.iv_starts ? a.iv_starts[r] : 0, a.sm_starts[r]};
     float t_term;
-    traverse_ray_general<FillSink, PRECOMPUTED>(a, gv, occ, r, sink, t_term);
+    traverse_ray_general<FillSink, EV, LDS_OCC>(a, gv, occ, r, sink, t_term);
     if (a.terminate_planes && !only_overflow) a.terminate_planes[r] = t_term;
     if (rewrite_counts) {
         if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
@@ -954,7 +984,7 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
     NFA_REQUIRE(n_grids > 0 && rx > 0 && ry > 0 && rz > 0, "pack_binaries: empty grid");
     NFA_REQUIRE(binaries && bricks, "pack_binaries: NULL pointer");
     const PackedLayout L = packed_layout(n_grids, rx, ry, rz);
-    NFA_REQUIRE(L.n_bricks < (1ll << 31), "pack_binaries: grid too large");
+    NFA_REQUIRE(L.n_bricks < (1ll << 24), "pack_binaries: grid too large (more than 2^24 bricks)");
     hipStream_t s = (hipStream_t)stream;
     uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
     uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
@@ -987,13 +1017,22 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     int64_t *block_sums = (int64_t *)workspace;
     const RunStore rs = make_runs(workspace, a->n_rays);
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
-#define NFA_LAUNCH_COUNT(PRE, LAT)                                                                                   \
-    do {                                                                                                             \
-        if (int rc = allow_lds(traverse_count_kernel<PRE, LAT>, lds)) return rc;                                      \
-        hipLaunchKernelGGL((traverse_count_kernel<PRE, LAT>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
+    const bool lds_occ = gv.lds_words > 0;
+#define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
+    do {                                                                                                                    \
+        if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((traverse_count_kernel<EVM, LAT, LDSO>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
     } while (0)
-    if (a->t_sorted) { if (lattice) NFA_LAUNCH_COUNT(true, true); else NFA_LAUNCH_COUNT(true, false); }
-    else             { if (lattice) NFA_LAUNCH_COUNT(false, true); else NFA_LAUNCH_COUNT(false, false); }
+#define NFA_COUNT_EV(EVM)                                                              \
+    do {                                                                               \
+        if (lattice) { if (lds_occ) NFA_LAUNCH_COUNT(EVM, true, true); else NFA_LAUNCH_COUNT(EVM, true, false); }   \
+        else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true); else NFA_LAUNCH_COUNT(EVM, false, false); } \
+    } while (0)
+    if (evm == EV_PRE) NFA_COUNT_EV(EV_PRE);
+    else if (evm == EV_ONE) NFA_COUNT_EV(EV_ONE);
+    else NFA_COUNT_EV(EV_MANY);
+#undef NFA_COUNT_EV
 #undef NFA_LAUNCH_COUNT
     if (int rc = check_launch("traverse_count_kernel")) return rc;
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s,
@@ -1007,13 +1046,18 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     const GridView gv = make_view(a, &lds);
     lds -= kEvBytes;                                  // no boundary lists in the general walk
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    if (a->t_sorted) {
-        if (int rc = allow_lds(traverse_fill_kernel<true>, lds)) return rc;
-        hipLaunchKernelGGL(traverse_fill_kernel<true>, dim3(nb), dim3(kBlock), lds, s, *a, gv, skip_empty, rewrite_counts, only_overflow);
-    } else {
-        if (int rc = allow_lds(traverse_fill_kernel<false>, lds)) return rc;
-        hipLaunchKernelGGL(traverse_fill_kernel<false>, dim3(nb), dim3(kBlock), lds, s, *a, gv, skip_empty, rewrite_counts, only_overflow);
-    }
+    const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
+    const bool lds_occ = gv.lds_words > 0;
+#define NFA_LAUNCH_FILL(EVM, LDSO)                                                                                           \
+    do {                                                                                                                     \
+        if (int rc = allow_lds(traverse_fill_kernel<EVM, LDSO>, lds)) return rc;                                              \
+        hipLaunchKernelGGL((traverse_fill_kernel<EVM, LDSO>), dim3(nb), dim3(kBlock), lds, s, *a, gv, skip_empty, rewrite_counts, \
+                           only_overflow);                                                                                   \
+    } while (0)
+    if (evm == EV_PRE) { if (lds_occ) NFA_LAUNCH_FILL(EV_PRE, true); else NFA_LAUNCH_FILL(EV_PRE, false); }
+    else if (evm == EV_ONE) { if (lds_occ) NFA_LAUNCH_FILL(EV_ONE, true); else NFA_LAUNCH_FILL(EV_ONE, false); }
+    else { if (lds_occ) NFA_LAUNCH_FILL(EV_MANY, true); else NFA_LAUNCH_FILL(EV_MANY, false); }
+#undef NFA_LAUNCH_FILL
     return check_launch("traverse_fill_kernel");
 }
 
