@@ -130,6 +130,22 @@ def main():
     g["mic_zero"] = torch.tensor(int((est.occs == 0).sum()))
     g["mic_occs_bits"] = np.packbits((est.occs == -1).numpy())
 
+    # _update evolution with the reference's RNG call order (occ_grid.py:345-404)
+    from nerfacc.estimators.prop_net import _transform_stot, get_proposal_requires_grad_fn
+
+    torch.manual_seed(123)
+    est2 = OccGridEstimator(roi_aabb=base, resolution=16, levels=2)
+    occ_fn = lambda x: torch.exp(-2.0 * (x**2).sum(-1, keepdim=True)) * 0.05
+    for step in (0, 16, 256, 272):
+        est2._update(step=step, occ_eval_fn=occ_fn, occ_thre=0.01)
+    g["upd_occs"] = est2.occs.clone()
+    g["upd_bin"] = np.packbits(est2.binaries.numpy().ravel())
+    fn = get_proposal_requires_grad_fn()
+    g["prop_sched"] = np.array([fn(i) for i in range(3000)])
+    sv = torch.linspace(0, 1, 17)[None]
+    g["stot_uni"] = _transform_stot("uniform", sv, 0.2, 1000.0)
+    g["stot_lin"] = _transform_stot("lindisp", sv, 0.2, 1000.0)
+
     out = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in g.items()}
     np.savez_compressed(os.path.join(OUT, "reference_cpu.npz"), **out)
     print("wrote", os.path.join(OUT, "reference_cpu.npz"), {k: v.shape for k, v in out.items()})
