@@ -20,6 +20,7 @@
 //     kernel give offsets and totals (one 32-byte readback per traverse_grids call);
 //   * pass 2, one lane per OUTPUT SAMPLE: binary-search the ray, pick the run, jump to the
 //     lattice point in closed form, store — fully coalesced, no grid access, no divergence.
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -576,7 +577,10 @@ __device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a,
 // one (voxel exit times never decrease, and the reference's per-voxel conditions are monotone
 // in t), and (b) jumps and batches have the closed forms of lattice.hpp.  The voxel loop only
 // records run boundaries; they are consumed afterwards, all lanes in step.
-constexpr int kEvCap = 16;   // run boundaries buffered per lane and round
+#ifndef NFA_EVCAP
+#define NFA_EVCAP 16
+#endif
+constexpr int kEvCap = NFA_EVCAP;   // run boundaries buffered per lane and round
 
 template <int EV, bool LDS_OCC>
 __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
@@ -723,6 +727,336 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
         a.sm_cnts[r] = sink.n_sm;
     }
     publish_block_sums(sink.n_iv, sink.n_sm, block_sums);
+}
+
+// ---- split walk: P lanes per ray ---------------------------------------------------------
+// With ~10^4 rays per training step a lane-per-ray walk fills only ~200 of the chip's 1024
+// SIMDs, one wave each, and its time is the instruction latency of ONE ray's ~400-voxel walk.
+// Plane crossings of each axis are chains t <- t + delta as well, so the DDA state after the
+// j-th crossing of the ray's major axis has a closed form (lattice.hpp) — the walk can START
+// anywhere.  Each ray is cut into P parts at major-axis crossings; a lane walks one part and
+// lists its occupied<->empty boundaries; lattice positions of boundaries are absolute (counted
+// from the segment start), so every lane resolves its own boundaries independently and the P
+// lanes of a ray are stitched with a P-wide shuffle prefix.  One level, cone_angle == 0,
+// no step limit (the training configuration); everything else uses the kernels above.
+
+// (time, axis) order of plane crossings in the voxel walk: earlier time first, ties z, y, x
+// (the strict '<' chain of utils_grid.cuh:119-141)
+__device__ __forceinline__ bool crossing_precedes(float ta, int rank_a, float tb, int rank_b) {
+    return (ta < tb) || (ta == tb && rank_a < rank_b);
+}
+
+// number of crossings of a chain (first at t0, then +d each) that precede (T, rank_T); also
+// returns the time of the first crossing that does not (the pending tdist of that axis)
+__device__ __forceinline__ int crossings_before(float t0, float d, int rank, float T, int rank_T, int n_max, float &pending) {
+    pending = t0;
+    if (n_max <= 0 || !crossing_precedes(t0, rank, T, rank_T)) return 0;
+    int i = 1;                          // v = time of crossing i
+    float v = t0;
+    const float est = (T - t0) / d;
+    if (est > 8.0f && est < 1.0e7f) {   // jump close, from below; verified
+        int j = (int)est - 2;
+        if (j > n_max) j = n_max;
+        const float vj = nfa_lattice_advance(t0, d, j - 1, nullptr);
+        if (crossing_precedes(vj, rank, T, rank_T)) { i = j; v = vj; }
+    }
+    while (i < n_max) {
+        const float nv = v + d;
+        if (!crossing_precedes(nv, rank, T, rank_T)) { pending = nv; return i; }
+        v = nv;
+        ++i;
+    }
+    pending = v + d;
+    return i;
+}
+
+// serial walk of one ray with the lattice arithmetic done inline at every transition: the
+// fallback of the split kernel for rays with too many transitions per part or a stuck lattice
+template <int EV, bool LDS_OCC>
+__device__ void traverse_ray_lattice_inline(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
+                                            int64_t r, CountSink &sink, float &t_term)
+{
+    const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
+    const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const float near = a.near_planes[r], far = a.far_planes[r];
+    const float dt = march_dt(0.0f, 0.0f, a.step_size);
+    const int G = a.n_grids;
+    Events<EV> ev;
+    ev.init(a, r, o, inv);
+    float t_last = near;
+    bool continuous = false;
+    BrickCache cache;
+    cache.id = -1;
+    cache.bits = 0;
+    for (int i = 0; i + 1 < 2 * G; ++i) {
+        int level;
+        float seg_lo, seg_hi;
+        if (!segment_of(ev, i, G, near, far, level, seg_lo, seg_hi)) continue;
+        int64_t k; bool stuck;
+        if (!continuous) { t_last = nfa_lattice_until(t_last, dt, seg_lo, &k, &stuck); if (stuck) t_last = seg_lo; }
+        Dda s;
+        dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
+        bool have_run = false, run_occ = false, more = true;
+        float run_exit = 0.f;
+        while (more || have_run) {
+            bool oc = false;
+            float t_cell = 0.f;
+            if (more) {
+                t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+                oc = occupied(gv, occ, cache, level, s.cx, s.cy, s.cz);
+            }
+            if (have_run && (!more || oc != run_occ)) {           // close the run that ends at run_exit
+                const float t_new = nfa_lattice_until(t_last, dt, run_exit, &k, &stuck);
+                if (run_occ) { sink.run(t_last, k, continuous); if (k > 0) continuous = true; t_last = t_new; }
+                else { continuous = false; t_last = stuck ? run_exit : t_new; }
+                have_run = false;
+            }
+            if (!more) break;
+            have_run = true;
+            run_occ = oc;
+            run_exit = t_cell;
+            more = dda_advance(s);
+        }
+    }
+    t_term = t_last;
+}
+
+template <bool LDS_OCC, int P, int CAP>
+__global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
+                                                                      int64_t *__restrict__ block_sums, RunStore rs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    const int occ_bytes = LDS_OCC ? (2 * occ.w4 * 4 + gv.lds_compact_cap * 8) : 0;
+    float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));        // [CAP][kBlock] times, then [CAP][kBlock] indices
+    const int tid = threadIdx.x, part = tid % P;
+    const int64_t R = a.n_rays;
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / P) + tid / P;
+    const bool ray_ok = r < R;
+    const int64_t rr = ray_ok ? r : 0;
+
+    const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
+    const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const float near = a.near_planes[rr], far = a.far_planes[rr];
+    const float dt = march_dt(0.0f, 0.0f, a.step_size);
+
+    // the single segment (grid.cu:129-150 with one level)
+    float x0 = 0.f, x1 = 0.f;
+    const bool hit = slab_test(o, inv, a.aabbs, -INFINITY, INFINITY, x0, x1);
+    const float seg_lo = fmaxf(x0, near), seg_hi = fminf(x1, far);
+    const bool live = ray_ok && hit && seg_lo < seg_hi;
+
+    // quantities shared by the P lanes of a ray are computed once and passed around by shuffles
+    const int group_base = lane_id() - part;
+    int64_t k_tmp; bool stuck_any = false, stuck = false;
+    float t_seg = near;
+    if (live && part == 0) { t_seg = nfa_lattice_until(near, dt, seg_lo, &k_tmp, &stuck); stuck_any = stuck; }
+    t_seg = __shfl(t_seg, group_base, 64);
+
+    Dda s;
+    s.tx = s.ty = s.tz = 0.f; s.dx = s.dy = s.dz = 0.f;
+    s.sx = s.sy = s.sz = 0; s.cx = s.cy = s.cz = 0; s.ox = s.oy = s.oz = 0;
+    if (live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs, gv.res);
+
+    // crossings until each axis reaches its overflow index, and when the walk ends
+    const int nx = s.sx ? (s.ox - s.cx) * s.sx : 1, ny = s.sy ? (s.oy - s.cy) * s.sy : 1, nz = s.sz ? (s.oz - s.cz) * s.sz : 1;
+    float T_mine = 0.f;                      // lane `a` of the group: last crossing of axis a (x, y, z)
+    {
+        const int ax = part % 3;
+        const float t0 = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
+        const float dl = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
+        const int nn = ax == 0 ? nx : (ax == 1 ? ny : nz);
+        if (P < 3 || part < 3) T_mine = nfa_lattice_advance(t0, dl, nn - 1, nullptr);
+    }
+    float Tx, Ty, Tz;
+    if (P >= 3) {
+        Tx = __shfl(T_mine, group_base, 64);
+        Ty = __shfl(T_mine, group_base + 1, 64);
+        Tz = __shfl(T_mine, group_base + 2, 64);
+    } else {
+        Tx = nfa_lattice_advance(s.tx, s.dx, nx - 1, nullptr);
+        Ty = nfa_lattice_advance(s.ty, s.dy, ny - 1, nullptr);
+        Tz = nfa_lattice_advance(s.tz, s.dz, nz - 1, nullptr);
+    }
+    int end_rank = 2; float T_end = Tx;                                   // ranks: z 0, y 1, x 2
+    if (crossing_precedes(Ty, 1, T_end, end_rank)) { T_end = Ty; end_rank = 1; }
+    if (crossing_precedes(Tz, 0, T_end, end_rank)) { T_end = Tz; end_rank = 0; }
+    // major axis: most crossings
+    const int m_rank = (nx >= ny && nx >= nz) ? 2 : (ny >= nz ? 1 : 0);
+    const int n_major = m_rank == 2 ? nx : (m_rank == 1 ? ny : nz);
+    const int j_begin = (int)(((int64_t)part * n_major) / P);
+    const int j_end = (part == P - 1) ? 0x7fffffff : (int)(((int64_t)(part + 1) * n_major) / P);
+
+    // index bookkeeping the closed forms rely on; anything odd (a final voxel "behind" the first
+    // one through float error) is left to the serial walk
+    const bool weird = live && (nx <= 0 || ny <= 0 || nz <= 0);
+    // parts whose range is empty do nothing; a part with j_begin == 0 starts at the segment start
+    bool part_live = live && !weird && j_begin < j_end;
+    bool have_run = false, run_occ = false;
+    float run_exit = 0.f;
+    BrickCache cache;
+    cache.id = -1;
+    cache.bits = 0;
+    if (part_live && j_begin > 0) {
+        const float t0m = m_rank == 2 ? s.tx : (m_rank == 1 ? s.ty : s.tz);
+        const float dm = m_rank == 2 ? s.dx : (m_rank == 1 ? s.dy : s.dz);
+        const float T_seam = nfa_lattice_advance(t0m, dm, j_begin - 1, nullptr);    // time of major crossing j_begin
+        if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;
+        else {
+            float pend;
+            if (m_rank != 2) { const int c = crossings_before(s.tx, s.dx, 2, T_seam, m_rank, nx, pend); s.cx += c * s.sx; s.tx = pend; }
+            if (m_rank != 1) { const int c = crossings_before(s.ty, s.dy, 1, T_seam, m_rank, ny, pend); s.cy += c * s.sy; s.ty = pend; }
+            if (m_rank != 0) { const int c = crossings_before(s.tz, s.dz, 0, T_seam, m_rank, nz, pend); s.cz += c * s.sz; s.tz = pend; }
+            // the voxel just before the seam: occupancy state the part inherits
+            int px = s.cx, py = s.cy, pz = s.cz;
+            if (m_rank == 2) { px += (j_begin - 1) * s.sx; s.cx += j_begin * s.sx; s.tx = T_seam + s.dx; }
+            else if (m_rank == 1) { py += (j_begin - 1) * s.sy; s.cy += j_begin * s.sy; s.ty = T_seam + s.dy; }
+            else { pz += (j_begin - 1) * s.sz; s.cz += j_begin * s.sz; s.tz = T_seam + s.dz; }
+            have_run = true;
+            run_occ = occupied(gv, occ, cache, 0, px, py, pz);
+            run_exit = fminf(T_seam, seg_hi);
+        }
+    }
+
+    // ---- A: this part's voxels, boundaries only
+    int n_ev = 0, major_done = j_begin;
+    unsigned ev_occ = 0;
+    bool overflow = false;
+    while (part_live) {
+        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+        const bool oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
+        if (have_run && oc != run_occ) {
+            if (n_ev == CAP - 1) { overflow = true; break; }
+            ev_lds[n_ev * kBlock + tid] = run_exit;
+            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+            ++n_ev;
+        }
+        have_run = true;
+        run_occ = oc;
+        run_exit = t_cell;
+        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        const bool cont = dda_advance(s);
+        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        major_done += (cm_after != cm_before) ? 1 : 0;
+        if (!cont) {                                   // end of the walk: the ray's last run
+            ev_lds[n_ev * kBlock + tid] = run_exit;
+            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+            ++n_ev;
+            part_live = false;
+        } else if (major_done >= j_end) part_live = false;     // next part's seam
+    }
+
+    // ---- B: absolute lattice position (T_j, K_j = steps from the segment start) of every own
+    // boundary; the lists stay in LDS
+    int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
+    int64_t K_last = 0;
+    float T_last = t_seg;
+    {
+        int64_t K = 0;
+        float T = t_seg;
+        for (int j = 0; j < n_ev; ++j) {
+            const float bound = ev_lds[j * kBlock + tid];
+            T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
+            stuck_any = stuck_any || stuck;
+            K += k_tmp;
+            ev_lds[j * kBlock + tid] = T;
+            ev_K[j * kBlock + tid] = (int32_t)K;
+        }
+        K_last = K;
+        T_last = T;
+    }
+    // group-wide decisions (the P lanes of a ray are adjacent lanes of one wave)
+    bool bad = overflow || stuck_any || weird || K_last > 0x7fffffffll;
+#ifdef NFA_FORCE_SERIAL
+    bad = true;
+#endif
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1) {
+        const int other = __shfl_xor((int)bad, off, 64);   // NOT inside a short-circuit: every lane must take part
+        bad = bad || (other != 0);
+    }
+    // boundary before this part's first one: the nearest earlier part that has boundaries
+    int64_t K_before = 0;
+    float T_before = t_seg;
+    {
+        bool found = false;
+#pragma unroll
+        for (int q = 1; q < P; ++q) {
+            const int has_q = __shfl_up(n_ev, q, 64);
+            const int64_t Kq = __shfl_up(K_last, q, 64);
+            const float Tq = __shfl_up(T_last, q, 64);
+            if (!found && part >= q && has_q > 0) { found = true; K_before = Kq; T_before = Tq; }
+        }
+    }
+    // samples of every occupied run that ends in this part; runs with samples are "fresh"
+    // (each is preceded by an empty run or starts the ray: boundaries alternate)
+    int64_t n_sm = 0;
+    int n_fresh = 0;
+    {
+        int64_t K_prev = K_before;
+        for (int j = 0; j < n_ev; ++j) {
+            const int64_t K = ev_K[j * kBlock + tid];
+            if (((ev_occ >> j) & 1u) && K > K_prev) { n_sm += K - K_prev; ++n_fresh; }
+            K_prev = K;
+        }
+    }
+    // exclusive prefix of fresh runs over the ray's parts, and ray totals
+    int fresh_before = 0, fresh_total = n_fresh;
+    int64_t sm_total = n_sm;
+    int last_part_with_ev = n_ev > 0 ? part : -1;
+#pragma unroll
+    for (int q = 1; q < P; ++q) {
+        const int f = __shfl_up(n_fresh, q, 64);
+        if (part >= q) fresh_before += f;
+    }
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1) {
+        fresh_total += __shfl_xor(fresh_total, off, 64);
+        sm_total += __shfl_xor(sm_total, off, 64);
+        last_part_with_ev = max(last_part_with_ev, __shfl_xor(last_part_with_ev, off, 64));
+    }
+    const float T_final = __shfl(T_last, group_base + max(last_part_with_ev, 0), 64);
+
+    if (!bad) {
+        // run records of this part
+        if (rs.t0 && n_fresh > 0) {
+            int64_t K_prev = K_before;
+            float T_prev = T_before;
+            int idx = fresh_before;
+            for (int j = 0; j < n_ev; ++j) {
+                const int64_t K = ev_K[j * kBlock + tid];
+                const float T = ev_lds[j * kBlock + tid];
+                if (((ev_occ >> j) & 1u) && K > K_prev) {
+                    if (idx < kMaxRuns) { rs.t0[(int64_t)idx * R + r] = T_prev; rs.len[(int64_t)idx * R + r] = (int32_t)(K - K_prev); }
+                    ++idx;
+                }
+                K_prev = K;
+                T_prev = T;
+            }
+        }
+        if (ray_ok && part == 0) {
+            const bool ovf = fresh_total > kMaxRuns;
+            if (rs.n_runs) rs.n_runs[r] = (uint8_t)(ovf ? kRunsOverflow : fresh_total);
+            if (ovf) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
+            if (a.iv_cnts) a.iv_cnts[r] = sm_total + fresh_total;
+            a.sm_cnts[r] = sm_total;
+            if (a.terminate_planes) a.terminate_planes[r] = last_part_with_ev >= 0 ? T_final : t_seg;
+            atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8)), (unsigned long long)(sm_total + fresh_total));
+            atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8) + 1), (unsigned long long)sm_total);
+        }
+    } else if (ray_ok && part == 0) {
+        CountSink sink{rs, r, R};
+        float t_term = 0.f;
+        traverse_ray_lattice_inline<EV_ONE, LDS_OCC>(a, gv, occ, r, sink, t_term);
+        if (sink.finish(true)) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
+        if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
+        a.sm_cnts[r] = sink.n_sm;
+        if (a.terminate_planes) a.terminate_planes[r] = t_term;
+        atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8)), (unsigned long long)sink.n_iv);
+        atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8) + 1), (unsigned long long)sink.n_sm);
+    }
 }
 
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
@@ -891,11 +1225,14 @@ int validate_traverse(const nfa_traverse_args *a) {
     return NFA_OK;
 }
 
-// LDS budget of the traversal kernels: occupancy image + boundary lists
+// LDS of the traversal kernels: occupancy image (bitmap + rank + compacted bricks) followed by
+// the per-lane boundary lists.  The image is sized from the caller's count of non-empty bricks
+// when known (args.n_nonempty_bricks >= 0, nfa_pack_binaries' header read back once per grid
+// update) so that several workgroups fit per CU; otherwise from the budget.
 constexpr int kLdsBudget = 96 * 1024;
-constexpr int kEvBytes = kEvCap * kBlock * 4;
+constexpr int kEvBytes = kEvCap * kBlock * 4 * 2;   // boundary times + lattice indices
 
-GridView make_view(const nfa_traverse_args *a, int *lds_bytes) {
+GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     GridView gv;
     const PackedLayout L = packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]);
     gv.bricks = a->bricks;
@@ -910,17 +1247,18 @@ GridView make_view(const nfa_traverse_args *a, int *lds_bytes) {
     gv.bricks_per_grid = gv.nbx * gv.nby * gv.nbz;
     gv.n_words = (int)L.n_words;
     const int64_t words_bytes = 2 * (((int64_t)L.n_words + 3) & ~3ll) * 4;
-    const int64_t room = (int64_t)kLdsBudget - kEvBytes - 16 - words_bytes;
-    if (room >= 4096) {
+    const int64_t room = (int64_t)kLdsBudget - ev_bytes - 16 - words_bytes;
+    if (room >= 2048) {
         gv.lds_words = (int)L.n_words;
         int64_t cap = room / 8;
         if (cap > L.n_bricks) cap = L.n_bricks;
+        if (a->n_nonempty_bricks >= 0 && cap > a->n_nonempty_bricks) cap = a->n_nonempty_bricks > 0 ? a->n_nonempty_bricks : 1;
         gv.lds_compact_cap = (int)cap;
-        *lds_bytes = (int)(((words_bytes + cap * 8 + 15) & ~15ll) + kEvBytes);
+        *lds_bytes = (int)(((words_bytes + cap * 8 + 15) & ~15ll) + ev_bytes);
     } else {                                      // bitmap too large for LDS: everything from L2
         gv.lds_words = 0;
         gv.lds_compact_cap = 0;
-        *lds_bytes = kEvBytes;
+        *lds_bytes = ev_bytes;
     }
     return gv;
 }
@@ -1011,14 +1349,11 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s);
     if (a->n_rays == 0) return NFA_OK;
     NFA_REQUIRE(workspace != nullptr, "traverse_count: workspace is NULL");
-    int lds = 0;
-    const GridView gv = make_view(a, &lds);
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     int64_t *block_sums = (int64_t *)workspace;
     const RunStore rs = make_runs(workspace, a->n_rays);
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
-    const bool lds_occ = gv.lds_words > 0;
 #define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
     do {                                                                                                                    \
         if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
@@ -1029,6 +1364,48 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (lattice) { if (lds_occ) NFA_LAUNCH_COUNT(EVM, true, true); else NFA_LAUNCH_COUNT(EVM, true, false); }   \
         else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true); else NFA_LAUNCH_COUNT(EVM, false, false); } \
     } while (0)
+    const bool split = lattice && evm == EV_ONE && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
+    // lanes per ray: enough waves to give every SIMD a few (latency hiding), no more
+    int P = 1;
+    if (split) {
+        // measured on MI355X (profiles/r01_split_sweep.md): 16 lanes per ray wins while the ray
+        // batch is too small to fill the chip (<= ~20 k rays: 86 us vs 139 us at 13 k rays); above
+        // that the lane-per-ray walk does the same in fewer instructions (134 us at 40 k rays).
+        if (a->n_rays <= 20000) P = 16;
+        if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
+        }
+    }
+    if (P > 1) {
+        const int cap = P >= 8 ? 8 : 16;
+        int lds = 0;
+        const GridView gv = make_view(a, cap * kBlock * 8, &lds);
+        const bool lds_occ = gv.lds_words > 0;
+        // per-ray totals are added to the 256-ray block sums with atomics
+        (void)hipMemsetAsync(block_sums, 0, 16 * (size_t)nb, s);
+        const unsigned nbs = (unsigned)ceil_div(a->n_rays, kBlock / P);
+#define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
+    do {                                                                                                                       \
+        if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \
+        hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    } while (0)
+        if (lds_occ) {
+            if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
+            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 8); else NFA_LAUNCH_SPLIT(true, 16, 8);
+        } else {
+            if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 16);
+            else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 8); else NFA_LAUNCH_SPLIT(false, 16, 8);
+        }
+#undef NFA_LAUNCH_SPLIT
+        if (int rc = check_launch("traverse_count_split_kernel")) return rc;
+        hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s,
+                           a->iv_cnts, a->iv_starts, a->sm_cnts, a->sm_starts, a->n_rays, block_sums, a->totals);
+        return check_launch("traverse_offsets_kernel");
+    }
+    int lds = 0;
+    const GridView gv = make_view(a, kEvBytes, &lds);
+    const bool lds_occ = gv.lds_words > 0;
     if (evm == EV_PRE) NFA_COUNT_EV(EV_PRE);
     else if (evm == EV_ONE) NFA_COUNT_EV(EV_ONE);
     else NFA_COUNT_EV(EV_MANY);
@@ -1043,8 +1420,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
 static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint8_t *only_overflow, hipStream_t s)
 {
     int lds = 0;
-    const GridView gv = make_view(a, &lds);
-    lds -= kEvBytes;                                  // no boundary lists in the general walk
+    const GridView gv = make_view(a, 0, &lds);       // no boundary lists in the general walk
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
     const bool lds_occ = gv.lds_words > 0;

@@ -40,6 +40,12 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
     const int ed = (int)((db >> 23) & 0xffu);
     const uint32_t D = (db & 0x7fffffu) | 0x800000u;
     const bool d_ok = ed >= 1 && ed < 255 && (db >> 31) == 0;     // positive normal
+    // Close to zero the binades are short (a binade below 32 d holds < 32 lattice points): plain
+    // adds are cheaper there than the per-binade bookkeeping below.
+    if (d_ok) {
+        const float small = d * 32.0f;
+        while (j > 0 && t < small && t > -small) { t = t + d; --j; }
+    }
     while (j > 0) {
         const uint32_t tb = nfa_f2u(t);
         const int e = (int)((tb >> 23) & 0xffu);
@@ -65,8 +71,15 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
             --j;
             continue;
         }
+        // steps that provably stay inside the binade: floor((lim - m) / c) + 1.  The quotient is
+        // taken in fp32 and corrected downwards (never upwards: a smaller count is always safe,
+        // it only costs one more trip through this loop) — an integer divide is ~40 instructions
+        // on the GPU.
         const uint32_t lim = (1u << 24) - c0 - 1u;
-        const uint64_t jmax = (uint64_t)((lim - m) / c) + 1u;
+        const uint32_t x = lim - m;
+        uint32_t q = (uint32_t)((float)x / (float)c);
+        while ((uint64_t)q * c > x) --q;
+        const uint64_t jmax = (uint64_t)q + 1u;
         const uint64_t n = jmax < (uint64_t)j ? jmax : (uint64_t)j;
         m += (uint32_t)n * c;                          // <= 2^24
         j -= (int64_t)n;

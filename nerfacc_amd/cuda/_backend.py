@@ -33,7 +33,8 @@ class _TraverseArgs(ctypes.Structure):
 
     _fields_ = [
         ("n_rays", c_int64), ("rays_o", c_void_p), ("rays_d", c_void_p), ("rays_mask", c_void_p),
-        ("n_grids", c_int32), ("res", c_int32 * 3), ("bricks", c_void_p), ("aabbs", c_void_p),
+        ("n_grids", c_int32), ("res", c_int32 * 3), ("bricks", c_void_p), ("n_nonempty_bricks", c_int64),
+        ("aabbs", c_void_p),
         ("hits", c_void_p), ("t_sorted", c_void_p), ("t_indices", c_void_p),
         ("near_planes", c_void_p), ("far_planes", c_void_p),
         ("step_size", c_float), ("cone_angle", c_float), ("traverse_steps_limit", c_int32),
@@ -236,7 +237,7 @@ class RaySegmentsSpec:
 # --------------------------------------------------------------------------------------
 # occupancy bricks: packed once per distinct `binaries` tensor state
 # --------------------------------------------------------------------------------------
-_brick_cache = {"ref": None, "version": None, "bricks": None}
+_brick_cache = {"ref": None, "version": None, "bricks": None, "nonempty": -1}
 
 
 def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
@@ -249,6 +250,7 @@ def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
     c = _brick_cache
     if c["ref"] is not None and c["ref"]() is binaries and c["version"] == binaries._version:
         return c["bricks"]
+    c["nonempty"] = -1
     L = load_library()
     G, rx, ry, rz = binaries.shape
     words = L.nfa_packed_grid_words(G, rx, ry, rz)
@@ -282,7 +284,17 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
         a.rays_mask = _ptr(rays_mask)
     a.n_grids = G
     a.res[0], a.res[1], a.res[2] = binaries.shape[1], binaries.shape[2], binaries.shape[3]
-    a.bricks = _ptr(packed_bricks(binaries))
+    bricks = packed_bricks(binaries)
+    a.bricks = _ptr(bricks)
+    if _brick_cache["bricks"] is bricks:
+        if _brick_cache["nonempty"] < 0:
+            # one readback per grid update (every 16 training steps): lets the kernels size their
+            # LDS occupancy image to the grid instead of to the worst case
+            n_bricks = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
+            _brick_cache["nonempty"] = int(bricks[n_bricks].item())
+        a.n_nonempty_bricks = _brick_cache["nonempty"]
+    else:
+        a.n_nonempty_bricks = -1
     a.aabbs = _ptr(aabbs)
     if t_sorted is not None:
         _check_input(t_sorted, "t_sorted", torch.float32)

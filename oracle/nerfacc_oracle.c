@@ -550,3 +550,29 @@ ORC_API void orc_searchsorted_batched(
         }
     }
 }
+
+/* debugging aid: the voxel sequence of one ray through one level (cells visited by the DDA of
+ * traverse_ray for segment [tmin,tmax)): returns the count, fills cx/cy/cz/t_exit/occ[max_n]
+ * and the initial tdist/delta/step in state[9] */
+ORC_API int64_t orc_debug_cells(const float *o, const float *d, float tmin, float tmax, const float *box,
+                                const int32_t *res, const uint8_t *binaries, int64_t max_n,
+                                int32_t *cx, int32_t *cy, int32_t *cz, float *t_exit, uint8_t *occ, float *state)
+{
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const int r3[3] = {res[0], res[1], res[2]};
+    dda_t s;
+    dda_setup(&s, o, d, inv, tmin, tmax, 1e-6f, box, r3);
+    for (int k = 0; k < 3; ++k) { state[k] = s.tdist[k]; state[3 + k] = s.delta[k]; state[6 + k] = (float)s.step[k]; }
+    int64_t n = 0;
+    for (;;) {
+        float t_cell = fminf(s.tdist[0], fminf(s.tdist[1], s.tdist[2]));
+        t_cell = fminf(t_cell, tmax);
+        if (n < max_n) {
+            cx[n] = s.cur[0]; cy[n] = s.cur[1]; cz[n] = s.cur[2]; t_exit[n] = t_cell;
+            occ[n] = binaries[((int64_t)s.cur[0] * r3[1] + s.cur[1]) * r3[2] + s.cur[2]];
+        }
+        ++n;
+        if (!dda_advance(&s)) break;
+    }
+    return n;
+}
