@@ -96,7 +96,7 @@ typedef struct nfa_traverse_args {
      * iv_* describe interval edges (RaySegmentsSpec intervals), sm_* samples. iv pair nullable. */
     int64_t *iv_cnts, *iv_starts; /* [n_rays] */
     int64_t *sm_cnts, *sm_starts; /* [n_rays] */
-    int64_t *totals;            /* [4] = {n_edges, n_samples, n_overflow_rays, 0}; device memory */
+    int64_t *totals;            /* [4] = {n_edges, n_samples, n_overflow_rays, 0}; device-visible (pinned host ok) */
     /* fill outputs, each nullable (grid.cu:219-255) */
     float *iv_vals; int64_t *iv_ray_indices; uint8_t *iv_is_left; uint8_t *iv_is_right; /* [n_edges]; masks pre-zeroed */
     float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;                      /* [n_samples] */
@@ -105,14 +105,16 @@ typedef struct nfa_traverse_args {
     float *terminate_planes;    /* [n_rays] nullable */
 } nfa_traverse_args;
 
-/* pass 1 (grid.cu:413): per-ray counts, then their exclusive sums and the totals; also writes
- * terminate_planes when given.  Besides counting, pass 1 records each ray's samples as
- * run-length records (lattice start, length) in `workspace`, which lets pass 2 emit them
- * without touching the grid again.  totals[2] counts the rays whose runs did not fit (they are
- * re-traversed by pass 2).
+/* pass 1 (grid.cu:413), one kernel: per-ray counts into iv_cnts / sm_cnts, terminate_planes when
+ * given, per-workgroup partial sums and each ray's samples as run-length records (lattice start,
+ * length) in `workspace` — the records let pass 2 emit samples without touching the grid again.
  * workspace: nfa_traverse_workspace_bytes(n_rays) bytes of device scratch. */
 int64_t nfa_traverse_workspace_bytes(int64_t n_rays);
 int nfa_traverse_count(const nfa_traverse_args *args, void *workspace, void *stream);
+/* pass 1b (the cumsum of data_spec.hpp:90), one kernel: iv_starts / sm_starts = exclusive sums of
+ * the counts, totals = {n_edges, n_samples, rays whose runs did not fit (re-traversed by pass 2), 0}.
+ * Same args and workspace as the nfa_traverse_count call it follows. */
+int nfa_traverse_offsets(const nfa_traverse_args *args, const void *workspace, void *stream);
 /* pass 2 (grid.cu:445 / the single over-allocated pass :375): write edges / samples at
  * iv_starts / sm_starts.
  * workspace != NULL: the workspace nfa_traverse_count filled for the SAME args, with

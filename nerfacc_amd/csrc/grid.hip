@@ -684,18 +684,20 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;   // valid in lane 0
 }
 
-// block-level reduction of the per-ray counts -> block_sums[2 b + {0,1}]
-__device__ __forceinline__ void publish_block_sums(int64_t n_iv, int64_t n_sm, int64_t *__restrict__ block_sums) {
-    __shared__ int64_t part[2][kWavesPerBlock];
-    const int64_t w_iv = wave_sum_i64(n_iv), w_sm = wave_sum_i64(n_sm);
+// block-level reduction of per-ray {edges, samples, overflow rays} -> block_sums[3 b + {0,1,2}]
+// (lanes that do not own a ray pass zeros)
+__device__ __forceinline__ void publish_block_sums(int64_t n_iv, int64_t n_sm, int64_t n_ovf, int64_t *__restrict__ block_sums) {
+    __shared__ int64_t part[3][kWavesPerBlock];
+    const int64_t w_iv = wave_sum_i64(n_iv), w_sm = wave_sum_i64(n_sm), w_ov = wave_sum_i64(n_ovf);
     const int wave = threadIdx.x >> 6;
-    if (lane_id() == 0) { part[0][wave] = w_iv; part[1][wave] = w_sm; }
+    if (lane_id() == 0) { part[0][wave] = w_iv; part[1][wave] = w_sm; part[2][wave] = w_ov; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int64_t s0 = 0, s1 = 0;
-        for (int w = 0; w < kWavesPerBlock; ++w) { s0 += part[0][w]; s1 += part[1][w]; }
-        block_sums[2 * blockIdx.x] = s0;
-        block_sums[2 * blockIdx.x + 1] = s1;
+        int64_t s0 = 0, s1 = 0, s2 = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) { s0 += part[0][w]; s1 += part[1][w]; s2 += part[2][w]; }
+        block_sums[3 * blockIdx.x] = s0;
+        block_sums[3 * blockIdx.x + 1] = s1;
+        block_sums[3 * blockIdx.x + 2] = s2;
     }
 }
 
@@ -718,15 +720,16 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
     } else if (active) {
         traverse_ray_general<CountSink, EV, LDS_OCC>(a, gv, occ, r, sink, t_term);
     }
+    int64_t ovf = 0;
     if (r < a.n_rays) {
         if (active) {
-            if (sink.finish(a.step_size > 0.0f)) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
+            ovf = sink.finish(a.step_size > 0.0f) ? 1 : 0;
             if (a.terminate_planes) a.terminate_planes[r] = t_term;
         } else if (rs.n_runs) rs.n_runs[r] = 0;
         if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
         a.sm_cnts[r] = sink.n_sm;
     }
-    publish_block_sums(sink.n_iv, sink.n_sm, block_sums);
+    publish_block_sums(sink.n_iv, sink.n_sm, ovf, block_sums);
 }
 
 // ---- split walk: P lanes per ray ---------------------------------------------------------
@@ -1036,27 +1039,31 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
                 T_prev = T;
             }
         }
+    }
+    int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
+    if (!bad) {
         if (ray_ok && part == 0) {
             const bool ovf = fresh_total > kMaxRuns;
             if (rs.n_runs) rs.n_runs[r] = (uint8_t)(ovf ? kRunsOverflow : fresh_total);
-            if (ovf) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
-            if (a.iv_cnts) a.iv_cnts[r] = sm_total + fresh_total;
-            a.sm_cnts[r] = sm_total;
+            out_iv = sm_total + fresh_total;
+            out_sm = sm_total;
+            out_ovf = ovf ? 1 : 0;
             if (a.terminate_planes) a.terminate_planes[r] = last_part_with_ev >= 0 ? T_final : t_seg;
-            atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8)), (unsigned long long)(sm_total + fresh_total));
-            atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8) + 1), (unsigned long long)sm_total);
         }
     } else if (ray_ok && part == 0) {
         CountSink sink{rs, r, R};
         float t_term = 0.f;
         traverse_ray_lattice_inline<EV_ONE, LDS_OCC>(a, gv, occ, r, sink, t_term);
-        if (sink.finish(true)) atomicAdd((unsigned long long *)(a.totals + 2), 1ull);
-        if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
-        a.sm_cnts[r] = sink.n_sm;
+        out_ovf = sink.finish(true) ? 1 : 0;
+        out_iv = sink.n_iv;
+        out_sm = sink.n_sm;
         if (a.terminate_planes) a.terminate_planes[r] = t_term;
-        atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8)), (unsigned long long)sink.n_iv);
-        atomicAdd((unsigned long long *)(block_sums + 2 * (r >> 8) + 1), (unsigned long long)sink.n_sm);
     }
+    if (ray_ok && part == 0) {
+        if (a.iv_cnts) a.iv_cnts[r] = out_iv;
+        a.sm_cnts[r] = out_sm;
+    }
+    publish_block_sums(out_iv, out_sm, out_ovf, block_sums);     // this block's kBlock / P rays
 }
 
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
@@ -1083,18 +1090,23 @@ __device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t *lds /
     return wave_off + inc - v;
 }
 
-// pass 1b: offsets.  Every block first adds up the block sums before it (<= R/256 values,
-// L2-resident), then scans its own 256 counts.  The last block also stores the totals.
+// pass 1b: offsets.  The count kernels publish one {edges, samples, overflow} triple per
+// workgroup of `rays_per_sum` rays; every block here first adds up the triples before its own
+// 256 rays (<= R / rays_per_sum values, L2-resident), then scans its 256 counts.  The last
+// block stores the totals.
 __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     const int64_t *__restrict__ iv_cnts, int64_t *__restrict__ iv_starts,
     const int64_t *__restrict__ sm_cnts, int64_t *__restrict__ sm_starts,
-    int64_t n_rays, const int64_t *__restrict__ block_sums, int64_t *__restrict__ totals)
+    int64_t n_rays, const int64_t *__restrict__ block_sums, int sums_per_block, int64_t n_sums,
+    int64_t *__restrict__ totals)
 {
     __shared__ int64_t lds[kWavesPerBlock];
     __shared__ int64_t base[2];
     const int b = blockIdx.x;
+    const bool last = b == (int)gridDim.x - 1;
     int64_t p0 = 0, p1 = 0;
-    for (int j = threadIdx.x; j < b; j += kBlock) { p0 += block_sums[2 * j]; p1 += block_sums[2 * j + 1]; }
+    const int64_t before = (int64_t)b * sums_per_block;
+    for (int64_t j = threadIdx.x; j < before; j += kBlock) { p0 += block_sums[3 * j]; p1 += block_sums[3 * j + 1]; }
     int64_t t0, t1;
     block_excl_scan_i64(p0, lds, t0);
     block_excl_scan_i64(p1, lds, t1);
@@ -1107,13 +1119,20 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
         const int64_t c = in ? iv_cnts[r] : 0;
         const int64_t e = block_excl_scan_i64(c, lds, tot);
         if (in) iv_starts[r] = base[0] + e;
-        if (b == (int)gridDim.x - 1 && threadIdx.x == 0) totals[0] = base[0] + tot;
-    } else if (b == (int)gridDim.x - 1 && threadIdx.x == 0) totals[0] = 0;
+        if (last && threadIdx.x == 0) totals[0] = base[0] + tot;
+    } else if (last && threadIdx.x == 0) totals[0] = 0;
     {
         const int64_t c = in ? sm_cnts[r] : 0;
         const int64_t e = block_excl_scan_i64(c, lds, tot);
         if (in) sm_starts[r] = base[1] + e;
-        if (b == (int)gridDim.x - 1 && threadIdx.x == 0) totals[1] = base[1] + tot;
+        if (last && threadIdx.x == 0) totals[1] = base[1] + tot;
+    }
+    if (last) {                                   // rays that need the pass-2 re-traversal
+        int64_t ov = 0;
+        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
+        int64_t tov;
+        block_excl_scan_i64(ov, lds, tov);
+        if (threadIdx.x == 0) { totals[2] = tov; totals[3] = 0; }
     }
 }
 
@@ -1263,8 +1282,9 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     return gv;
 }
 
-// workspace layout (bytes): [ block_sums: 2*nb int64 ][ run t0: kMaxRuns*R f32 ][ run len: kMaxRuns*R i32 ][ n_runs: R u8 ]
-inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 16 * ceil_div(n_rays > 0 ? n_rays : 1, kBlock); }
+// workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: kMaxRuns*R f32 ][ run len: kMaxRuns*R i32 ][ n_runs: R u8 ]
+// one triple per 16 rays is the finest granularity any count kernel publishes
+inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * ceil_div(n_rays > 0 ? n_rays : 1, 16); }
 RunStore make_runs(void *workspace, int64_t n_rays) {
     RunStore rs;
     uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
@@ -1341,31 +1361,10 @@ NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     return ws_block_sums_bytes(R) + (int64_t)kMaxRuns * R * 8 + ceil_div(R, 16) * 16;
 }
 
-NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, void *stream)
-{
-    if (int rc = validate_traverse(a)) return rc;
-    NFA_REQUIRE(a->totals != nullptr, "traverse_count: totals is NULL");
-    hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s);
-    if (a->n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(workspace != nullptr, "traverse_count: workspace is NULL");
-    const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    int64_t *block_sums = (int64_t *)workspace;
-    const RunStore rs = make_runs(workspace, a->n_rays);
+// lanes per ray of the count pass for this call (1 = lane-per-ray kernels)
+static int count_lanes_per_ray(const nfa_traverse_args *a) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
-    const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
-#define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
-    do {                                                                                                                    \
-        if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
-        hipLaunchKernelGGL((traverse_count_kernel<EVM, LAT, LDSO>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
-    } while (0)
-#define NFA_COUNT_EV(EVM)                                                              \
-    do {                                                                               \
-        if (lattice) { if (lds_occ) NFA_LAUNCH_COUNT(EVM, true, true); else NFA_LAUNCH_COUNT(EVM, true, false); }   \
-        else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true); else NFA_LAUNCH_COUNT(EVM, false, false); } \
-    } while (0)
-    const bool split = lattice && evm == EV_ONE && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
-    // lanes per ray: enough waves to give every SIMD a few (latency hiding), no more
+    const bool split = lattice && !a->t_sorted && a->n_grids == 1 && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
     int P = 1;
     if (split) {
         // measured on MI355X (profiles/r01_split_sweep.md): 16 lanes per ray wins while the ray
@@ -1377,13 +1376,25 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
         }
     }
+    return P;
+}
+
+NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, void *stream)
+{
+    if (int rc = validate_traverse(a)) return rc;
+    if (a->n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(workspace != nullptr, "traverse_count: workspace is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t *block_sums = (int64_t *)workspace;
+    const RunStore rs = make_runs(workspace, a->n_rays);
+    const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
+    const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
+    const int P = count_lanes_per_ray(a);
     if (P > 1) {
         const int cap = P >= 8 ? 8 : 16;
         int lds = 0;
         const GridView gv = make_view(a, cap * kBlock * 8, &lds);
         const bool lds_occ = gv.lds_words > 0;
-        // per-ray totals are added to the 256-ray block sums with atomics
-        (void)hipMemsetAsync(block_sums, 0, 16 * (size_t)nb, s);
         const unsigned nbs = (unsigned)ceil_div(a->n_rays, kBlock / P);
 #define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
     do {                                                                                                                       \
@@ -1398,22 +1409,42 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 8); else NFA_LAUNCH_SPLIT(false, 16, 8);
         }
 #undef NFA_LAUNCH_SPLIT
-        if (int rc = check_launch("traverse_count_split_kernel")) return rc;
-        hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s,
-                           a->iv_cnts, a->iv_starts, a->sm_cnts, a->sm_starts, a->n_rays, block_sums, a->totals);
-        return check_launch("traverse_offsets_kernel");
+        return check_launch("traverse_count_split_kernel");
     }
+    const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     int lds = 0;
     const GridView gv = make_view(a, kEvBytes, &lds);
     const bool lds_occ = gv.lds_words > 0;
+#define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
+    do {                                                                                                                    \
+        if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((traverse_count_kernel<EVM, LAT, LDSO>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    } while (0)
+#define NFA_COUNT_EV(EVM)                                                              \
+    do {                                                                               \
+        if (lattice) { if (lds_occ) NFA_LAUNCH_COUNT(EVM, true, true); else NFA_LAUNCH_COUNT(EVM, true, false); }   \
+        else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true); else NFA_LAUNCH_COUNT(EVM, false, false); } \
+    } while (0)
     if (evm == EV_PRE) NFA_COUNT_EV(EV_PRE);
     else if (evm == EV_ONE) NFA_COUNT_EV(EV_ONE);
     else NFA_COUNT_EV(EV_MANY);
 #undef NFA_COUNT_EV
 #undef NFA_LAUNCH_COUNT
-    if (int rc = check_launch("traverse_count_kernel")) return rc;
-    hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s,
-                       a->iv_cnts, a->iv_starts, a->sm_cnts, a->sm_starts, a->n_rays, block_sums, a->totals);
+    return check_launch("traverse_count_kernel");
+}
+
+NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *workspace, void *stream)
+{
+    if (int rc = validate_traverse(a)) return rc;
+    NFA_REQUIRE(a->totals != nullptr, "traverse_offsets: totals is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->n_rays == 0) { (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s); return NFA_OK; }
+    NFA_REQUIRE(workspace != nullptr, "traverse_offsets: workspace is NULL");
+    const int P = count_lanes_per_ray(a);
+    const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
+    const int64_t n_sums = ceil_div(a->n_rays, kBlock / P);
+    hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
+                       a->sm_starts, a->n_rays, (const int64_t *)workspace, P, n_sums, a->totals);
     return check_launch("traverse_offsets_kernel");
 }
 

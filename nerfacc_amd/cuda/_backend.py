@@ -65,6 +65,7 @@ _SIGNATURES = {
     "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
+    "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P, c_int64, c_int64, _P]),
     "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
     "nfa_pack_info": (ctypes.c_int, [_P, c_int64, c_int64, _P, _P]),
@@ -235,6 +236,28 @@ class RaySegmentsSpec:
 
 
 # --------------------------------------------------------------------------------------
+# host readback of the few integers a call needs (sample totals, kept counts).  The kernels
+# store them straight into pinned host memory (device-visible on ROCm), so the readback is a
+# stream wait plus a CPU load — no D2H copy to launch.
+# --------------------------------------------------------------------------------------
+_pinned = {}
+
+
+def _host_ints(device: torch.device, n: int = 4) -> torch.Tensor:
+    key = (device.index, n)
+    buf = _pinned.get(key)
+    if buf is None:
+        buf = torch.zeros(n, dtype=torch.int64).pin_memory()
+        _pinned[key] = buf
+    return buf
+
+
+def _read_ints(buf: torch.Tensor, device: torch.device):
+    torch.cuda.current_stream(device).synchronize()
+    return buf.tolist()
+
+
+# --------------------------------------------------------------------------------------
 # occupancy bricks: packed once per distinct `binaries` tensor state
 # --------------------------------------------------------------------------------------
 _brick_cache = {"ref": None, "version": None, "bricks": None, "nonempty": -1}
@@ -374,13 +397,14 @@ class _C:
                 iv_cnts = torch.empty(R, **i64) if compute_intervals else None
                 iv_starts = torch.empty(R, **i64) if compute_intervals else None
                 sm_cnts, sm_starts = torch.empty(R, **i64), torch.empty(R, **i64)
-                totals = torch.empty(4, **i64)
+                totals = _host_ints(dev)
                 ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
                 a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
                 a.sm_cnts, a.sm_starts, a.totals = _ptr(sm_cnts), _ptr(sm_starts), _ptr(totals)
                 a.terminate_planes = _ptr(terminate)
                 _check(L.nfa_traverse_count(ctypes.byref(a), _ptr(ws), stream))
-                n_edges, n_samples, n_overflow, _ = totals.tolist()   # the one host sync (data_spec.hpp:91)
+                _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
+                n_edges, n_samples, n_overflow, _ = _read_ints(totals, dev)   # the one host sync (data_spec.hpp:91)
             a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
             a.sm_cnts, a.sm_starts = _ptr(sm_cnts), _ptr(sm_starts)
             if compute_intervals:
@@ -580,11 +604,12 @@ class _C:
             a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, None, None, None, near_planes, far_planes,
                                step_size, cone_angle, -1)
             packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
-            totals = torch.empty(4, **i64)
+            totals = _host_ints(dev)
             ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
             a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
             _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
-            _, n, n_overflow, _ = totals.tolist()
+            _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
+            _, n, n_overflow, _ = _read_ints(totals, dev)
             ray_indices = torch.empty(n, **i64)
             ts = torch.empty((2, n), dtype=torch.float32, device=dev)
             a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
@@ -651,13 +676,13 @@ class _C:
         o_idx = torch.empty(n, dtype=torch.int64, device=dev)
         o_t = torch.empty((2, n), dtype=torch.float32, device=dev)
         mask = torch.empty(n, dtype=torch.bool, device=dev) if want_mask else None
-        n_out = torch.empty(1, dtype=torch.int64, device=dev)
+        n_out = _host_ints(dev)
         ws = torch.empty(max(L.nfa_visibility_workspace_bytes(n), 16), dtype=torch.uint8, device=dev)
         with _Guard(dens):
             _check(_call("visibility", L.nfa_visibility_compact, _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n,
                                             early_stop_eps, alpha_thre, _ptr(o_idx), o_t[0].data_ptr(), o_t[1].data_ptr(),
                                             _ptr(mask), _ptr(n_out), _ptr(ws), _stream(dens)))
-        k = n_out.item()
+        k = _read_ints(n_out, dev)[0]
         return o_idx[:k], o_t[0, :k], o_t[1, :k], mask
 
     @staticmethod
