@@ -153,3 +153,36 @@ def test_traverse_empty_inputs_and_errors():
         traverse_grids(torch.rand(5, 3), torch.rand(5, 3), B.cpu(), A.cpu())
     with pytest.raises(AssertionError):
         traverse_grids(torch.rand(5, 3, device=DEV), torch.rand(5, 3, device=DEV), B, A, over_allocate=True)
+
+
+def test_traverse_large_grid_global_occupancy_path():
+    """2 levels of 256^3 (BASELINE configs[4] resolution): the brick bitmap no longer fits the
+    LDS budget, so the kernels read the sparse occupancy from L2 instead — same results."""
+    from nerfacc_amd.grid import traverse_grids
+
+    rng = np.random.default_rng(7)
+    o, d, aabbs, _ = scene(11, n_rays=200, levels=2, res=8)
+    g = (np.arange(256) + 0.5) / 256 * 2 - 1
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    shell = (np.abs(np.sqrt(X**2 + Y**2 + Z**2) - 0.6) < 0.05) | ((np.abs(X) < 0.02) & (np.abs(Y) < 0.5))
+    binaries = np.stack([shell, rng.random((256, 256, 256)) < 0.02])
+    for kw in (dict(step_size=4e-3), dict(step_size=4e-3, cone_angle=0.003)):
+        r_iv, r_sm, r_term = oracle.traverse_grids(o, d, binaries, aabbs, **kw)
+        iv, sm, term = traverse_grids(t(o), t(d), t(binaries), t(aabbs), **kw)
+        assert r_sm["vals"].shape[0] > 1000
+        _compare(iv, sm, term, r_iv, r_sm, r_term)
+
+
+def test_sampling_many_rays_serial_and_split_walks_agree():
+    """the count pass uses 16 lanes per ray below ~20 k rays and one lane per ray above: both
+    must give the oracle's answer (same scene, 4 k and 30 k rays)"""
+    from nerfacc_amd import cuda as C
+
+    for n_rays in (4000, 30000):
+        o, d, aabb, occ = lego_like(5, n_rays)
+        near = np.zeros(n_rays, np.float32)
+        far = np.full(n_rays, 1e10, np.float32)
+        ri, ts, te, pk = C.sample_occgrid(t(o), t(d), t(occ), t(aabb), t(near), t(far), 5e-3, 0.0)
+        r_ri, r_ts, r_te, r_pk = oracle.sampling(o, d, occ, aabb, render_step_size=5e-3)
+        assert np.array_equal(n(ri), r_ri) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
+        assert np.array_equal(n(pk), r_pk)
