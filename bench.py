@@ -259,11 +259,14 @@ def main():
         if g_samples > 0:
             # train_ngp_nerf_occ.py:187-194, on the global counts so all ranks stay in step
             state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
+        optimizer.zero_grad()
         if n_samples > 0:
             loss = F.smooth_l1_loss(rgb, pixels)
-            optimizer.zero_grad()
             (loss * loss_scale).backward()
-            sharding.allreduce_gradients(field.parameters())
+        # every rank takes part in the exchange every step, samples or not (a rank that skipped
+        # the collective would deadlock the others); missing grads count as zeros
+        sharding.allreduce_gradients(field.parameters())
+        if n_samples > 0 or world_size > 1:
             optimizer.step()
         stats["rays"] += n
         stats["samples"] += n_samples

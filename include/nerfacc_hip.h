@@ -79,7 +79,9 @@ typedef struct nfa_traverse_args {
     int32_t res[3];
     const uint64_t *bricks;     /* from nfa_pack_binaries */
     int64_t n_nonempty_bricks;  /* bricks[n_bricks] (the header word nfa_pack_binaries writes) if the
-                                   caller has read it back, else -1; only sizes the kernels' LDS image */
+                                   caller has read it back, else -1.  When given it MUST be that value:
+                                   it sizes the kernels' LDS image of the grid; with -1 (or a grid too
+                                   large for LDS) the kernels read the packed grid from L2 instead */
     const float *aabbs;         /* [n_grids, 6] */
     /* sorted ray/grid intersections (grid.py:156-162).  All three nullable together: when
      * NULL the kernel runs the slab test and the per-ray sort of the 2*n_grids events itself. */

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/nerfacc_hip.h"
 
@@ -163,6 +164,10 @@ __device__ __forceinline__ TileRange snapped_tile(const int64_t *__restrict__ ke
 // nominal tile size: multiples of 64, small enough to give every SIMD of the chip a few waves
 // on mid-size inputs, large enough (<= 2048) to amortise the boundary search on big ones.
 inline int64_t pick_tile(int64_t n) {
+    if (const char *e = getenv("NFA_TILE")) {           // tuning knob (multiple of 64)
+        const int64_t v = atoll(e);
+        if (v >= 64 && v % 64 == 0) return v;
+    }
     const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
     int64_t t = ceil_div(ceil_div(n, target_waves), 64) * 64;
     if (t < 256) t = 256;

@@ -340,10 +340,10 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
             const uint32_t w = lc[id >> 5];
             if (w & bit) {
                 const int k = (int)lc[l.w4 + (id >> 5)] + __popc(w & (bit - 1u));
-                // unconditional ds_read (clamped) + rare global override: a select between an LDS
-                // and a global pointer would turn into a flat load
-                bits = ((const uint64_t *)(lc + 2 * l.w4))[min(k, l.cap - 1)];
-                if (k >= l.cap) bits = g.compact[k];
+                // the LDS image holds ALL non-empty bricks (make_view only selects this variant
+                // when they fit), so there is no global fallback here: a "k < cap ? lds : global"
+                // select is compiled into one flat load, which is what this code avoids
+                bits = ((const uint64_t *)(lc + 2 * l.w4))[k];
             }
         } else {
             const uint32_t w = g.coarse[id >> 5];
@@ -902,6 +902,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     BrickCache cache;
     cache.id = -1;
     cache.bits = 0;
+#ifdef NFA_ABL_NOSEAM
+    if (j_begin > 0) part_live = false;
+#endif
     if (part_live && j_begin > 0) {
         const float t0m = m_rank == 2 ? s.tx : (m_rank == 1 ? s.ty : s.tz);
         const float dm = m_rank == 2 ? s.dx : (m_rank == 1 ? s.dy : s.dz);
@@ -923,6 +926,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         }
     }
 
+#ifdef NFA_ABL_NOWALK
+    part_live = false;
+#endif
     // ---- A: this part's voxels, boundaries only
     int n_ev = 0, major_done = j_begin;
     unsigned ev_occ = 0;
@@ -1267,14 +1273,13 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     gv.n_words = (int)L.n_words;
     const int64_t words_bytes = 2 * (((int64_t)L.n_words + 3) & ~3ll) * 4;
     const int64_t room = (int64_t)kLdsBudget - ev_bytes - 16 - words_bytes;
-    if (room >= 2048) {
+    // LDS variant only when the caller told us how many bricks are non-empty and they all fit
+    const int64_t need = a->n_nonempty_bricks >= 0 ? (a->n_nonempty_bricks > 0 ? a->n_nonempty_bricks : 1) : -1;
+    if (need > 0 && room >= need * 8) {
         gv.lds_words = (int)L.n_words;
-        int64_t cap = room / 8;
-        if (cap > L.n_bricks) cap = L.n_bricks;
-        if (a->n_nonempty_bricks >= 0 && cap > a->n_nonempty_bricks) cap = a->n_nonempty_bricks > 0 ? a->n_nonempty_bricks : 1;
-        gv.lds_compact_cap = (int)cap;
-        *lds_bytes = (int)(((words_bytes + cap * 8 + 15) & ~15ll) + ev_bytes);
-    } else {                                      // bitmap too large for LDS: everything from L2
+        gv.lds_compact_cap = (int)need;
+        *lds_bytes = (int)(((words_bytes + need * 8 + 15) & ~15ll) + ev_bytes);
+    } else {                                      // unknown count or too large for LDS: read from L2
         gv.lds_words = 0;
         gv.lds_compact_cap = 0;
         *lds_bytes = ev_bytes;
@@ -1367,10 +1372,11 @@ static int count_lanes_per_ray(const nfa_traverse_args *a) {
     const bool split = lattice && !a->t_sorted && a->n_grids == 1 && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
     int P = 1;
     if (split) {
-        // measured on MI355X (profiles/r01_split_sweep.md): 16 lanes per ray wins while the ray
-        // batch is too small to fill the chip (<= ~20 k rays: 86 us vs 139 us at 13 k rays); above
-        // that the lane-per-ray walk does the same in fewer instructions (134 us at 40 k rays).
-        if (a->n_rays <= 20000) P = 16;
+        // measured on MI355X (profiles/r01_split_sweep.md): splitting pays while the ray batch is
+        // too small to fill the chip with one lane per ray; beyond ~40 k rays the lane-per-ray
+        // walk does the same job in fewer instructions.
+        if (a->n_rays <= 16384) P = 8;
+        else if (a->n_rays <= 36864) P = 4;
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
@@ -1391,7 +1397,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
     const int P = count_lanes_per_ray(a);
     if (P > 1) {
-        const int cap = P >= 8 ? 8 : 16;
+        const int cap = P >= 16 ? 8 : 16;
         int lds = 0;
         const GridView gv = make_view(a, cap * kBlock * 8, &lds);
         const bool lds_occ = gv.lds_words > 0;
@@ -1403,10 +1409,10 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     } while (0)
         if (lds_occ) {
             if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
-            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 8); else NFA_LAUNCH_SPLIT(true, 16, 8);
+            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
         } else {
             if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 16);
-            else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 8); else NFA_LAUNCH_SPLIT(false, 16, 8);
+            else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 8);
         }
 #undef NFA_LAUNCH_SPLIT
         return check_launch("traverse_count_split_kernel");
