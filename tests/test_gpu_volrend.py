@@ -252,3 +252,21 @@ def test_large_n_properties():
     assert torch.allclose(lhs, rhs, atol=1e-5)
     assert torch.equal(render_weight_from_density(ts, te, sig, ray_indices=ri)[0], w)
     assert torch.equal(pack_info(ri, R)[:, 1], cnts)
+
+
+def test_accumulate_unsorted_ray_indices_like_index_add():
+    """the reference's index_add_ accepts any order of ray_indices; grouped-but-not-ascending and
+    fully interleaved indices must give the same sums here (runs of one ray in different wave
+    tiles meet through float atomics)"""
+    from nerfacc_amd.volrend import accumulate_along_rays
+
+    rng = np.random.default_rng(3)
+    for ri_ in (np.array([2, 2, 0, 0, 1, 1, 1], np.int64),
+                rng.integers(0, 50, 20000).astype(np.int64),
+                np.repeat(rng.permutation(3000), 7).astype(np.int64)):
+        N, R = ri_.shape[0], int(ri_.max()) + 1
+        w_ = rng.random(N).astype(np.float32)
+        v_ = rng.random((N, 3)).astype(np.float32)
+        out = accumulate_along_rays(t(w_), t(v_), t(ri_), R)
+        ref = torch.zeros(R, 3, device=DEV).index_add_(0, t(ri_), t(w_)[:, None] * t(v_))
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
