@@ -77,27 +77,79 @@ struct OpProd {
     static __device__ __forceinline__ float apply(float a, float b) { return a * b; }
 };
 
+// --- cross-lane moves on the DPP path ----------------------------------------------------
+// ds_bpermute shuffles go through the LDS crossbar (~100+ cycles each, and a scan is a chain of
+// dependent ones); DPP operand modifiers move data inside the VALU in a few cycles.  gfx950
+// still has the GFX9 full set: row_shr/row_shl (within a 16-lane row), row_bcast:15/31
+// (last lane of a row / of the lower half to the following rows) and wave_shr/wave_shl:1.
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138,
+              kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+// lanes without a source (outside the row / wave) keep `old`
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int64_t dpp_i64(int64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v >> 32), CTRL, 0xf, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+// value of lane-1 (lane 0 gets `fill`) / lane+1 (lane 63 gets `fill`)
+__device__ __forceinline__ float lane_prev_f(float v, float fill) { return dpp_f<kDppWaveShr1>(fill, v); }
+__device__ __forceinline__ float lane_next_f(float v, float fill) { return dpp_f<kDppWaveShl1>(fill, v); }
+__device__ __forceinline__ int64_t lane_prev_i64(int64_t v) { return dpp_i64<kDppWaveShr1>(v); }
+__device__ __forceinline__ int64_t lane_next_i64(int64_t v) { return dpp_i64<kDppWaveShl1>(v); }
+
+// wave-uniform read of one lane (v_readlane_b32: VALU -> SGPR, no LDS); SRC is a constant
+template <int SRC>
+__device__ __forceinline__ float readlane_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), SRC));
+}
+template <int SRC>
+__device__ __forceinline__ int64_t readlane_i64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, SRC);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), SRC);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // Segmented inclusive scan over the 64 lanes of a wave, forward (towards higher lanes).
 // `dist` = number of lanes between this lane and the first lane of its segment inside this
-// wave-chunk (0 for a segment head).  Hillis-Steele with ds_bpermute shuffles; a lane only
-// accepts a partner that lies inside its own segment.
+// wave-chunk (0 for a segment head).  Four row_shr steps scan each 16-lane row, row_bcast:15
+// then row_bcast:31 stitch the rows; a lane only accepts a partner inside its own segment.
 template <class Op>
 __device__ __forceinline__ float wave_seg_scan_fwd(float v, int dist) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float u = __shfl_up(v, off, 64);
-        if (dist >= off) v = Op::apply(u, v);
-    }
+    const int lane = lane_id();
+    const int rl = lane & 15;
+    const int dr = dist < rl ? dist : rl;
+    float u;
+    u = dpp_f<kDppRowShr + 1>(Op::identity(), v); if (dr >= 1) v = Op::apply(u, v);
+    u = dpp_f<kDppRowShr + 2>(Op::identity(), v); if (dr >= 2) v = Op::apply(u, v);
+    u = dpp_f<kDppRowShr + 4>(Op::identity(), v); if (dr >= 4) v = Op::apply(u, v);
+    u = dpp_f<kDppRowShr + 8>(Op::identity(), v); if (dr >= 8) v = Op::apply(u, v);
+    u = dpp_f<kDppRowBcast15>(Op::identity(), v); if ((lane & 16) && dist > rl) v = Op::apply(u, v);
+    u = dpp_f<kDppRowBcast31>(Op::identity(), v); if ((lane & 32) && dist > (lane & 31)) v = Op::apply(u, v);
     return v;
 }
 // Same, towards lower lanes; `dist` = lanes between this lane and the last lane of its segment.
+// There is no downward row broadcast, so the rows are stitched with three v_readlane.
 template <class Op>
 __device__ __forceinline__ float wave_seg_scan_bwd(float v, int dist) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float u = __shfl_down(v, off, 64);
-        if (dist >= off) v = Op::apply(v, u);
-    }
+    const int lane = lane_id();
+    const int rr = 15 - (lane & 15);
+    const int row = lane >> 4;
+    const int dr = dist < rr ? dist : rr;
+    float u;
+    u = dpp_f<kDppRowShl + 1>(Op::identity(), v); if (dr >= 1) v = Op::apply(v, u);
+    u = dpp_f<kDppRowShl + 2>(Op::identity(), v); if (dr >= 2) v = Op::apply(v, u);
+    u = dpp_f<kDppRowShl + 4>(Op::identity(), v); if (dr >= 4) v = Op::apply(v, u);
+    u = dpp_f<kDppRowShl + 8>(Op::identity(), v); if (dr >= 8) v = Op::apply(v, u);
+    const bool reaches = dist > rr;
+    u = readlane_f<48>(v); if (row == 2 && reaches) v = Op::apply(v, u);
+    u = readlane_f<32>(v); if (row == 1 && reaches) v = Op::apply(v, u);
+    u = readlane_f<16>(v); if (row == 0 && reaches) v = Op::apply(v, u);
     return v;
 }
 
@@ -117,7 +169,6 @@ __device__ __forceinline__ int dist_to_tail(unsigned long long tails, int lane, 
     return open ? 63 - lane : (__ffsll((long long)m) - 1) - lane;
 }
 
-__device__ __forceinline__ float readlane_f(float v, int src) { return __shfl(v, src, 64); }
 
 // ----------------------------------------------------------------------------------------
 // Snapped tiling of a key-grouped array (DESIGN.md "segment-snapped wave tiles").
@@ -162,7 +213,10 @@ __device__ __forceinline__ TileRange snapped_tile(const int64_t *__restrict__ ke
 }
 
 // nominal tile size: multiples of 64, small enough to give every SIMD of the chip a few waves
-// on mid-size inputs, large enough (<= 2048) to amortise the boundary search on big ones.
+// on mid-size inputs.  Capped at 576 (nine chunks, not a power of two): with big tiles every
+// resident wave streams its own region `tile` elements apart, and at 2048 x 4 B = 8 KiB spacing
+// the concurrent 256-byte requests alias onto a subset of the HBM channels (measured at
+// N = 2^24: weight_bwd 3.77 -> 4.80 TB/s, keyed scan 4.03 -> 4.77 TB/s, profiles/r01_tile_sweep.md).
 inline int64_t pick_tile(int64_t n) {
     if (const char *e = getenv("NFA_TILE")) {           // tuning knob (multiple of 64)
         const int64_t v = atoll(e);
@@ -171,7 +225,7 @@ inline int64_t pick_tile(int64_t n) {
     const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
     int64_t t = ceil_div(ceil_div(n, target_waves), 64) * 64;
     if (t < 256) t = 256;
-    if (t > 2048) t = 2048;
+    if (t > 576) t = 576;
     return t;
 }
 

@@ -28,7 +28,7 @@ struct SegFwd {
 };
 __device__ __forceinline__ SegFwd seg_fwd(int64_t key, bool active, bool first_chunk, int64_t edge_key, int lane) {
     SegFwd s;
-    const int64_t pk = __shfl_up(key, 1, 64);
+    const int64_t pk = lane_prev_i64(key);
     s.head = !active || key != pk;
     if (lane == 0) s.head = first_chunk || key != edge_key;
     s.heads = __ballot(s.head);
@@ -49,7 +49,7 @@ struct SegBwd {
 };
 __device__ __forceinline__ SegBwd seg_bwd(int64_t key, bool active, int64_t i, int64_t end, int64_t edge_key, int lane) {
     SegBwd s;
-    const int64_t nk = __shfl_down(key, 1, 64);
+    const int64_t nk = lane_next_i64(key);
     s.tail = !active || (i + 1 >= end) || key != nk;
     if (lane == 63 && active && i + 1 < end) s.tail = key != edge_key;
     const unsigned long long tails = __ballot(s.tail);
@@ -60,25 +60,25 @@ __device__ __forceinline__ SegBwd seg_bwd(int64_t key, bool active, int64_t i, i
 __device__ __forceinline__ float seg_incl_fwd(float v, const SegFwd &s, float &carry) {
     float incl = wave_seg_scan_fwd<OpSum>(v, s.dist);
     if (s.open) incl += carry;
-    carry = readlane_f(incl, 63);
+    carry = readlane_f<63>(incl);
     return incl;
 }
 __device__ __forceinline__ float seg_excl_fwd(float v, const SegFwd &s, float &carry, int lane) {
     float incl = wave_seg_scan_fwd<OpSum>(v, s.dist);
     if (s.open) incl += carry;
-    float excl = __shfl_up(incl, 1, 64);
+    float excl = lane_prev_f(incl, 0.0f);
     if (s.head) excl = 0.0f;
     else if (lane == 0) excl = carry;
-    carry = readlane_f(incl, 63);
+    carry = readlane_f<63>(incl);
     return excl;
 }
 __device__ __forceinline__ float seg_excl_bwd(float v, const SegBwd &s, float &carry, int lane) {
     float incl = wave_seg_scan_bwd<OpSum>(v, s.dist);
     if (s.open) incl += carry;
-    float excl = __shfl_down(incl, 1, 64);
+    float excl = lane_next_f(incl, 0.0f);
     if (s.tail) excl = 0.0f;
     else if (lane == 63) excl = carry;
-    carry = readlane_f(incl, 0);
+    carry = readlane_f<0>(incl);
     return excl;
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
         if (active) { key = keys[i]; sd = sigmas[i] * (te[i] - ts[i]); }
         const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
         const float acc = seg_excl_fwd(sd, s, carry, lane);
-        edge_key = __shfl(key, 63, 64);
+        edge_key = readlane_i64<63>(key);
         if (active) {
             const float a = 1.0f - expf(-sd);
             float T = expf(-acc);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void weight_bwd_kernel(
         const SegBwd s = seg_bwd(key, active, i, tr.end, edge_key, lane);
         const float q = gw * (T * a) + gT * T;
         const float suffix = seg_excl_bwd(q, s, carry, lane);
-        edge_key = __shfl(key, 0, 64);
+        edge_key = readlane_i64<0>(key);
         if (active) g_sigmas[i] = ((gw * T + ga) * (1.0f - a) - suffix) * (te[i] - ts[i]);
     }
 }
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
             if (from_alpha) {   // exclusive product of (1 - alpha), volrend.py:207-209
                 float incl = wave_seg_scan_fwd<OpProd>(active ? x : 1.0f, s.dist);
                 if (s.open) incl = carry * incl;
-                T = __shfl_up(incl, 1, 64);
+                T = lane_prev_f(incl, 0.0f);
                 if (s.head) T = 1.0f;
                 else if (lane == 0) T = carry;
-                carry = readlane_f(incl, 63);
+                carry = readlane_f<63>(incl);
             } else {
                 T = expf(-seg_excl_fwd(x, s, carry, lane));
             }
-            edge_key = __shfl(key, 63, 64);
+            edge_key = readlane_i64<63>(key);
             bool keep = active && (T >= eps);
             if (alpha_thre > 0.0f) keep = keep && (a >= alpha_thre);
             if (active) mask[i] = keep ? 1 : 0;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(
         if (active) { key = keys[i]; w = weights[i]; }
         const SegFwd s = seg_fwd(key, active, ch == 0, edge_key, lane);
         const bool tail = seg_is_tail(s, keys, key, i, tr.end, active, lane);
-        edge_key = __shfl(key, 63, 64);
+        edge_key = readlane_i64<63>(key);
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
             float v = w;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
         }
         const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
         const bool tail = seg_is_tail(s, keys, key, i, tr.end, active, lane);
-        edge_key = __shfl(key, 63, 64);
+        edge_key = readlane_i64<63>(key);
         const float acc = seg_excl_fwd(sd, s, c_sd, lane);
         float w = 0.0f;
         if (active) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
         }
         const SegBwd s = seg_bwd(key, active, i, tr.end, edge_key, lane);
         const float suffix = seg_excl_bwd(gw * w + gT * T, s, carry, lane);
-        edge_key = __shfl(key, 0, 64);
+        edge_key = readlane_i64<0>(key);
         if (active && g_sigmas) g_sigmas[i] = ((gw * T + ga) * (1.0f - a) - suffix) * dt;
     }
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
         }
         float incl, excl;
         if (!REV) {
-            int64_t pk = __shfl_up(key, 1, 64);
+            int64_t pk = lane_prev_i64(key);
             bool head = !active || key != pk;
             if (lane == 0) head = (c == 0) || key != edge_key;
             const unsigned long long heads = __ballot(head);
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
             const int dist = dist_to_head(heads, lane, open);
             incl = wave_seg_scan_fwd<Op>(v, dist);
             if (open) incl = Op::apply(carry, incl);
-            excl = __shfl_up(incl, 1, 64);
+            excl = lane_prev_f(incl, 0.0f);
             if (head) excl = ident;
             else if (lane == 0) excl = carry;
-            carry = readlane_f(incl, 63);
-            edge_key = __shfl(key, 63, 64);
+            carry = readlane_f<63>(incl);
+            edge_key = readlane_i64<63>(key);
         } else {
-            int64_t nk = __shfl_down(key, 1, 64);
+            int64_t nk = lane_next_i64(key);
             bool tail = !active || (i + 1 >= tr.end) || key != nk;
             if (lane == 63 && active && i + 1 < tr.end) tail = key != edge_key;
             const unsigned long long tails = __ballot(tail);
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
             const int dist = dist_to_tail(tails, lane, open);
             incl = wave_seg_scan_bwd<Op>(v, dist);
             if (open) incl = Op::apply(incl, carry);
-            excl = __shfl_down(incl, 1, 64);
+            excl = lane_next_f(incl, 0.0f);
             if (tail) excl = ident;
             else if (lane == 63) excl = carry;
-            carry = readlane_f(incl, 0);
-            edge_key = __shfl(key, 0, 64);
+            carry = readlane_f<0>(incl);
+            edge_key = readlane_i64<0>(key);
         }
         if (active) {
             float r = INCL ? incl : excl;
