@@ -68,7 +68,8 @@ def lego_like_density(x: torch.Tensor) -> torch.Tensor:
 
 
 class DenseGridField(torch.nn.Module):
-    """sigma = exp(density_grid(x)), rgb = sigmoid(colour_grid(x)); trilinear lookups."""
+    """sigma = exp(g[0](x)), rgb = sigmoid(g[1:4](x)); one 4-channel voxel grid, trilinear lookups
+    (one gather pass forward, one scatter pass backward per query)."""
 
     def __init__(self, aabb, res=128):
         super().__init__()
@@ -81,21 +82,23 @@ class DenseGridField(torch.nn.Module):
         dens = torch.where(occ, math.log(50.0), math.log(1e-4)).float()
         gen = torch.Generator().manual_seed(42)
         col = torch.randn((3, res, res, res), generator=gen) * 0.5 + (pts.permute(3, 0, 1, 2) * 1.5)
-        self.density = torch.nn.Parameter(dens[None, None].contiguous())
-        self.color = torch.nn.Parameter(col[None].contiguous())
+        # stored [1, 4, Z, Y, X] so that grid_sample's (x, y, z) coordinate order needs no shuffle
+        vol = torch.cat([dens[None], col], 0).permute(0, 3, 2, 1)
+        self.grid = torch.nn.Parameter(vol[None].contiguous())
+        self.register_buffer("u_scale", 2.0 / (hi - lo))
+        self.register_buffer("u_shift", -2.0 * lo / (hi - lo) - 1.0)
 
     def _lookup(self, grid, x):
-        lo, hi = self.aabb[:3], self.aabb[3:]
-        u = ((x - lo) / (hi - lo)) * 2.0 - 1.0
-        u = u[:, [2, 1, 0]].view(1, 1, 1, -1, 3)        # grid_sample wants (z, y, x) for a [X, Y, Z] volume
+        u = torch.addcmul(self.u_shift, x, self.u_scale).view(1, 1, 1, -1, 3)
         out = F.grid_sample(grid, u, mode="bilinear", padding_mode="border", align_corners=False)
         return out.view(grid.shape[1], -1).t()
 
     def query_density(self, x):
-        return torch.exp(self._lookup(self.density, x))
+        return torch.exp(self._lookup(self.grid[:, :1], x))
 
     def forward(self, x, dirs=None):
-        return torch.sigmoid(self._lookup(self.color, x)), self.query_density(x)
+        f = self._lookup(self.grid, x)
+        return torch.sigmoid(f[:, 1:4]), torch.exp(f[:, :1])
 
 
 def make_ray_pool(n_pool: int, seed: int, device) -> tuple:
@@ -131,7 +134,7 @@ def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
         if t_starts.shape[0] == 0:
             return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
         pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
-        rgb, sigma = field(pos, rays_d[ray_indices])
+        rgb, sigma = field(pos)            # (this stand-in field has no view dependence)
         return rgb, sigma.squeeze(-1)
 
     ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
@@ -219,7 +222,7 @@ def main():
     field = DenseGridField(AABB, GRID_RES).to(device)
     teacher = DenseGridField(AABB, GRID_RES).to(device).eval()
     est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=GRID_RES, levels=1).to(device)
-    optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6)
+    optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
     loss_scale = 2.0**10
     bkgd = torch.ones(3, device=device)
 

@@ -31,8 +31,8 @@ def train(steps=1500, device="cuda:0", res=128, seed=0, log=print):
     teacher = DenseGridField(AABB, res).to(device).eval()           # analytic scene sampled on a grid
     student = DenseGridField(AABB, res).to(device)
     with torch.no_grad():                                           # start from fog and grey
-        student.density.fill_(math.log(0.5))
-        student.color.zero_()
+        student.grid[:, :1].fill_(math.log(0.5))
+        student.grid[:, 1:].zero_()
     est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=res, levels=1).to(device)
     est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=res, levels=1).to(device)
     est_t.train()

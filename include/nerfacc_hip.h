@@ -64,6 +64,25 @@ int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t r
 int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
                       uint64_t *bricks, void *stream);
 
+/* Occupancy-grid maintenance, the device side of OccGridEstimator._update (occ_grid.py:366-404;
+ * pure torch in the reference).  Random numbers are the caller's (torch generator, reference
+ * call order); everything is asynchronous on `stream`.
+ * nfa_grid_cell_points   :377-384  points[i] = lo + ((coords(id_i) + jitter[i]) / res) * (hi - lo);
+ *                        cell_ids nullable = cells 0..n-1; ids are level-local, x-major; `aabb` is
+ *                        the level's 6 floats in DEVICE memory.
+ * nfa_grid_ema_update    :388-390  occs[id_i] = max(occs[id_i] * ema_decay, occ_new[i]), every
+ *                        candidate formed from the old grid; with repeated ids one candidate wins
+ *                        (as index_put_).  `occs` points at the level's first cell; scratch: n floats.
+ * nfa_grid_threshold     :392-404  binaries[c] = occs[c] > min(mean(occs[occs >= 0]), occ_thre) over
+ *                        all levels; threshold_out (nullable, device) receives the threshold. */
+int nfa_grid_cell_points(const int64_t *cell_ids, int64_t n, const float *jitter,
+                         int32_t rx, int32_t ry, int32_t rz, const float *aabb, float *points, void *stream);
+int nfa_grid_ema_update(float *occs, const int64_t *cell_ids, int64_t n, const float *occ_new,
+                        float ema_decay, float *scratch, void *stream);
+int64_t nfa_grid_threshold_workspace_bytes(void);
+int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_thre, void *workspace,
+                       uint8_t *binaries, float *threshold_out, void *stream);
+
 /* Arguments of traverse_grids (nerfacc.cpp:71-98, grid.cu:320-474).  The reference does
  * count -> cumsum + .item() -> allocate -> fill inside one C++ call; a C ABI cannot allocate
  * torch tensors, so the two halves are separate calls and the caller allocates in between

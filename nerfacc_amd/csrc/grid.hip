@@ -825,12 +825,36 @@ __device__ void traverse_ray_lattice_inline(const nfa_traverse_args &a, const Gr
     t_term = t_last;
 }
 
+#ifdef NFA_PHASE_CYCLES
+// build-time instrumentation (tools/phase_cycles.py builds with -DNFA_PHASE_CYCLES): shader-clock
+// stamps between the phases of the split kernel, kept in registers and stored once per wave at the
+// end (one slot per wave, no atomics); read back with nfa_debug_phase_cycles
+constexpr int kPhaseSlots = 16384;
+__device__ unsigned long long g_phase_cycles[kPhaseSlots][16];
+#define NFA_PHASE_BEGIN() unsigned long long ph_[16] = {0}; unsigned long long phase_t_ = __builtin_readcyclecounter(); const unsigned long long phase_t0_ = phase_t_
+#define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
+#define NFA_PHASE_END()                                                                        \
+    do {                                                                                      \
+        const int slot_ = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);           \
+        if (lane_id() == 0 && slot_ < kPhaseSlots) {                                          \
+            ph_[14] = phase_t0_; ph_[15] = 1;                                                  \
+            for (int i_ = 0; i_ < 16; ++i_) g_phase_cycles[slot_][i_] += ph_[i_];              \
+        }                                                                                     \
+    } while (0)
+#else
+#define NFA_PHASE_MARK(i) do {} while (0)
+#define NFA_PHASE_BEGIN() do {} while (0)
+#define NFA_PHASE_END() do {} while (0)
+#endif
+
 template <bool LDS_OCC, int P, int CAP>
 __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
                                                                       int64_t *__restrict__ block_sums, RunStore rs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    NFA_PHASE_BEGIN();
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    NFA_PHASE_MARK(0);
     const int occ_bytes = LDS_OCC ? (2 * occ.w4 * 4 + gv.lds_compact_cap * 8) : 0;
     float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));        // [CAP][kBlock] times, then [CAP][kBlock] indices
     const int tid = threadIdx.x, part = tid % P;
@@ -862,6 +886,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     s.tx = s.ty = s.tz = 0.f; s.dx = s.dy = s.dz = 0.f;
     s.sx = s.sy = s.sz = 0; s.cx = s.cy = s.cz = 0; s.ox = s.oy = s.oz = 0;
     if (live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs, gv.res);
+    NFA_PHASE_MARK(1);
 
     // crossings until each axis reaches its overflow index, and when the walk ends
     const int nx = s.sx ? (s.ox - s.cx) * s.sx : 1, ny = s.sy ? (s.oy - s.cy) * s.sy : 1, nz = s.sz ? (s.oz - s.cz) * s.sz : 1;
@@ -894,6 +919,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
 
     // index bookkeeping the closed forms rely on; anything odd (a final voxel "behind" the first
     // one through float error) is left to the serial walk
+    NFA_PHASE_MARK(2);
     const bool weird = live && (nx <= 0 || ny <= 0 || nz <= 0);
     // parts whose range is empty do nothing; a part with j_begin == 0 starts at the segment start
     bool part_live = live && !weird && j_begin < j_end;
@@ -929,6 +955,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
 #ifdef NFA_ABL_NOWALK
     part_live = false;
 #endif
+    NFA_PHASE_MARK(3);
     // ---- A: this part's voxels, boundaries only
     int n_ev = 0, major_done = j_begin;
     unsigned ev_occ = 0;
@@ -957,6 +984,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         } else if (major_done >= j_end) part_live = false;     // next part's seam
     }
 
+    NFA_PHASE_MARK(4);
     // ---- B: absolute lattice position (T_j, K_j = steps from the segment start) of every own
     // boundary; the lists stay in LDS
     int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
@@ -976,6 +1004,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         K_last = K;
         T_last = T;
     }
+    NFA_PHASE_MARK(5);
     // group-wide decisions (the P lanes of a ray are adjacent lanes of one wave)
     bool bad = overflow || stuck_any || weird || K_last > 0x7fffffffll;
 #ifdef NFA_FORCE_SERIAL
@@ -1046,6 +1075,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
             }
         }
     }
+    NFA_PHASE_MARK(6);
     int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
     if (!bad) {
         if (ray_ok && part == 0) {
@@ -1069,7 +1099,10 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         if (a.iv_cnts) a.iv_cnts[r] = out_iv;
         a.sm_cnts[r] = out_sm;
     }
+    NFA_PHASE_MARK(7);
     publish_block_sums(out_iv, out_sm, out_ovf, block_sums);     // this block's kBlock / P rays
+    NFA_PHASE_MARK(8);
+    NFA_PHASE_END();
 }
 
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
@@ -1507,3 +1540,26 @@ NFA_EXPORT int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *st
     hipLaunchKernelGGL(excl_sum_i64_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnts, n, starts, total);
     return check_launch("excl_sum_i64_kernel");
 }
+
+#ifdef NFA_PHASE_CYCLES
+// instrumentation builds only: sum the per-wave slots into out16 (and optionally clear them)
+extern "C" __attribute__((visibility("default"))) int nfa_debug_phase_cycles(unsigned long long *out16, int clear) {
+    static unsigned long long host[nfa::kPhaseSlots][16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(nfa::g_phase_cycles), sizeof(host)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (int w = 0; w < nfa::kPhaseSlots; ++w) {
+        if (!host[w][15]) continue;
+        for (int i = 0; i < 14; ++i) out16[i] += host[w][i];
+        out16[15] += host[w][15];
+    }
+    if (clear) {
+        if (hipMemset((void *)nullptr, 0, 0) != hipSuccess) {}
+        void *sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_cycles)) != hipSuccess) return 1;
+        if (hipMemset(sym, 0, sizeof(host)) != hipSuccess) return 1;
+    }
+    (void)t_min; (void)t_max;
+    return 0;
+}
+#endif

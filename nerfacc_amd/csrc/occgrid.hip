@@ -1,0 +1,149 @@
+// occgrid.hip — occupancy-grid maintenance for gfx950.
+//
+// The reference keeps its grid with ~25 small ATen ops per level and update
+// (OccGridEstimator._update, occ_grid.py:366-404): gather voxel coordinates, jitter, scale to
+// world space, query the field, gather / decay / maximum / scatter into `occs`, masked mean,
+// threshold.  Here everything either side of the user's occ_eval_fn is three launches:
+//   cell points   voxel ids (+ the caller's U[0,1) jitter) -> world positions      :377-384
+//   EMA-max       occs[id] = max(occs[id] * decay, occ)                              :388-390
+//   threshold     mean of the non-negative occs -> binaries = occs > min(mean, thre) :392-404
+// Random numbers stay with the caller (torch's generator, drawn in the reference's order), so
+// the result is a function of the same inputs as the reference's.  All HBM-streaming, one
+// element per lane; arithmetic order follows the torch expressions (no contraction: the
+// library is built with -ffp-contract=off).
+#include "common.hpp"
+
+namespace nfa {
+namespace {
+
+// occ_grid.py:377-384: x = (coords + rand) / resolution ; x = lo + x * (hi - lo)
+__global__ __launch_bounds__(kBlock) void grid_cell_points_kernel(
+    const int64_t *__restrict__ cell_ids, int64_t n, const float *__restrict__ jitter,
+    int rx, int ry, int rz, const float *__restrict__ aabb, float *__restrict__ points)
+{
+    const float lo[3] = {aabb[0], aabb[1], aabb[2]};
+    const float ext[3] = {aabb[3] - lo[0], aabb[4] - lo[1], aabb[5] - lo[2]};
+    const float resf[3] = {(float)rx, (float)ry, (float)rz};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t id = cell_ids ? cell_ids[i] : i;
+        const int64_t yz = (int64_t)ry * rz;
+        const int c[3] = {(int)(id / yz), (int)((id / rz) % ry), (int)(id % rz)};   // x-major voxel order (grid.cu:187-192)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float unit = ((float)c[a] + jitter[3 * i + a]) / resf[a];
+            points[3 * i + a] = lo[a] + unit * ext[a];
+        }
+    }
+}
+
+// torch.maximum semantics (NaN wins)
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+
+// EMA-max in two launches: every candidate is formed from the OLD value of its cell before any
+// cell is written (ids may repeat — uniform draws with replacement, :350-352 — and the reference's
+// gather-then-scatter never sees a half-updated grid); with repeats one of the candidates wins,
+// as with index_put_.
+__global__ __launch_bounds__(kBlock) void grid_ema_candidates_kernel(
+    const float *__restrict__ occs, const int64_t *__restrict__ cell_ids, int64_t n,
+    const float *__restrict__ occ_new, float decay, float *__restrict__ cand)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t id = cell_ids ? cell_ids[i] : i;
+        cand[i] = max_nan(occs[id] * decay, occ_new[i]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void grid_scatter_kernel(
+    float *__restrict__ occs, const int64_t *__restrict__ cell_ids, int64_t n, const float *__restrict__ cand)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        occs[cell_ids ? cell_ids[i] : i] = cand[i];
+}
+
+// sum and count of the visible cells (occs >= 0; invisible ones hold -1, :330-332); one
+// {sum, count} pair of doubles per workgroup, combined in a fixed order by the threshold kernel
+constexpr int kReduceBlocks = 512;
+__global__ __launch_bounds__(kBlock) void grid_mean_partials_kernel(const float *__restrict__ occs, int64_t n, double *__restrict__ partials)
+{
+    __shared__ double s_sum[kWavesPerBlock], s_cnt[kWavesPerBlock];
+    double sum = 0.0, cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float v = occs[i];
+        if (v >= 0.0f) { sum += (double)v; cnt += 1.0; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_down(sum, off, 64); cnt += __shfl_down(cnt, off, 64); }
+    if (lane_id() == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) { a += s_sum[w]; b += s_cnt[w]; }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+}
+// binaries = occs > min(mean, occ_thre)  (:392-404; an all-invisible grid has a NaN mean: nothing passes)
+__global__ __launch_bounds__(kBlock) void grid_threshold_kernel(
+    const float *__restrict__ occs, int64_t n, const double *__restrict__ partials, int n_partials, float occ_thre,
+    uint8_t *__restrict__ binaries, float *__restrict__ thre_out)
+{
+    __shared__ float s_thre;
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int p = 0; p < n_partials; ++p) { a += partials[2 * p]; b += partials[2 * p + 1]; }
+        const float mean = b > 0.0 ? (float)(a / b) : __builtin_nanf("");
+        s_thre = (mean != mean) ? mean : fminf(mean, occ_thre);
+        if (blockIdx.x == 0 && thre_out) *thre_out = s_thre;
+    }
+    __syncthreads();
+    const float thre = s_thre;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        binaries[i] = occs[i] > thre ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace nfa
+
+using namespace nfa;
+
+NFA_EXPORT int nfa_grid_cell_points(const int64_t *cell_ids, int64_t n, const float *jitter,
+                                    int32_t rx, int32_t ry, int32_t rz, const float *aabb,
+                                    float *points, void *stream)
+{
+    NFA_REQUIRE(n >= 0, "grid_cell_points: n < 0");
+    NFA_REQUIRE(rx > 0 && ry > 0 && rz > 0, "grid_cell_points: bad resolution %d x %d x %d", rx, ry, rz);
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(jitter && aabb && points, "grid_cell_points: NULL pointer");
+    NFA_REQUIRE(cell_ids || n <= (int64_t)rx * ry * rz, "grid_cell_points: n exceeds the cells of one level");
+    hipLaunchKernelGGL(grid_cell_points_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       cell_ids, n, jitter, rx, ry, rz, aabb, points);
+    return check_launch("grid_cell_points_kernel");
+}
+
+NFA_EXPORT int nfa_grid_ema_update(float *occs, const int64_t *cell_ids, int64_t n, const float *occ_new,
+                                   float ema_decay, float *scratch, void *stream)
+{
+    NFA_REQUIRE(n >= 0, "grid_ema_update: n < 0");
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(occs && occ_new && scratch, "grid_ema_update: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(grid_ema_candidates_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, s, occs, cell_ids, n, occ_new, ema_decay, scratch);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, s, occs, cell_ids, n, scratch);
+    return check_launch("grid_ema_update");
+}
+
+NFA_EXPORT int64_t nfa_grid_threshold_workspace_bytes(void) { return (int64_t)kReduceBlocks * 2 * sizeof(double); }
+
+NFA_EXPORT int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_thre, void *workspace,
+                                  uint8_t *binaries, float *threshold_out, void *stream)
+{
+    NFA_REQUIRE(n_cells >= 0, "grid_threshold: n_cells < 0");
+    if (n_cells == 0) return NFA_OK;
+    NFA_REQUIRE(occs && workspace && binaries, "grid_threshold: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = (int)blocks_for(n_cells);
+    if (nb > kReduceBlocks) nb = kReduceBlocks;
+    hipLaunchKernelGGL(grid_mean_partials_kernel, dim3(nb), dim3(kBlock), 0, s, occs, n_cells, (double *)workspace);
+    hipLaunchKernelGGL(grid_threshold_kernel, dim3(blocks_for(n_cells)), dim3(kBlock), 0, s, occs, n_cells,
+                       (const double *)workspace, nb, occ_thre, binaries, threshold_out);
+    return check_launch("grid_threshold");
+}

@@ -63,6 +63,10 @@ _SIGNATURES = {
     "nfa_ray_aabb_intersect": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, c_float, c_float, c_float, _P, _P, _P, _P]),
     "nfa_packed_grid_words": (c_int64, [c_int32] * 4),
     "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nfa_grid_cell_points": (ctypes.c_int, [_P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "nfa_grid_ema_update": (ctypes.c_int, [_P, _P, c_int64, _P, c_float, _P, _P]),
+    "nfa_grid_threshold_workspace_bytes": (c_int64, []),
+    "nfa_grid_threshold": (ctypes.c_int, [_P, c_int64, c_float, _P, _P, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
@@ -712,6 +716,61 @@ class _C:
             _check(load_library().nfa_accumulate_along_rays_bwd(_ptr(ray_indices), _ptr(weights), _ptr(values), _ptr(g_out),
                                                                 weights.shape[0], D, _ptr(g_w), _ptr(g_v), _stream(weights)))
         return g_w, g_v
+
+    # ---- occupancy-grid maintenance (OccGridEstimator._update, occ_grid.py:366-404) ----
+    @staticmethod
+    def grid_cell_points(cell_ids, jitter, resolution, aabb):
+        """world positions of jittered voxels: aabb.lo + ((coords(cell_ids) + jitter) / resolution) * extent.
+        cell_ids: int64 [n] level-local ids or None (cells 0..n-1); jitter: float32 [n, 3];
+        resolution: 3 host ints; aabb: float32 [6] device tensor of the level."""
+        _check_input(jitter, "jitter", torch.float32)
+        _check_input(aabb, "aabb", torch.float32)
+        n = jitter.shape[0]
+        if cell_ids is not None:
+            _check_input(cell_ids, "cell_ids", torch.int64)
+            if cell_ids.shape != (n,):
+                raise RuntimeError("cell_ids must have shape [n] matching jitter [n, 3]")
+        if jitter.shape != (n, 3) or aabb.numel() != 6:
+            raise RuntimeError("jitter must be [n, 3] and aabb must hold 6 floats")
+        rx, ry, rz = (int(r) for r in resolution)
+        points = torch.empty((n, 3), dtype=torch.float32, device=jitter.device)
+        with _Guard(jitter):
+            _check(_call("grid_cell_points", load_library().nfa_grid_cell_points,
+                         _ptr(cell_ids), n, _ptr(jitter), rx, ry, rz, _ptr(aabb), _ptr(points), _stream(jitter)))
+        return points
+
+    @staticmethod
+    def grid_ema_update(occs_level, cell_ids, occ_new, ema_decay: float):
+        """in place: occs_level[cell_ids] = maximum(occs_level[cell_ids] * ema_decay, occ_new)"""
+        _check_input(occs_level, "occs", torch.float32)
+        _check_input(occ_new, "occ_new", torch.float32)
+        n = occ_new.numel()
+        if cell_ids is not None:
+            _check_input(cell_ids, "cell_ids", torch.int64)
+            if cell_ids.numel() != n:
+                raise RuntimeError("cell_ids and occ_new must have the same number of elements")
+        elif n > occs_level.numel():
+            raise RuntimeError("occ_new has more elements than the level has cells")
+        scratch = torch.empty(n, dtype=torch.float32, device=occs_level.device)
+        with _Guard(occs_level):
+            _check(_call("grid_ema_update", load_library().nfa_grid_ema_update,
+                         _ptr(occs_level), _ptr(cell_ids), n, _ptr(occ_new), float(ema_decay), _ptr(scratch),
+                         _stream(occs_level)))
+
+    @staticmethod
+    def grid_threshold(occs, occ_thre: float):
+        """binaries (flat bool) = occs > min(mean(occs[occs >= 0]), occ_thre); also returns the
+        threshold as a 1-element device tensor (no host sync)."""
+        _check_input(occs, "occs", torch.float32)
+        L = load_library()
+        n = occs.numel()
+        ws = torch.empty(L.nfa_grid_threshold_workspace_bytes() // 8, dtype=torch.float64, device=occs.device)
+        binaries = torch.empty(n, dtype=torch.bool, device=occs.device)
+        thre = torch.empty(1, dtype=torch.float32, device=occs.device)
+        with _Guard(occs):
+            _check(_call("grid_threshold", L.nfa_grid_threshold, _ptr(occs), n, float(occ_thre), _ptr(ws),
+                         _ptr(binaries), _ptr(thre), _stream(occs)))
+        return binaries, thre
 
     @staticmethod
     def rendering_fwd(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays: int, bkgd, expected_depths: bool):

@@ -203,6 +203,23 @@ class OccGridEstimator(AbstractEstimator):
         else:
             lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
 
+        if self.occs.is_cuda:
+            # device path: three fused launches around occ_eval_fn (csrc/occgrid.hip); the random
+            # numbers are drawn here, same generator calls in the same order as the reference
+            res = tuple(self.binaries.shape[1:])
+            for lvl, indices in enumerate(lvl_indices):
+                jitter = torch.rand((indices.shape[0], 3), dtype=torch.float32, device=self.occs.device)
+                world = _C.grid_cell_points(indices.contiguous(), jitter, res, self.aabbs[lvl].contiguous())
+                occ = occ_eval_fn(world).reshape(-1).float().contiguous()
+                lo = lvl * self.cells_per_lvl
+                _C.grid_ema_update(self.occs[lo:lo + self.cells_per_lvl], indices.contiguous(), occ, ema_decay)
+            binaries, _ = _C.grid_threshold(self.occs, occ_thre)
+            self.binaries = binaries.view(self.binaries.shape)
+            from ..cuda._backend import packed_bricks
+
+            packed_bricks(self.binaries)      # the bit-packed form the traversal kernels read
+            return
+        # host tensors: the reference's own composition of torch ops (occ_grid.py:377-404)
         for lvl, indices in enumerate(lvl_indices):
             coords = self.grid_coords[indices]
             unit = (coords + torch.rand_like(coords, dtype=torch.float32)) / self.resolution

@@ -307,3 +307,44 @@ def searchsorted(key_vals, query_vals):
     lib().orc_searchsorted_batched(_c_i64(R), _c_i64(Q), _p(query_vals), _c_i64(K), _p(key_vals),
                                    _p(l), _p(r))
     return l, r
+
+
+# ---------------------------------------------------------------- occupancy-grid maintenance
+# numpy restatement of OccGridEstimator._update (nerfacc/estimators/occ_grid.py:366-404).  The
+# random numbers are inputs (the reference draws them with torch's generator); float32
+# arithmetic in the reference's operation order.
+def grid_cell_points(cell_ids, jitter, resolution, aabb):
+    """occ_grid.py:377-384: x = (grid_coords[ids] + rand) / resolution; x = lo + x * (hi - lo)."""
+    jitter, aabb = _f32(jitter), _f32(aabb)
+    rx, ry, rz = (int(r) for r in resolution)
+    ids = np.arange(jitter.shape[0], dtype=np.int64) if cell_ids is None else _i64(cell_ids)
+    coords = np.stack([ids // (ry * rz), (ids // rz) % ry, ids % rz], -1).astype(np.float32)   # x-major (grid.cu:187-192)
+    unit = (coords + jitter) / np.array([rx, ry, rz], np.float32)
+    return (aabb[:3] + unit * (aabb[3:] - aabb[:3])).astype(np.float32)
+
+
+def grid_ema_update(occs_level, cell_ids, occ_new, ema_decay=0.95):
+    """occ_grid.py:388-390: occs[ids] = maximum(occs[ids] * decay, occ); returns the new level.
+    Repeated ids: numpy (like CPU index_put_) keeps the last candidate; any candidate is a valid
+    outcome of the reference's GPU scatter — compare with `grid_ema_candidates` there."""
+    occs_level = _f32(occs_level).copy()
+    ids = np.arange(len(occ_new), dtype=np.int64) if cell_ids is None else _i64(cell_ids)
+    occs_level[ids] = np.maximum(occs_level[ids] * np.float32(ema_decay), _f32(occ_new))
+    return occs_level
+
+
+def grid_ema_candidates(occs_level, cell_ids, occ_new, ema_decay=0.95):
+    """the value each (id, occ) pair wants to write, formed from the OLD grid"""
+    ids = np.arange(len(occ_new), dtype=np.int64) if cell_ids is None else _i64(cell_ids)
+    return np.maximum(_f32(occs_level)[ids] * np.float32(ema_decay), _f32(occ_new))
+
+
+def grid_threshold(occs, occ_thre=0.01):
+    """occ_grid.py:392-404: thre = clamp(mean(occs[occs >= 0]), max=occ_thre); binaries = occs > thre.
+    The mean is accumulated in float64 (torch's float32 tree sum differs from any fixed order in
+    the last bits; cells that close to the threshold are excluded from parity checks)."""
+    occs = _f32(occs)
+    vis = occs[occs >= 0]
+    mean = np.float32(vis.astype(np.float64).mean()) if vis.size else np.float32(np.nan)
+    thre = mean if np.isnan(mean) else np.float32(min(mean, np.float32(occ_thre)))
+    return occs > thre, thre

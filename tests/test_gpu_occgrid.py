@@ -1,0 +1,138 @@
+"""Occupancy-grid maintenance kernels (csrc/occgrid.hip) vs the oracle restatement of
+OccGridEstimator._update (occ_grid.py:366-404), through the C ABI (nerfacc_amd.cuda)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_utils import n, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("res", [(16, 16, 16), (32, 8, 20)])
+def test_cell_points_bit_exact(res):
+    from nerfacc_amd import cuda as C
+
+    rng = np.random.default_rng(0)
+    cells = res[0] * res[1] * res[2]
+    aabb = np.array([-1.5, -0.5, 0.25, 1.0, 2.5, 3.0], np.float32)
+    for ids in (None, rng.integers(0, cells, 5000), np.arange(cells)[::-1].copy()):
+        m = cells if ids is None else len(ids)
+        jit = rng.random((m, 3), dtype=np.float32)
+        want = oracle.grid_cell_points(ids, jit, res, aabb)
+        got = C.grid_cell_points(None if ids is None else t(ids.astype(np.int64)), t(jit), res, t(aabb))
+        assert np.array_equal(n(got), want)          # float32, same operation order: bit-exact
+    with pytest.raises(RuntimeError):
+        C.grid_cell_points(None, torch.rand(4, 3), res, t(aabb))          # host tensor: no CPU path
+
+
+def test_ema_update_and_repeated_ids():
+    from nerfacc_amd import cuda as C
+
+    rng = np.random.default_rng(1)
+    cells = 4096
+    occs = rng.random(cells, dtype=np.float32)
+    occs[rng.integers(0, cells, 300)] = -1.0                       # invisible cells keep -1 * decay vs occ
+    # (a) a permutation: no repeats, bit-exact
+    ids = rng.permutation(cells)[:3000].astype(np.int64)
+    occ_new = (rng.random(3000, dtype=np.float32) * 1.2).astype(np.float32)
+    want = oracle.grid_ema_update(occs, ids, occ_new, 0.95)
+    g = t(occs.copy())
+    C.grid_ema_update(g, t(ids), t(occ_new), 0.95)
+    assert np.array_equal(n(g), want)
+    # (b) all cells (ids = None)
+    occ_all = rng.random(cells, dtype=np.float32)
+    g = t(occs.copy())
+    C.grid_ema_update(g, None, t(occ_all), 0.5)
+    assert np.array_equal(n(g), oracle.grid_ema_update(occs, None, occ_all, 0.5))
+    # (c) repeats (uniform draws with replacement, occ_grid.py:350-352): every written cell holds one
+    # of the candidates formed from the OLD grid; cells not named are untouched
+    ids = rng.integers(0, 512, 6000).astype(np.int64)
+    occ_new = rng.random(6000, dtype=np.float32)
+    cand = oracle.grid_ema_candidates(occs, ids, occ_new, 0.95)
+    g = t(occs.copy())
+    C.grid_ema_update(g, t(ids), t(occ_new), 0.95)
+    got = n(g)
+    assert np.array_equal(got[512:], occs[512:])
+    for c in range(512):
+        sel = ids == c
+        if sel.any():
+            assert got[c] in cand[sel]
+        else:
+            assert got[c] == occs[c]
+
+
+def test_threshold_matches_reference_rule():
+    from nerfacc_amd import cuda as C
+
+    rng = np.random.default_rng(2)
+    occs = (rng.random(2 * 32**3, dtype=np.float32) ** 4 * 0.05).astype(np.float32)
+    occs[rng.integers(0, len(occs), 5000)] = -1.0
+    for occ_thre in (0.01, 1e-4, 10.0):
+        want_bin, want_thre = oracle.grid_threshold(occs, occ_thre)
+        got_bin, got_thre = C.grid_threshold(t(occs), occ_thre)
+        assert got_bin.dtype == torch.bool
+        thre = float(got_thre.item())
+        assert abs(thre - float(want_thre)) <= 1e-6 * abs(float(want_thre))
+        near = np.abs(occs - want_thre) <= 1e-6 * abs(float(want_thre))      # cells within rounding of the threshold
+        assert np.array_equal(n(got_bin)[~near], want_bin[~near])
+        # and the torch composition the reference runs on the device
+        o = t(occs)
+        ref = o > torch.clamp(o[o >= 0].mean(), max=occ_thre)
+        assert (ref.cpu().numpy()[~near] == n(got_bin)[~near]).all()
+    allneg = np.full(1000, -1.0, np.float32)                        # nothing visible: NaN mean, nothing passes
+    b, th = C.grid_threshold(t(allneg), 0.01)
+    assert not b.any() and torch.isnan(th).all()
+
+
+def test_update_end_to_end_vs_oracle():
+    """OccGridEstimator._update on the device == the oracle replay fed with the same draws of the
+    device generator (same calls, same order: occ_grid.py:345-404)."""
+    from nerfacc_amd import OccGridEstimator
+
+    res, levels = 16, 2
+    cells = res**3
+    est = OccGridEstimator(roi_aabb=[-1.0, -1, -1, 1, 1, 1], resolution=res, levels=levels).to(DEV)
+    occ_fn = lambda x: torch.exp(-2.0 * (x**2).sum(-1, keepdim=True)) * 0.05
+    occs = np.zeros(levels * cells, np.float32)
+    binaries = np.zeros(levels * cells, bool)
+    aabbs = n(est.aabbs)
+    for step in (0, 16, 256, 272):
+        torch.manual_seed(100 + step)
+        est._update(step=step, occ_eval_fn=occ_fn, occ_thre=0.01)
+        torch.manual_seed(100 + step)
+        lvl_ids = []
+        if step < 256:
+            lvl_ids = [np.nonzero(occs[l * cells:(l + 1) * cells] >= 0)[0] for l in range(levels)]
+        else:
+            q = cells // 4
+            for l in range(levels):
+                uni = n(torch.randint(cells, (q,), device=DEV))
+                uni = uni[occs[l * cells + uni] >= 0]
+                occd = np.nonzero(binaries[l * cells:(l + 1) * cells])[0]
+                if q < len(occd):
+                    occd = occd[n(torch.randint(len(occd), (q,), device=DEV))]
+                lvl_ids.append(np.concatenate([uni, occd]))
+        for l, ids in enumerate(lvl_ids):
+            jitter = n(torch.rand((len(ids), 3), device=DEV))
+            pts = oracle.grid_cell_points(ids, jitter, (res, res, res), aabbs[l])
+            occ = n(occ_fn(t(pts)).squeeze(-1))                      # the user's field stays a torch function
+            lvl = occs[l * cells:(l + 1) * cells]
+            new = oracle.grid_ema_update(lvl, ids, occ, 0.95)
+            # repeated ids: accept whichever candidate the device kept
+            got = n(est.occs[l * cells:(l + 1) * cells])
+            uniq, cnt = np.unique(ids, return_counts=True)
+            rep = np.zeros(cells, bool)
+            rep[uniq[cnt > 1]] = True
+            assert np.array_equal(got[~rep], new[~rep])
+            cand = oracle.grid_ema_candidates(lvl, ids, occ, 0.95)
+            for c in uniq[cnt > 1]:
+                assert got[c] in cand[ids == c]
+            occs[l * cells:(l + 1) * cells] = got
+        binaries, thre = oracle.grid_threshold(occs, 0.01)
+        near = np.abs(occs - thre) <= 1e-6 * abs(float(thre))
+        assert np.array_equal(n(est.binaries).ravel()[~near], binaries[~near])
+        binaries = n(est.binaries).ravel().copy()
+    assert 0 < binaries.sum() < binaries.size

@@ -250,3 +250,43 @@ def test_sampling_min_max_distances():
     ri, ts, te, _ = oracle.sampling(o, d, binaries, aabbs, 0.15, 0.85, tmin, tmax, 0.01)
     assert ri.size > 0
     assert (ts >= tmin[ri] - 0.005).all() and (te <= tmax[ri] + 0.005).all()
+
+
+def test_grid_maintenance_replays_reference_update(golden):
+    """oracle.grid_* driven with the reference's RNG calls (torch CPU generator, seed 123, the
+    call order of occ_grid.py:345-404) must reproduce the reference's `_update` evolution that
+    tests/golden/make_golden.py recorded from nerfacc itself."""
+    import torch
+
+    torch.manual_seed(123)
+    res, levels = 16, 2
+    cells = res**3
+    base = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    ctr, half = (base[:3] + base[3:]) / 2, (base[3:] - base[:3]) / 2
+    aabbs = np.stack([np.concatenate([ctr - half * 2**i, ctr + half * 2**i]) for i in range(levels)]).astype(np.float32)
+    occs = np.zeros(levels * cells, np.float32)
+    binaries = np.zeros(levels * cells, bool)
+    occ_fn = lambda x: (np.exp(np.float32(-2.0) * (x.astype(np.float32) ** 2).sum(-1, dtype=np.float32)) * np.float32(0.05)).astype(np.float32)
+    for step in (0, 16, 256, 272):
+        lvl_ids = []
+        if step < 256:                                                    # occ_grid.py:372-374 via _get_all_cells
+            for lvl in range(levels):
+                lvl_ids.append(np.nonzero(occs[lvl * cells:(lvl + 1) * cells] >= 0)[0])
+        else:                                                             # :345-364
+            n = cells // 4
+            for lvl in range(levels):
+                uni = torch.randint(cells, (n,)).numpy()
+                uni = uni[occs[lvl * cells + uni] >= 0]
+                occd = np.nonzero(binaries[lvl * cells:(lvl + 1) * cells])[0]
+                if n < len(occd):
+                    occd = occd[torch.randint(len(occd), (n,)).numpy()]
+                lvl_ids.append(np.concatenate([uni, occd]))
+        for lvl, ids in enumerate(lvl_ids):
+            jitter = torch.rand((len(ids), 3)).numpy()
+            pts = oracle.grid_cell_points(ids, jitter, (res, res, res), aabbs[lvl])
+            # the reference evaluates occ_fn in torch; exp may differ from numpy's in the last bit
+            occ = (torch.exp(-2.0 * (torch.from_numpy(pts) ** 2).sum(-1)) * 0.05).numpy()
+            occs[lvl * cells:(lvl + 1) * cells] = oracle.grid_ema_update(occs[lvl * cells:(lvl + 1) * cells], ids, occ, 0.95)
+        binaries, _ = oracle.grid_threshold(occs, 0.01)
+    np.testing.assert_array_equal(occs, golden["upd_occs"])
+    assert np.array_equal(np.packbits(binaries), golden["upd_bin"])

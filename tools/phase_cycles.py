@@ -1,0 +1,60 @@
+"""Where do the cycles of traverse_count_split_kernel go?  Builds an instrumented copy of the
+library (-DNFA_PHASE_CYCLES: shader-clock stamps between the phases of the kernel, summed over
+waves), runs the count pass on bench.py's ray batch and prints average cycles per wave and phase.
+
+    python tools/phase_cycles.py [n_rays] [iters]        (NFA_SPLIT_P=<P> selects lanes per ray)
+"""
+import ctypes, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out_dir = os.path.join(ROOT, "tools", "_prof")
+os.makedirs(out_dir, exist_ok=True)
+so = os.path.join(out_dir, "libnerfacc_hip_prof.so")
+srcs = sorted(glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hip")))
+if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                           "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", "-shared", *srcs, "-o", so])
+if "--build-only" in sys.argv:
+    sys.exit(0)
+import torch
+from nerfacc_amd.cuda import _backend
+_backend.LIB_PATH = so
+import bench
+import nerfacc_amd as nerfacc
+from nerfacc_amd import cuda as C
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 13120
+iters = int(args[1]) if len(args) > 1 else 20
+dev = torch.device("cuda:0")
+torch.manual_seed(42)
+field = bench.DenseGridField(bench.AABB, 128).to(dev)
+est = nerfacc.OccGridEstimator(roi_aabb=bench.AABB, resolution=128, levels=1).to(dev)
+est.train()
+for _ in range(4):
+    est._update(step=0, occ_eval_fn=lambda x: field.query_density(x) * bench.RENDER_STEP, occ_thre=1e-2)
+pool_o, pool_d = bench.make_ray_pool(n, 42, dev)
+near = torch.rand(n, device=dev) * bench.RENDER_STEP
+far = torch.full((n,), 1e10, device=dev)
+lib = _backend.load_library()
+lib.nfa_debug_phase_cycles.restype = ctypes.c_int
+buf = (ctypes.c_ulonglong * 16)()
+def run():
+    return C.sample_occgrid(pool_o, pool_d, est.binaries, est.aabbs, near, far, bench.RENDER_STEP, 0.0)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+lib.nfa_debug_phase_cycles(buf, 1)
+for _ in range(iters):
+    run()
+torch.cuda.synchronize()
+lib.nfa_debug_phase_cycles(buf, 0)
+waves = buf[15]
+names = ["stage occupancy into LDS (+barrier)", "ray loads, slab test, lattice to segment start, DDA setup",
+         "end-of-walk times (3 closed forms), major axis", "seam restart (closed-form DDA state at the part start)",
+         "A: voxel walk of the part", "B: lattice position of own boundaries", "stitch across the P lanes + run records",
+         "per-ray outputs (+ serial fallback)", "block sums"]
+tot = sum(buf[i] for i in range(9))
+print(f"rays {n}  P={os.environ.get('NFA_SPLIT_P', 'auto')}  waves/launch {waves / iters:.0f}  cycles/wave {tot / max(waves, 1):.0f}")
+for i, nm in enumerate(names):
+    print(f"  {buf[i] / max(waves, 1):9.0f} cyc  {100.0 * buf[i] / max(tot, 1):5.1f} %  {nm}")
