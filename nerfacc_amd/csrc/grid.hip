@@ -1517,8 +1517,9 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_fill: t_starts without t_ends");
     hipStream_t s = (hipStream_t)stream;
     if (!workspace) return launch_fill(a, skip_empty, rewrite_counts, nullptr, s);
-    // runs recorded by nfa_traverse_count with the same args (two-pass mode only)
-    NFA_REQUIRE(!rewrite_counts && a->rays_mask == nullptr, "traverse_fill: replay is for the two-pass mode");
+    // runs recorded by nfa_traverse_count with the same args (two-pass mode only; skipped rays
+    // of a rays_mask recorded no runs)
+    NFA_REQUIRE(!rewrite_counts, "traverse_fill: replay is for the two-pass mode");
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {

@@ -594,10 +594,16 @@ class _C:
     # (no counterpart in the reference's extension: there these are chains of ATen ops)
     @staticmethod
     def sample_occgrid(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float,
-                       cone_angle: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                       cone_angle: float, rays_mask=None, traverse_steps_limit: int = -1,
+                       with_terminate_planes: bool = False):
         """traverse_grids + the two is_left/is_right compactions of occ_grid.py:164-177 in
         one count pass and one fill pass: returns (ray_indices, t_starts, t_ends, packed_info).
-        Ray/AABB tests and the per-ray event sort run inside the kernel."""
+        Ray/AABB tests and the per-ray event sort run inside the kernel.
+
+        rays_mask (bool [R], rays with False are skipped) and traverse_steps_limit (at most that
+        many samples per ray) give one round of the test-time marcher (examples/utils.py:349-372)
+        with exactly sized, already compacted outputs instead of over-allocation + masks;
+        with_terminate_planes appends where each ray stopped (its near plane if it was skipped)."""
         L = load_library()
         _check_input(rays_o, "rays_o", torch.float32)
         dev = rays_o.device
@@ -605,20 +611,27 @@ class _C:
         i64 = dict(dtype=torch.int64, device=dev)
         with _Guard(rays_o):
             stream = _stream(rays_o)
-            a = _traverse_args(rays_o, rays_d, None, binaries, aabbs, None, None, None, near_planes, far_planes,
-                               step_size, cone_angle, -1)
+            a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, None, None, None, near_planes, far_planes,
+                               step_size, cone_angle, traverse_steps_limit)
             packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
             totals = _host_ints(dev)
             ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
             a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
+            term = None
+            if with_terminate_planes:
+                term = near_planes.clone()
+                a.terminate_planes = _ptr(term)
             _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
             _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
             _, n, n_overflow, _ = _read_ints(totals, dev)
             ray_indices = torch.empty(n, **i64)
             ts = torch.empty((2, n), dtype=torch.float32, device=dev)
             a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
+            a.terminate_planes = None                    # written by the count pass only
             if n > 0:
                 _check(_call("traverse_fill", L.nfa_traverse_fill, ctypes.byref(a), 1, 0, _ptr(ws), n, n_overflow, stream))
+        if with_terminate_planes:
+            return ray_indices, ts[0], ts[1], packed.t(), term
         return ray_indices, ts[0], ts[1], packed.t()
 
     @staticmethod

@@ -84,3 +84,44 @@ def test_iterative_test_mode_matches_training_path():
     assert torch.allclose(opa_t, opa, atol=2e-3)
     hit = opa[:, 0] > 0.5
     assert torch.allclose(dep_t[hit], dep[hit], atol=2e-2)
+
+
+def test_fused_rounds_match_reference_api_marcher():
+    """examples/utils.py: the fused per-round call (exactly sized, compacted samples) must march
+    the same samples as the over-allocated traverse_grids + mask gathers of the reference loop."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import nerfacc_amd as nerfacc
+    import utils as U
+    from nerfacc_amd import cuda as C
+    from nerfacc_amd.grid import traverse_grids
+
+    o, d, aabb, occ = lego_like(11, 4000, res=64)
+    est = nerfacc.OccGridEstimator(roi_aabb=t(aabb[0]), resolution=64, levels=1).to(DEV)
+    est.binaries = t(occ)
+    O, D = t(o), t(d)
+
+    class Field(torch.nn.Module):
+        def forward(self, pos, dirs=None):
+            rgb, sigma = _field(pos)
+            return rgb, sigma[:, None]
+
+    # one round, sample by sample: mask + per-ray limit
+    mask = torch.rand(4000, device=DEV) < 0.6
+    near = torch.rand(4000, device=DEV) * 0.3
+    far = torch.full((4000,), 1e10, device=DEV)
+    iv, sm, term = traverse_grids(O, D, est.binaries, est.aabbs, near, far, 1e-2, 0.0, 7, True, mask)
+    ri, ts, te, pk, term_f = C.sample_occgrid(O, D, est.binaries, est.aabbs, near, far, 1e-2, 0.0, rays_mask=mask,
+                                              traverse_steps_limit=7, with_terminate_planes=True)
+    assert torch.equal(ri, sm.ray_indices[sm.is_valid])
+    assert torch.equal(ts, iv.vals[iv.is_left]) and torch.equal(te, iv.vals[iv.is_right])
+    assert torch.equal(pk[:, 1], sm.packed_info[:, 1]) and int(pk[:, 1].max()) == 7
+    assert torch.equal(term_f[mask], term[mask]) and torch.equal(term_f[~mask], near[~mask])
+    assert (pk[~mask, 1] == 0).all()
+
+    bk = torch.ones(3, device=DEV)
+    a = U.render_image_with_occgrid_test(1024, Field(), est, U.Rays(O, D), render_step_size=1e-2, render_bkgd=bk)
+    b = U.render_image_with_occgrid_test_fused(1024, Field(), est, U.Rays(O, D), render_step_size=1e-2, render_bkgd=bk)
+    assert a[3] == b[3] and a[3] > 0                                   # same number of marched samples
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.allclose(x, y, atol=1e-5)                         # float atomics order only
