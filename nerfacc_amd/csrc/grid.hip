@@ -442,45 +442,48 @@ __device__ __forceinline__ bool segment_of(const Ev &ev, int i, int G, float nea
 
 // ---- run-length records (pass 1 -> pass 2) -------------------------------------------------
 // All samples of a ray sit on its marching lattice, so a maximal run of consecutive samples is
-// described by the lattice point it starts at (the exact float) and its length.  kMaxRuns runs
-// per ray, laid out [run][ray] so a wave's lanes touch consecutive words; a ray with more runs
-// (or step_size <= 0, where edges come from voxel faces) is flagged and re-traversed in pass 2.
-constexpr int kMaxRuns = 14;
-constexpr int kRunsOverflow = 255;
+// described by the lattice point it starts at (the exact float) and the index of its first
+// sample within the ray.  Up to max_runs runs per ray, laid out [run][ray] so a wave's lanes touch
+// consecutive words; a ray with more runs (or step_size <= 0, where edges come from voxel faces)
+// is flagged and re-traversed in pass 2.  max_runs is sized from the ray count (run_capacity):
+// blob-like grids need a handful, a noise grid (tests/test_grid.py: rand > 0.5) a run per ~2 voxels.
+constexpr int kMinRuns = 14, kMaxRunsCap = 512;
+constexpr int kRunsOverflow = 0xffff;
+constexpr int64_t kRunBudgetBytes = 256ll << 20;
+
+inline int run_capacity(int64_t n_rays) {
+    const int64_t fit = kRunBudgetBytes / (8 * (n_rays > 0 ? n_rays : 1));
+    return (int)(fit < kMinRuns ? kMinRuns : (fit > kMaxRunsCap ? kMaxRunsCap : fit));
+}
 
 struct RunStore {
-    float *t0;        // [kMaxRuns][R]
-    int32_t *len;     // [kMaxRuns][R]
-    uint8_t *n_runs;  // [R]
+    float *t0;         // [max_runs][R] lattice point the run starts at
+    int32_t *first;    // [max_runs][R] index of the run's first sample within its ray
+    uint16_t *n_runs;  // [R]
+    int max_runs;
 };
 
 struct CountSink {
     RunStore rs;
     int64_t r, R;
     int64_t n_iv = 0, n_sm = 0;
-    int n_runs = 0, cur_len = 0;
+    int n_runs = 0;
     // k consecutive samples starting at lattice point t0
     __device__ __forceinline__ void run(float t0, int64_t k, bool continuous) {
         if (k <= 0) return;
+        if (rs.t0 && !continuous) {
+            if (n_runs < rs.max_runs) { rs.t0[(int64_t)n_runs * R + r] = t0; rs.first[(int64_t)n_runs * R + r] = (int32_t)n_sm; }
+            n_runs += 1;
+        }
         n_iv += continuous ? k : k + 1;
         n_sm += k;
-        if (!rs.t0) return;
-        if (continuous) { cur_len += (int)k; return; }
-        close_run();
-        if (n_runs < kMaxRuns) rs.t0[(int64_t)n_runs * R + r] = t0;
-        n_runs += 1;
-        cur_len = (int)k;
     }
     __device__ __forceinline__ void sample(float t0, float, bool continuous) { run(t0, 1, continuous); }
-    __device__ __forceinline__ void close_run() {
-        if (n_runs >= 1 && n_runs <= kMaxRuns) rs.len[(int64_t)(n_runs - 1) * R + r] = cur_len;
-    }
     // returns true when the ray needs the re-traversal fallback
     __device__ __forceinline__ bool finish(bool replayable) {
         if (!rs.t0) return false;
-        close_run();
-        const bool overflow = (n_sm > 0) && (n_runs > kMaxRuns || !replayable);
-        rs.n_runs[r] = (uint8_t)(overflow ? kRunsOverflow : n_runs);
+        const bool overflow = (n_sm > 0) && (n_runs > rs.max_runs || !replayable || n_sm > 0x7fffffffll);
+        rs.n_runs[r] = (uint16_t)(overflow ? kRunsOverflow : n_runs);
         return overflow;
     }
 };
@@ -1040,14 +1043,15 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
             K_prev = K;
         }
     }
-    // exclusive prefix of fresh runs over the ray's parts, and ray totals
+    // exclusive prefixes of fresh runs and samples over the ray's parts, and ray totals
     int fresh_before = 0, fresh_total = n_fresh;
-    int64_t sm_total = n_sm;
+    int64_t sm_before = 0, sm_total = n_sm;
     int last_part_with_ev = n_ev > 0 ? part : -1;
 #pragma unroll
     for (int q = 1; q < P; ++q) {
         const int f = __shfl_up(n_fresh, q, 64);
-        if (part >= q) fresh_before += f;
+        const int64_t m = __shfl_up(n_sm, q, 64);
+        if (part >= q) { fresh_before += f; sm_before += m; }
     }
 #pragma unroll
     for (int off = 1; off < P; off <<= 1) {
@@ -1060,14 +1064,15 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     if (!bad) {
         // run records of this part
         if (rs.t0 && n_fresh > 0) {
-            int64_t K_prev = K_before;
+            int64_t K_prev = K_before, first = sm_before;
             float T_prev = T_before;
             int idx = fresh_before;
             for (int j = 0; j < n_ev; ++j) {
                 const int64_t K = ev_K[j * kBlock + tid];
                 const float T = ev_lds[j * kBlock + tid];
                 if (((ev_occ >> j) & 1u) && K > K_prev) {
-                    if (idx < kMaxRuns) { rs.t0[(int64_t)idx * R + r] = T_prev; rs.len[(int64_t)idx * R + r] = (int32_t)(K - K_prev); }
+                    if (idx < rs.max_runs) { rs.t0[(int64_t)idx * R + r] = T_prev; rs.first[(int64_t)idx * R + r] = (int32_t)first; }
+                    first += K - K_prev;
                     ++idx;
                 }
                 K_prev = K;
@@ -1079,8 +1084,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
     if (!bad) {
         if (ray_ok && part == 0) {
-            const bool ovf = fresh_total > kMaxRuns;
-            if (rs.n_runs) rs.n_runs[r] = (uint8_t)(ovf ? kRunsOverflow : fresh_total);
+            const bool ovf = fresh_total > rs.max_runs;
+            if (rs.n_runs) rs.n_runs[r] = (uint16_t)(ovf ? kRunsOverflow : fresh_total);
             out_iv = sm_total + fresh_total;
             out_sm = sm_total;
             out_ovf = ovf ? 1 : 0;
@@ -1180,7 +1185,7 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
 template <int EV, bool LDS_OCC>
 __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args a, GridView gv,
                                                                int skip_empty, int rewrite_counts,
-                                                               const uint8_t *__restrict__ only_overflow)
+                                                               const uint16_t *__restrict__ only_overflow)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
@@ -1203,7 +1208,7 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
 }
 
 // pass 2, fast form: ONE LANE PER OUTPUT SAMPLE.  sample s -> ray (binary search in the
-// exclusive offsets) -> run (<= kMaxRuns lengths) -> lattice point (closed form) -> coalesced
+// exclusive offsets) -> run (binary search in the runs' first-sample indices) -> lattice point (closed form) -> coalesced
 // stores of ray_indices / t_starts / t_ends (+ interval edges when asked for).
 __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t n_samples)
 {
@@ -1216,8 +1221,10 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args
         const int n_runs = rs.n_runs[r];
         if (n_runs == kRunsOverflow) continue;        // written by the fallback launch
         int64_t j = s - a.sm_starts[r];
-        int q = 0, len = rs.len[r];
-        while (j >= len) { j -= len; ++q; len = rs.len[(int64_t)q * R + r]; }
+        int qlo = 1, qhi = n_runs;                    // last run whose first sample is <= j (run 0 starts at 0)
+        while (qlo < qhi) { const int m = qlo + ((qhi - qlo) >> 1); if ((int64_t)rs.first[(int64_t)m * R + r] <= j) qlo = m + 1; else qhi = m; }
+        const int q = qlo - 1;
+        if (q > 0) j -= rs.first[(int64_t)q * R + r];
         float t0 = rs.t0[(int64_t)q * R + r];
         if (cone == 0.0f) t0 = nfa_lattice_advance(t0, march_dt(t0, cone, step_size), j, nullptr);
         else for (int64_t k = 0; k < j; ++k) t0 = t0 + march_dt(t0, cone, step_size);
@@ -1320,15 +1327,16 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     return gv;
 }
 
-// workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: kMaxRuns*R f32 ][ run len: kMaxRuns*R i32 ][ n_runs: R u8 ]
+// workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: max_runs*R f32 ][ run first: max_runs*R i32 ][ n_runs: R u16 ]
 // one triple per 16 rays is the finest granularity any count kernel publishes
 inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * ceil_div(n_rays > 0 ? n_rays : 1, 16); }
 RunStore make_runs(void *workspace, int64_t n_rays) {
     RunStore rs;
     uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
+    rs.max_runs = run_capacity(n_rays);
     rs.t0 = (float *)p;
-    rs.len = (int32_t *)(p + (int64_t)kMaxRuns * n_rays * 4);
-    rs.n_runs = p + (int64_t)kMaxRuns * n_rays * 8;
+    rs.first = (int32_t *)(p + (int64_t)rs.max_runs * n_rays * 4);
+    rs.n_runs = (uint16_t *)(p + (int64_t)rs.max_runs * n_rays * 8);
     return rs;
 }
 
@@ -1396,7 +1404,7 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
 
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     const int64_t R = n_rays > 0 ? n_rays : 1;
-    return ws_block_sums_bytes(R) + (int64_t)kMaxRuns * R * 8 + ceil_div(R, 16) * 16;
+    return ws_block_sums_bytes(R) + (int64_t)run_capacity(R) * R * 8 + ceil_div(2 * R, 16) * 16;
 }
 
 // lanes per ray of the count pass for this call (1 = lane-per-ray kernels)
@@ -1487,7 +1495,7 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     return check_launch("traverse_offsets_kernel");
 }
 
-static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint8_t *only_overflow, hipStream_t s)
+static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint16_t *only_overflow, hipStream_t s)
 {
     int lds = 0;
     const GridView gv = make_view(a, 0, &lds);       // no boundary lists in the general walk
