@@ -288,8 +288,8 @@ struct GridView {
     int nbx, nby, nbz;
     int bricks_per_grid;
     int n_words;
-    int lds_words;        // coarse/prefix words staged in LDS (0 = the sparse form stays global)
-    int lds_compact_cap;  // compact bricks staged in LDS
+    int lds_words;        // bitmap (and rank) words staged in LDS (0 = nothing staged)
+    int lds_compact_cap;  // compact bricks staged in LDS (0 with lds_words > 0: bitmap only, bricks from L2)
 };
 
 struct BrickCache {
@@ -297,13 +297,21 @@ struct BrickCache {
     uint64_t bits;
 };
 
-// The sparse occupancy is read either from its LDS image (LDS_OCC, arrays addressed off the
-// dynamic-LDS base so the compiler emits ds_read, not flat loads) or from global memory.
-// LDS image layout: coarse[W4] u32 | prefix[W4] u32 | compact[cap] u64, W4 = lds_words rounded to 4.
+// Where a voxel's occupancy comes from, per kernel variant:
+//   LDS_OCC  the whole sparse form sits in LDS — bitmap of non-empty bricks, its rank prefix and the
+//            compacted non-empty bricks (arrays addressed off the dynamic-LDS base so the compiler
+//            emits ds_read, not flat loads).  Chosen when the non-empty bricks fit (make_view).
+//   else     the dense brick array in global memory (L2-resident: 8 B per 64 voxels), ONE load per
+//            brick the walk enters — a dependent bitmap -> rank -> brick chain through L2 costs
+//            three latencies per brick.  When the bitmap alone fits in LDS it is staged and
+//            answers the empty bricks without touching memory.
+// LDS image layout: coarse[W4] u32 | prefix[W4] u32 | compact[cap] u64, W4 = lds_words rounded to 4
+// (bitmap-only: just coarse[W4]).
 template <bool LDS_OCC>
 struct Occ {
     const char *smem;
     int w4, cap;
+    int bytes;      // LDS bytes of the image; the per-lane boundary lists start behind it (16-aligned)
 };
 
 template <bool LDS_OCC>
@@ -312,8 +320,9 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
     l.smem = smem;
     l.w4 = (g.lds_words + 3) & ~3;
     l.cap = 0;
+    l.bytes = 0;
+    uint32_t *lc = (uint32_t *)smem;
     if (LDS_OCC) {
-        uint32_t *lc = (uint32_t *)smem;
         uint32_t *lp = lc + l.w4;
         uint64_t *lb = (uint64_t *)(lp + l.w4);
         for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) { lc[i] = g.coarse[i]; lp[i] = g.prefix[i]; }
@@ -321,6 +330,11 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
         if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
         for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
         l.cap = n_compact;
+        l.bytes = (2 * l.w4 * 4 + g.lds_compact_cap * 8 + 15) & ~15;
+        __syncthreads();
+    } else if (g.lds_words > 0) {
+        for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) lc[i] = g.coarse[i];
+        l.bytes = (l.w4 * 4 + 15) & ~15;
         __syncthreads();
     }
     return l;
@@ -335,8 +349,8 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
         c.id = id;
         const uint32_t bit = 1u << (id & 31);
         uint64_t bits = 0;
+        const uint32_t *lc = (const uint32_t *)l.smem;
         if (LDS_OCC) {
-            const uint32_t *lc = (const uint32_t *)l.smem;
             const uint32_t w = lc[id >> 5];
             if (w & bit) {
                 const int k = (int)lc[l.w4 + (id >> 5)] + __popc(w & (bit - 1u));
@@ -345,9 +359,10 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
                 // select is compiled into one flat load, which is what this code avoids
                 bits = ((const uint64_t *)(lc + 2 * l.w4))[k];
             }
+        } else if (l.bytes > 0) {                     // bitmap in LDS, bricks dense in L2 (wave-uniform branch)
+            if (lc[id >> 5] & bit) bits = g.bricks[id];
         } else {
-            const uint32_t w = g.coarse[id >> 5];
-            if (w & bit) bits = g.compact[(int)g.prefix[id >> 5] + __popc(w & (bit - 1u))];
+            bits = g.bricks[id];
         }
         c.bits = bits;
     }
@@ -717,8 +732,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
     float t_term = 0.f;
     if (LATTICE) {
         // the boundary lists sit behind the occupancy image in LDS
-        const int occ_bytes = LDS_OCC ? (2 * occ.w4 * 4 + gv.lds_compact_cap * 8) : 0;
-        float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));
+        float *ev_lds = (float *)(smem + occ.bytes);
         traverse_ray_lattice<EV, LDS_OCC>(a, gv, occ, ev_lds, r, active, sink, t_term);
     } else if (active) {
         traverse_ray_general<CountSink, EV, LDS_OCC>(a, gv, occ, r, sink, t_term);
@@ -858,8 +872,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     NFA_PHASE_BEGIN();
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
     NFA_PHASE_MARK(0);
-    const int occ_bytes = LDS_OCC ? (2 * occ.w4 * 4 + gv.lds_compact_cap * 8) : 0;
-    float *ev_lds = (float *)(smem + ((occ_bytes + 15) & ~15));        // [CAP][kBlock] times, then [CAP][kBlock] indices
+    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][kBlock] times, then [CAP][kBlock] indices
     const int tid = threadIdx.x, part = tid % P;
     const int64_t R = a.n_rays;
     const int64_t r = (int64_t)blockIdx.x * (kBlock / P) + tid / P;
@@ -1311,15 +1324,22 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     gv.nbz = (a->res[2] + 3) / 4;
     gv.bricks_per_grid = gv.nbx * gv.nby * gv.nbz;
     gv.n_words = (int)L.n_words;
-    const int64_t words_bytes = 2 * (((int64_t)L.n_words + 3) & ~3ll) * 4;
+    const int64_t w4 = ((int64_t)L.n_words + 3) & ~3ll;
+    const int64_t words_bytes = 2 * w4 * 4;
     const int64_t room = (int64_t)kLdsBudget - ev_bytes - 16 - words_bytes;
-    // LDS variant only when the caller told us how many bricks are non-empty and they all fit
+    // full LDS image only when the caller told us how many bricks are non-empty and they all fit
     const int64_t need = a->n_nonempty_bricks >= 0 ? (a->n_nonempty_bricks > 0 ? a->n_nonempty_bricks : 1) : -1;
     if (need > 0 && room >= need * 8) {
         gv.lds_words = (int)L.n_words;
         gv.lds_compact_cap = (int)need;
         *lds_bytes = (int)(((words_bytes + need * 8 + 15) & ~15ll) + ev_bytes);
-    } else {                                      // unknown count or too large for LDS: read from L2
+    } else if (w4 * 4 <= 16 * 1024 && (int64_t)kLdsBudget - ev_bytes - 16 >= w4 * 4) {
+        // bricks from L2; a small bitmap of non-empty bricks (<= 16 KiB: up to 128 K bricks) is
+        // still staged and answers the empty bricks
+        gv.lds_words = (int)L.n_words;
+        gv.lds_compact_cap = 0;
+        *lds_bytes = (int)(((w4 * 4 + 15) & ~15ll) + ev_bytes);
+    } else {                                      // everything from L2
         gv.lds_words = 0;
         gv.lds_compact_cap = 0;
         *lds_bytes = ev_bytes;
@@ -1407,16 +1427,20 @@ NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     return ws_block_sums_bytes(R) + (int64_t)run_capacity(R) * R * 8 + ceil_div(2 * R, 16) * 16;
 }
 
-// lanes per ray of the count pass for this call (1 = lane-per-ray kernels)
-static int count_lanes_per_ray(const nfa_traverse_args *a) {
+// lanes per ray of the count pass for this call (1 = lane-per-ray kernels).  `sparse`: the full
+// occupancy image fits in LDS (few non-empty bricks: a blob-like grid, few occupied<->empty
+// boundaries per ray).
+static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     const bool split = lattice && !a->t_sorted && a->n_grids == 1 && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
     int P = 1;
     if (split) {
         // measured on MI355X (profiles/r01_split_sweep.md): splitting pays while the ray batch is
         // too small to fill the chip with one lane per ray; beyond ~40 k rays the lane-per-ray
-        // walk does the same job in fewer instructions.
-        if (a->n_rays <= 16384) P = 8;
+        // walk does the same job in fewer instructions.  Dense / noisy grids have a boundary every
+        // few voxels, so their parts are kept shorter (more lanes per ray).
+        if (a->n_rays <= 8192) P = sparse ? 8 : 16;
+        else if (a->n_rays <= 16384) P = 8;
         else if (a->n_rays <= 36864) P = 4;
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
@@ -1424,6 +1448,26 @@ static int count_lanes_per_ray(const nfa_traverse_args *a) {
         }
     }
     return P;
+}
+
+// split kernels: a part keeps its boundaries in LDS, CAP of them (8 B each per lane).  With the
+// sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
+// be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
+// LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
+struct SplitPlan { int P, cap, lds; GridView gv; };
+static SplitPlan plan_split(const nfa_traverse_args *a) {
+    SplitPlan p;
+    p.P = count_lanes_per_ray(a, true);
+    p.cap = p.P >= 16 ? 8 : 16;
+    p.lds = 0;
+    if (p.P <= 1) return p;
+    p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
+    if (p.gv.lds_compact_cap == 0) {
+        p.P = count_lanes_per_ray(a, false);
+        p.cap = 32;
+        p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
+    }
+    return p;
 }
 
 NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, void *stream)
@@ -1436,12 +1480,12 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     const RunStore rs = make_runs(workspace, a->n_rays);
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
-    const int P = count_lanes_per_ray(a);
+    const SplitPlan plan = plan_split(a);
+    const int P = plan.P;
     if (P > 1) {
-        const int cap = P >= 16 ? 8 : 16;
-        int lds = 0;
-        const GridView gv = make_view(a, cap * kBlock * 8, &lds);
-        const bool lds_occ = gv.lds_words > 0;
+        const int lds = plan.lds;
+        const GridView &gv = plan.gv;
+        const bool lds_occ = gv.lds_compact_cap > 0;
         const unsigned nbs = (unsigned)ceil_div(a->n_rays, kBlock / P);
 #define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
     do {                                                                                                                       \
@@ -1452,8 +1496,8 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
             else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
         } else {
-            if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 16);
-            else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 8);
+            if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 32); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 32);
+            else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 32); else NFA_LAUNCH_SPLIT(false, 16, 32);
         }
 #undef NFA_LAUNCH_SPLIT
         return check_launch("traverse_count_split_kernel");
@@ -1461,7 +1505,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     int lds = 0;
     const GridView gv = make_view(a, kEvBytes, &lds);
-    const bool lds_occ = gv.lds_words > 0;
+    const bool lds_occ = gv.lds_compact_cap > 0;
 #define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
     do {                                                                                                                    \
         if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
@@ -1487,7 +1531,7 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     hipStream_t s = (hipStream_t)stream;
     if (a->n_rays == 0) { (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s); return NFA_OK; }
     NFA_REQUIRE(workspace != nullptr, "traverse_offsets: workspace is NULL");
-    const int P = count_lanes_per_ray(a);
+    const int P = plan_split(a).P;
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     const int64_t n_sums = ceil_div(a->n_rays, kBlock / P);
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
@@ -1501,7 +1545,7 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     const GridView gv = make_view(a, 0, &lds);       // no boundary lists in the general walk
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
-    const bool lds_occ = gv.lds_words > 0;
+    const bool lds_occ = gv.lds_compact_cap > 0;
 #define NFA_LAUNCH_FILL(EVM, LDSO)                                                                                           \
     do {                                                                                                                     \
         if (int rc = allow_lds(traverse_fill_kernel<EVM, LDSO>, lds)) return rc;                                              \

@@ -127,11 +127,17 @@ def pdf_case(R=4096):
             cpu_ms(lambda: oracle.searchsorted(edges, q)))
 
 
-traversal_case("M1", 128, "random 50 %")
-traversal_case("M1", 128, "sphere 11 %")
-traversal_case("M6", 256, "sphere 11 %")
-traversal_case("M6", 256, "random 50 %")
-pdf_case()
+only = os.environ.get("NFA_MICROBENCH_ONLY")      # e.g. "M1-random" for a rocprofv3 run of one case
+if only is None or only == "M1-random":
+    traversal_case("M1", 128, "random 50 %")
+if only is None or only == "M1-sphere":
+    traversal_case("M1", 128, "sphere 11 %")
+if only is None or only == "M6-sphere":
+    traversal_case("M6", 256, "sphere 11 %")
+if only is None or only == "M6-random":
+    traversal_case("M6", 256, "random 50 %")
+if only is None or only == "M4":
+    pdf_case()
 if len(sys.argv) > 1:
     with open(sys.argv[1], "w") as f:
         f.write("| workload | op | units | GPU us | G units/s | algorithmic GB/s | frac of 8 TB/s | CPU oracle ms (1 thread) | GPU/CPU |\n|---|---|---|---|---|---|---|---|---|\n")

@@ -28,19 +28,32 @@ n = int(args[0]) if len(args) > 0 else 13120
 iters = int(args[1]) if len(args) > 1 else 20
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
-field = bench.DenseGridField(bench.AABB, 128).to(dev)
-est = nerfacc.OccGridEstimator(roi_aabb=bench.AABB, resolution=128, levels=1).to(dev)
-est.train()
-for _ in range(4):
-    est._update(step=0, occ_eval_fn=lambda x: field.query_density(x) * bench.RENDER_STEP, occ_thre=1e-2)
-pool_o, pool_d = bench.make_ray_pool(n, 42, dev)
-near = torch.rand(n, device=dev) * bench.RENDER_STEP
+if os.environ.get("NFA_PHASE_WORKLOAD") == "m1-random":      # rand > 0.5 grid, 4096 rays
+    import numpy as np
+    g = np.random.default_rng(42)
+    v = g.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    o = (0.5 + 1.5 * v).astype(np.float32)
+    d = g.random((n, 3)).astype(np.float32) - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pool_o, pool_d = torch.from_numpy(o).to(dev), torch.from_numpy(d.astype(np.float32)).to(dev)
+    binaries = torch.from_numpy(g.random((1, 128, 128, 128)) > 0.5).to(dev)
+    aabbs = torch.tensor([[0.0, 0, 0, 1, 1, 1]], device=dev)
+    step = 5e-3 / 3
+    near = torch.zeros(n, device=dev)
+else:
+    field = bench.DenseGridField(bench.AABB, 128).to(dev)
+    est = nerfacc.OccGridEstimator(roi_aabb=bench.AABB, resolution=128, levels=1).to(dev)
+    est.train()
+    for _ in range(4):
+        est._update(step=0, occ_eval_fn=lambda x: field.query_density(x) * bench.RENDER_STEP, occ_thre=1e-2)
+    pool_o, pool_d = bench.make_ray_pool(n, 42, dev)
+    binaries, aabbs, step = est.binaries, est.aabbs, bench.RENDER_STEP
+    near = torch.rand(n, device=dev) * bench.RENDER_STEP
 far = torch.full((n,), 1e10, device=dev)
 lib = _backend.load_library()
 lib.nfa_debug_phase_cycles.restype = ctypes.c_int
 buf = (ctypes.c_ulonglong * 16)()
 def run():
-    return C.sample_occgrid(pool_o, pool_d, est.binaries, est.aabbs, near, far, bench.RENDER_STEP, 0.0)
+    return C.sample_occgrid(pool_o, pool_d, binaries, aabbs, near, far, step, 0.0)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
