@@ -49,6 +49,12 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         grads.append(p.grad)
+    if len(grads) == 1 and grads[0].dtype == torch.float32 and grads[0].is_contiguous():
+        # a single tensor already is the flat bucket: reduce it in place, no staging copies
+        dist.all_reduce(grads[0], op=dist.ReduceOp.SUM)
+        if average:
+            grads[0].div_(ws)
+        return
     flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:

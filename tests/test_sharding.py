@@ -38,6 +38,12 @@ def _worker(rank, world, port, out_dir):
         loss.backward()
         sharding.allreduce_gradients(model.parameters())
         flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+        # --- a single-tensor field (bench.py's voxel grid) takes the in-place path; a rank without
+        # samples (no grad) contributes zeros
+        single = torch.nn.Parameter(torch.full((4, 5), float(rank + 1)))
+        if rank == 0:
+            (single * 3.0).sum().backward()
+        sharding.allreduce_gradients([single])
         # --- counts
         s, r = sharding.allreduce_counts(1000 + rank, e - b, "cpu")
         # --- grid agreement: independent RNG diverges, synchronized_rng / broadcast agree
@@ -52,7 +58,7 @@ def _worker(rank, world, port, out_dir):
         est_b = OccGridEstimator([-1.0, -1, -1, 1, 1, 1], resolution=8, levels=1)
         est_b._update(step=0, occ_eval_fn=occ_fn)           # diverges between ranks
         sharding.broadcast_grid(est_b, src=0)
-        torch.save(dict(grad=flat, counts=(s, r), occs=est.occs, occs_b=est_b.occs, bin_b=est_b.binaries, own=own_stream),
+        torch.save(dict(grad=flat, single=single.grad.clone(), counts=(s, r), occs=est.occs, occs_b=est_b.occs, bin_b=est_b.binaries, own=own_stream),
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -71,6 +77,7 @@ def test_two_rank_step_exchange(tmp_path):
     torch.nn.functional.smooth_l1_loss(model(rays), target).backward()
     ref = torch.cat([p.grad.flatten() for p in model.parameters()])
     assert torch.allclose(r0["grad"], ref, atol=1e-6) and torch.equal(r0["grad"], r1["grad"])
+    assert torch.equal(r0["single"], torch.full((4, 5), 1.5)) and torch.equal(r1["single"], r0["single"])
     assert r0["counts"] == r1["counts"] == (2001, 64)
     assert torch.equal(r0["occs"], r1["occs"]) and (r0["occs"] > 0).any()
     assert torch.equal(r0["occs_b"], r1["occs_b"]) and torch.equal(r0["bin_b"], r1["bin_b"])
