@@ -842,6 +842,34 @@ __device__ void traverse_ray_lattice_inline(const nfa_traverse_args &a, const Gr
     t_term = t_last;
 }
 
+// Voxel walk of one part of a ray (split kernel): `on_boundary(t_exit, run_was_occupied)` is called
+// for every occupied<->empty boundary and for the ray's last run; returning false stops the walk.
+// `major_done` counts crossings of the ray's major axis; the part ends at crossing j_end.
+template <bool LDS_OCC, class F>
+__device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC> &occ, BrickCache cache, Dda s, bool live,
+                                          bool have_run, bool run_occ, float run_exit, int major_done, int j_end,
+                                          int m_rank, float seg_hi, F &&on_boundary)
+{
+    while (live) {
+        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+        const bool oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
+        if (have_run && oc != run_occ) {
+            if (!on_boundary(run_exit, run_occ)) break;
+        }
+        have_run = true;
+        run_occ = oc;
+        run_exit = t_cell;
+        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        const bool cont = dda_advance(s);
+        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        major_done += (cm_after != cm_before) ? 1 : 0;
+        if (!cont) {                                   // end of the walk: the ray's last run
+            on_boundary(run_exit, run_occ);
+            live = false;
+        } else if (major_done >= j_end) live = false;  // next part's seam
+    }
+}
+
 #ifdef NFA_PHASE_CYCLES
 // build-time instrumentation (tools/phase_cycles.py builds with -DNFA_PHASE_CYCLES): shader-clock
 // stamps between the phases of the split kernel, kept in registers and stored once per wave at the
@@ -972,32 +1000,26 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     part_live = false;
 #endif
     NFA_PHASE_MARK(3);
-    // ---- A: this part's voxels, boundaries only
-    int n_ev = 0, major_done = j_begin;
+    // ---- A: this part's voxels, boundaries only (times into the lane's LDS list)
+    int n_ev = 0;
     unsigned ev_occ = 0;
     bool overflow = false;
-    while (part_live) {
-        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-        const bool oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
-        if (have_run && oc != run_occ) {
-            if (n_ev == CAP - 1) { overflow = true; break; }
-            ev_lds[n_ev * kBlock + tid] = run_exit;
-            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
-            ++n_ev;
-        }
-        have_run = true;
-        run_occ = oc;
-        run_exit = t_cell;
-        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        const bool cont = dda_advance(s);
-        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        major_done += (cm_after != cm_before) ? 1 : 0;
-        if (!cont) {                                   // end of the walk: the ray's last run
-            ev_lds[n_ev * kBlock + tid] = run_exit;
-            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
-            ++n_ev;
-            part_live = false;
-        } else if (major_done >= j_end) part_live = false;     // next part's seam
+    walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
+                       [&](float t_exit, bool o) {
+                           if (n_ev == CAP) { overflow = true; return false; }
+                           ev_lds[n_ev * kBlock + tid] = t_exit;
+                           ev_occ |= (o ? 1u : 0u) << n_ev;
+                           ++n_ev;
+                           return true;
+                       });
+    // a part with more boundaries than its list holds puts its whole ray (all P lanes) into
+    // streaming mode: boundaries are resolved as the walk finds them and only aggregates are kept
+    // (S1); the run records are written by walking once more when the ray's prefixes are known (S2)
+    bool streaming = overflow;
+#pragma unroll
+    for (int off = 1; off < P; off <<= 1) {
+        const int other = __shfl_xor((int)streaming, off, 64);
+        streaming = streaming || (other != 0);
     }
 
     NFA_PHASE_MARK(4);
@@ -1006,7 +1028,11 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
     int64_t K_last = 0;
     float T_last = t_seg;
-    {
+    // streaming aggregates: first boundary kept apart (its samples depend on the previous part)
+    int64_t K_first = 0, sm_rest = 0;
+    int fresh_rest = 0;
+    bool occ_first = false;
+    if (!streaming) {
         int64_t K = 0;
         float T = t_seg;
         for (int j = 0; j < n_ev; ++j) {
@@ -1019,10 +1045,28 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         }
         K_last = K;
         T_last = T;
+    } else {
+        int64_t K = 0, K_prev = 0;
+        float T = t_seg;
+        n_ev = 0;
+        walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
+                           [&](float t_exit, bool o) {
+                               int64_t k; bool st;
+                               T = nfa_lattice_until(T, dt, t_exit, &k, &st);
+                               stuck_any = stuck_any || st;
+                               K += k;
+                               if (n_ev == 0) { K_first = K; occ_first = o; }
+                               else if (o && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; }
+                               K_prev = K;
+                               ++n_ev;
+                               return true;
+                           });
+        K_last = K;
+        T_last = T;
     }
     NFA_PHASE_MARK(5);
     // group-wide decisions (the P lanes of a ray are adjacent lanes of one wave)
-    bool bad = overflow || stuck_any || weird || K_last > 0x7fffffffll;
+    bool bad = stuck_any || weird || K_last > 0x7fffffffll;
 #ifdef NFA_FORCE_SERIAL
     bad = true;
 #endif
@@ -1048,13 +1092,17 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     // (each is preceded by an empty run or starts the ray: boundaries alternate)
     int64_t n_sm = 0;
     int n_fresh = 0;
-    {
+    if (!streaming) {
         int64_t K_prev = K_before;
         for (int j = 0; j < n_ev; ++j) {
             const int64_t K = ev_K[j * kBlock + tid];
             if (((ev_occ >> j) & 1u) && K > K_prev) { n_sm += K - K_prev; ++n_fresh; }
             K_prev = K;
         }
+    } else if (n_ev > 0) {
+        n_sm = sm_rest;
+        n_fresh = fresh_rest;
+        if (occ_first && K_first > K_before) { n_sm += K_first - K_before; ++n_fresh; }
     }
     // exclusive prefixes of fresh runs and samples over the ray's parts, and ray totals
     int fresh_before = 0, fresh_total = n_fresh;
@@ -1074,9 +1122,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     }
     const float T_final = __shfl(T_last, group_base + max(last_part_with_ev, 0), 64);
 
-    if (!bad) {
-        // run records of this part
-        if (rs.t0 && n_fresh > 0) {
+    // run records of this part
+    if (!bad && rs.t0 && n_fresh > 0 && fresh_total <= rs.max_runs) {
+        if (!streaming) {
             int64_t K_prev = K_before, first = sm_before;
             float T_prev = T_before;
             int idx = fresh_before;
@@ -1084,13 +1132,33 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
                 const int64_t K = ev_K[j * kBlock + tid];
                 const float T = ev_lds[j * kBlock + tid];
                 if (((ev_occ >> j) & 1u) && K > K_prev) {
-                    if (idx < rs.max_runs) { rs.t0[(int64_t)idx * R + r] = T_prev; rs.first[(int64_t)idx * R + r] = (int32_t)first; }
+                    rs.t0[(int64_t)idx * R + r] = T_prev;
+                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
                     first += K - K_prev;
                     ++idx;
                 }
                 K_prev = K;
                 T_prev = T;
             }
+        } else {                                   // S2: the same walk again, now writing
+            int64_t K = 0, K_prev = K_before, first = sm_before;
+            float T = t_seg, T_prev = T_before;
+            int idx = fresh_before;
+            walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
+                               [&](float t_exit, bool o) {
+                                   int64_t k; bool st;
+                                   T = nfa_lattice_until(T, dt, t_exit, &k, &st);
+                                   K += k;
+                                   if (o && K > K_prev) {
+                                       rs.t0[(int64_t)idx * R + r] = T_prev;
+                                       rs.first[(int64_t)idx * R + r] = (int32_t)first;
+                                       first += K - K_prev;
+                                       ++idx;
+                                   }
+                                   K_prev = K;
+                                   T_prev = T;
+                                   return true;
+                               });
         }
     }
     NFA_PHASE_MARK(6);

@@ -95,10 +95,36 @@ def test_fuzz_multi_level_and_cone(seed):
 
 
 def test_many_transitions_overflow_paths():
-    """checkerboard grid + fine lattice: > 14 runs per ray (run-record overflow -> pass-2
-    re-traversal) and > 15 boundaries per part (split kernel's serial fallback)"""
+    """checkerboard grid + fine lattice: tens of runs per ray and more boundaries per part than a
+    lane's LDS list holds (the split kernel's streaming mode: two more walks, aggregates only).
+    NFA_SPLIT_P pins the lanes per ray so that every list size / part length is exercised."""
+    import os
+
     rng = np.random.default_rng(9)
     g = np.indices((32, 32, 32)).sum(0) % 2 == 0
     aabbs = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
     o, d = _rays(rng, 900)
     assert _check(o, d, g[None], aabbs, step_size=2e-3) > 0
+    noise = rng.random((1, 128, 128, 128)) > 0.5           # SURVEY 8d M1(i): boundary every other voxel
+    box = np.array([[0, 0, 0, 1, 1, 1]], np.float32)
+    o2 = (0.5 + 1.5 * d).astype(np.float32)
+    d2 = (rng.random((900, 3)).astype(np.float32) - o2)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    from nerfacc_amd import cuda as C
+
+    def fused(o, d, grid, aabb, step):               # the fused sampling call is what runs the split kernels
+        R = o.shape[0]
+        near, far = np.zeros(R, np.float32), np.full(R, 1e10, np.float32)
+        ri, ts, te, pk = C.sample_occgrid(t(o), t(d), t(grid), t(aabb), t(near), t(far), step, 0.0)
+        r_ri, r_ts, r_te, r_pk = oracle.sampling(o, d, grid, aabb, render_step_size=step)
+        assert np.array_equal(n(ri), r_ri) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
+        assert np.array_equal(n(pk), r_pk)
+        return len(r_ri)
+
+    try:
+        for p in ("2", "4", "8", "16", "1"):
+            os.environ["NFA_SPLIT_P"] = p
+            assert fused(o2, d2.astype(np.float32), noise, box, float(np.float32(5e-3 / 3))) > 100000
+            assert fused(o, d, g[None], aabbs, 2e-3) > 0
+    finally:
+        os.environ.pop("NFA_SPLIT_P", None)
