@@ -35,12 +35,11 @@ __device__ __forceinline__ SegFwd seg_fwd(int64_t key, bool active, bool first_c
     s.dist = dist_to_head(s.heads, lane, s.open);
     return s;
 }
-// tail flags for a forward walk: lane l is a tail iff lane l+1 is a head; lane 63 peeks.
-__device__ __forceinline__ bool seg_is_tail(const SegFwd &s, const int64_t *__restrict__ keys, int64_t key,
-                                            int64_t i, int64_t end, bool active, int lane) {
-    bool t = (s.heads >> ((lane + 1) & 63)) & 1ull;
-    if (lane == 63) t = active && ((i + 1 >= end) || keys[i + 1] != key);
-    return t;
+// tail flag for a forward walk: the sample is the last of its ray.  Every lane loads the key after
+// its own together with its other inputs (same cache lines, one memory round trip) — peeking
+// keys[i + 1] from lane 63 only, after the scan flags, made each chunk wait for memory twice.
+__device__ __forceinline__ int64_t load_next_key(const int64_t *__restrict__ keys, int64_t i, int64_t end, int64_t key) {
+    return (i + 1 < end) ? keys[i + 1] : ~key;
 }
 // Reverse-direction flags.
 struct SegBwd {
@@ -240,11 +239,11 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(
     for (int64_t ch = 0; ch < n_chunks; ++ch) {
         const int64_t i = tr.begin + ch * 64 + lane;
         const bool active = i < tr.end;
-        int64_t key = 0;
+        int64_t key = 0, nkey = -1;
         float w = 0.0f;
-        if (active) { key = keys[i]; w = weights[i]; }
+        if (active) { key = keys[i]; nkey = load_next_key(keys, i, tr.end, key); w = weights[i]; }
         const SegFwd s = seg_fwd(key, active, ch == 0, edge_key, lane);
-        const bool tail = seg_is_tail(s, keys, key, i, tr.end, active, lane);
+        const bool tail = active && nkey != key;
         edge_key = readlane_i64<63>(key);
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
@@ -304,16 +303,17 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t i = tr.begin + c * 64 + lane;
         const bool active = i < tr.end;
-        int64_t key = 0;
+        int64_t key = 0, nkey = -1;
         float t0 = 0.f, t1 = 0.f, sd = 0.f, r = 0.f, g = 0.f, b = 0.f;
         if (active) {
             key = keys[i];
+            nkey = load_next_key(keys, i, tr.end, key);
             t0 = ts[i]; t1 = te[i];
             sd = sigmas[i] * (t1 - t0);
             r = rgbs[3 * i]; g = rgbs[3 * i + 1]; b = rgbs[3 * i + 2];
         }
         const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
-        const bool tail = seg_is_tail(s, keys, key, i, tr.end, active, lane);
+        const bool tail = active && nkey != key;
         edge_key = readlane_i64<63>(key);
         const float acc = seg_excl_fwd(sd, s, c_sd, lane);
         float w = 0.0f;
