@@ -150,20 +150,25 @@ def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
 # sample of the same workload.  Only this function touches oracle/.
 # ------------------------------------------------------------------------------------------
 def cpu_baseline(field, est, pool_o, pool_d, n_rays=16384, budget_s=20.0):
+    """oracle (C port of the reference algorithm) on the host: one thread on `n_rays` rays, then all
+    host cores on a proportionally larger sample (ctypes releases the GIL: one Python thread per
+    core, each running the whole per-ray pipeline on its own contiguous slice of rays)."""
+    import concurrent.futures
     import oracle
 
-    o = pool_o[:n_rays].cpu().numpy()
-    d = pool_d[:n_rays].cpu().numpy()
     binaries = est.binaries.cpu().numpy()
     aabbs = est.aabbs.cpu().numpy()
     field_cpu = DenseGridField(AABB, GRID_RES)
     field_cpu.load_state_dict({k: v.cpu() for k, v in field.state_dict().items()})
+    torch.set_num_threads(1)            # the field is excluded from the timing; keep it from oversubscribing
 
-    def once():
+    def once(o, d):
+        """returns (seconds spent outside the radiance field, rendered samples)"""
+        R = o.shape[0]
         t_field = 0.0
         t0 = time.perf_counter()
-        iv, sm, _ = oracle.traverse_grids(o, d, binaries, aabbs, np.zeros(n_rays, np.float32),
-                                          np.full(n_rays, 1e10, np.float32), RENDER_STEP, 0.0)
+        iv, sm, _ = oracle.traverse_grids(o, d, binaries, aabbs, np.zeros(R, np.float32),
+                                          np.full(R, 1e10, np.float32), RENDER_STEP, 0.0)
         ts, te, ri = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], sm["ray_indices"]
         tf = time.perf_counter()
         with torch.no_grad():
@@ -179,32 +184,60 @@ def cpu_baseline(field, est, pool_o, pool_d, n_rays=16384, budget_s=20.0):
             rgb, sig = field_cpu(pos)
             rgb, sig = rgb.numpy(), sig.squeeze(-1).numpy()
         t_field += time.perf_counter() - tf
-        col, opa, dep, ex = oracle.rendering(ts, te, ri, n_rays, sig, rgb, np.ones(3, np.float32))
+        col, opa, dep, ex = oracle.rendering(ts, te, ri, R, sig, rgb, np.ones(3, np.float32))
         gw = np.ascontiguousarray((rgb * col[ri]).sum(-1).astype(np.float32))      # stand-in for dL/dw
         oracle.render_weight_from_density_bwd(ts, te, sig, ri, g_w=gw)
         return time.perf_counter() - t0 - t_field, ri.shape[0]
 
-    once()
+    # ---- one thread
+    o1 = pool_o[:n_rays].cpu().numpy()
+    d1 = pool_d[:n_rays].cpu().numpy()
+    once(o1, d1)
     times, n_s = [], 0
     t_begin = time.perf_counter()
-    while len(times) < 10 and time.perf_counter() - t_begin < budget_s:
-        dt, n_s = once()
+    while len(times) < 10 and time.perf_counter() - t_begin < budget_s / 2:
+        dt, n_s = once(o1, d1)
         times.append(dt)
-    med = float(np.median(times))
+    med1 = float(np.median(times))
+
+    # ---- all cores: `per` rays per thread, slices of the same pool
+    cores = os.cpu_count() or 1
+    per = 2048
+    n_all = min(cores * per, pool_o.shape[0])
+    oa = pool_o[:n_all].cpu().numpy()
+    da = pool_d[:n_all].cpu().numpy()
+    slices = [(i, min(i + per, n_all)) for i in range(0, n_all, per)]
+
+    def run_all(pool):
+        t0 = time.perf_counter()
+        res = list(pool.map(lambda s: once(oa[s[0]:s[1]], da[s[0]:s[1]]), slices))
+        wall = time.perf_counter() - t0       # (the slices' field queries run concurrently and stay in)
+        return wall, sum(r[1] for r in res)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(slices)) as pool:
+        run_all(pool)
+        walls = []
+        t_begin = time.perf_counter()
+        while len(walls) < 5 and time.perf_counter() - t_begin < budget_s / 2:
+            walls.append(run_all(pool))
+    wall, n_s_all = sorted(walls)[len(walls) // 2]
     return {
-        "value": n_rays / med, "unit": "rays/s", "cores": 1, "kind": "port",
-        "samples_per_sec": n_s / med,
-        "sample": f"{n_rays} rays of the same pool/grid: oracle traversal + visibility + rendering fwd + weight bwd, "
-                  f"single thread, median of {len(times)}; radiance-field evaluation (torch CPU) excluded",
-        "host_cores_available": os.cpu_count(),
+        "value": n_all / wall, "unit": "rays/s", "cores": len(slices), "kind": "port",
+        "samples_per_sec": n_s_all / wall,
+        "sample": f"{n_all} rays of the same pool/grid in {len(slices)} slices, one thread per host core: oracle traversal + "
+                  f"visibility + rendering fwd + weight bwd per slice, wall clock of the whole batch (includes the "
+                  f"threads' torch-CPU field queries), median of {len(walls)}",
+        "single_thread": {"value": n_rays / med1, "unit": "rays/s", "samples_per_sec": n_s / med1,
+                          "sample": f"{n_rays} rays, median of {len(times)}, radiance-field evaluation excluded"},
+        "host_cores_available": cores,
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=1 << 21)
     args = ap.parse_args()
