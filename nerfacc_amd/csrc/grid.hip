@@ -1295,8 +1295,24 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args
 {
     const float step_size = a.step_size, cone = a.cone_angle;
     const int64_t R = a.n_rays;
-    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n_samples; s += (int64_t)gridDim.x * kBlock) {
-        int64_t lo = 0, hi = R;                       // last ray with sm_starts <= s
+    __shared__ int64_t s_span[2];
+    for (int64_t s0 = (int64_t)blockIdx.x * kBlock; s0 < n_samples; s0 += (int64_t)gridDim.x * kBlock) {
+        // the workgroup's 256 consecutive samples belong to a narrow range of rays: two lanes
+        // search the whole offset array for the first and the last sample, everyone else only
+        // that range (a dozen rays for NeRF-like rays: 4 dependent loads instead of log2 R)
+        const int64_t s_last = (s0 + kBlock - 1 < n_samples ? s0 + kBlock - 1 : n_samples - 1);
+        if (threadIdx.x < 2) {
+            const int64_t target = threadIdx.x == 0 ? s0 : s_last;
+            int64_t lo = 0, hi = R;                   // last ray with sm_starts <= target
+            while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (a.sm_starts[m] <= target) lo = m + 1; else hi = m; }
+            s_span[threadIdx.x] = lo - 1;
+        }
+        __syncthreads();
+        const int64_t r_first = s_span[0], r_last = s_span[1];
+        __syncthreads();
+        const int64_t s = s0 + threadIdx.x;
+        if (s >= n_samples) continue;
+        int64_t lo = r_first, hi = r_last + 1;
         while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (a.sm_starts[m] <= s) lo = m + 1; else hi = m; }
         const int64_t r = lo - 1;
         const int n_runs = rs.n_runs[r];

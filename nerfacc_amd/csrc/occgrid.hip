@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(
 
 // sum and count of the visible cells (occs >= 0; invisible ones hold -1, :330-332); one
 // {sum, count} pair of doubles per workgroup, combined in a fixed order by the threshold kernel
-constexpr int kReduceBlocks = 512;
+constexpr int kReduceBlocks = 128;
 __global__ __launch_bounds__(kBlock) void grid_mean_partials_kernel(const float *__restrict__ occs, int64_t n, double *__restrict__ partials)
 {
     __shared__ double s_sum[kWavesPerBlock], s_cnt[kWavesPerBlock];
@@ -87,12 +87,18 @@ __global__ __launch_bounds__(kBlock) void grid_threshold_kernel(
     uint8_t *__restrict__ binaries, float *__restrict__ thre_out)
 {
     __shared__ float s_thre;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                       // first wave: fixed-order tree over the <= 128 partial pairs
+        const int l = threadIdx.x;
         double a = 0.0, b = 0.0;
-        for (int p = 0; p < n_partials; ++p) { a += partials[2 * p]; b += partials[2 * p + 1]; }
-        const float mean = b > 0.0 ? (float)(a / b) : __builtin_nanf("");
-        s_thre = (mean != mean) ? mean : fminf(mean, occ_thre);
-        if (blockIdx.x == 0 && thre_out) *thre_out = s_thre;
+        if (l < n_partials) { a = partials[2 * l]; b = partials[2 * l + 1]; }
+        if (l + 64 < n_partials) { a += partials[2 * (l + 64)]; b += partials[2 * (l + 64) + 1]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+        if (l == 0) {
+            const float mean = b > 0.0 ? (float)(a / b) : __builtin_nanf("");
+            s_thre = (mean != mean) ? mean : fminf(mean, occ_thre);
+            if (blockIdx.x == 0 && thre_out) *thre_out = s_thre;
+        }
     }
     __syncthreads();
     const float thre = s_thre;
