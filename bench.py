@@ -375,7 +375,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled
                 # per the gfx950 note of MI355X_MICROARCH.md) on this same ray batch: profiles/r01_pmc_traffic.md
-                "traffic": 8.1e6 if abs(rays_per_launch - 13120) < 2000 else None,
+                "traffic": 7.97e6 if abs(rays_per_launch - 13120) < 2000 else None,
                 "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "candidate_samples_per_sec_of_kernel_time": cand / (ms * 1e-3) if ms > 0 else 0.0,
