@@ -696,26 +696,26 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
     t_term = t_last;
 }
 
+// sum over the 64 lanes, result in every lane: four row_shr adds inside each 16-lane row on the
+// DPP path, then the four row totals through v_readlane (no LDS crossbar, no barrier)
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;   // valid in lane 0
+    v += dpp_i64<kDppRowShr + 1>(v);
+    v += dpp_i64<kDppRowShr + 2>(v);
+    v += dpp_i64<kDppRowShr + 4>(v);
+    v += dpp_i64<kDppRowShr + 8>(v);
+    return readlane_i64<15>(v) + readlane_i64<31>(v) + readlane_i64<47>(v) + readlane_i64<63>(v);
 }
 
-// block-level reduction of per-ray {edges, samples, overflow rays} -> block_sums[3 b + {0,1,2}]
-// (lanes that do not own a ray pass zeros)
-__device__ __forceinline__ void publish_block_sums(int64_t n_iv, int64_t n_sm, int64_t n_ovf, int64_t *__restrict__ block_sums) {
-    __shared__ int64_t part[3][kWavesPerBlock];
+// per-WAVE reduction of per-ray {edges, samples, overflow rays} -> wave_sums[3 w + {0,1,2}], w = the
+// wave's global index (lanes that do not own a ray pass zeros).  One triple per wave instead of
+// per workgroup: no LDS, no __syncthreads, so a wave that finished its rays retires at once.
+__device__ __forceinline__ void publish_wave_sums(int64_t n_iv, int64_t n_sm, int64_t n_ovf, int64_t *__restrict__ wave_sums) {
     const int64_t w_iv = wave_sum_i64(n_iv), w_sm = wave_sum_i64(n_sm), w_ov = wave_sum_i64(n_ovf);
-    const int wave = threadIdx.x >> 6;
-    if (lane_id() == 0) { part[0][wave] = w_iv; part[1][wave] = w_sm; part[2][wave] = w_ov; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t s0 = 0, s1 = 0, s2 = 0;
-        for (int w = 0; w < kWavesPerBlock; ++w) { s0 += part[0][w]; s1 += part[1][w]; s2 += part[2][w]; }
-        block_sums[3 * blockIdx.x] = s0;
-        block_sums[3 * blockIdx.x + 1] = s1;
-        block_sums[3 * blockIdx.x + 2] = s2;
+    if (lane_id() == 0) {
+        const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        wave_sums[3 * w] = w_iv;
+        wave_sums[3 * w + 1] = w_sm;
+        wave_sums[3 * w + 2] = w_ov;
     }
 }
 
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
         if (a.iv_cnts) a.iv_cnts[r] = sink.n_iv;
         a.sm_cnts[r] = sink.n_sm;
     }
-    publish_block_sums(sink.n_iv, sink.n_sm, ovf, block_sums);
+    publish_wave_sums(sink.n_iv, sink.n_sm, ovf, block_sums);
 }
 
 // ---- split walk: P lanes per ray ---------------------------------------------------------
@@ -923,8 +923,6 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     const int group_base = lane_id() - part;
     int64_t k_tmp; bool stuck_any = false, stuck = false;
     float t_seg = near;
-    if (live && part == 0) { t_seg = nfa_lattice_until(near, dt, seg_lo, &k_tmp, &stuck); stuck_any = stuck; }
-    t_seg = __shfl(t_seg, group_base, 64);
 
     Dda s;
     s.tx = s.ty = s.tz = 0.f; s.dx = s.dy = s.dz = 0.f;
@@ -932,22 +930,48 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     if (live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs, gv.res);
     NFA_PHASE_MARK(1);
 
-    // crossings until each axis reaches its overflow index, and when the walk ends
+    // crossings until each axis reaches its overflow index
     const int nx = s.sx ? (s.ox - s.cx) * s.sx : 1, ny = s.sy ? (s.oy - s.cy) * s.sy : 1, nz = s.sz ? (s.oz - s.cz) * s.sz : 1;
-    float T_mine = 0.f;                      // lane `a` of the group: last crossing of axis a (x, y, z)
-    {
-        const int ax = part % 3;
-        const float t0 = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
-        const float dl = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
-        const int nn = ax == 0 ? nx : (ax == 1 ? ny : nz);
-        if (P < 3 || part < 3) T_mine = nfa_lattice_advance(t0, dl, nn - 1, nullptr);
-    }
-    float Tx, Ty, Tz;
-    if (P >= 3) {
-        Tx = __shfl(T_mine, group_base, 64);
-        Ty = __shfl(T_mine, group_base + 1, 64);
-        Tz = __shfl(T_mine, group_base + 2, 64);
+    float Tx, Ty, Tz;      // time of the last crossing of each axis: when the walk ends
+    if (P >= 4) {
+        // FOUR closed-form jumps per ray — the lattice from `near` to the segment start and the
+        // last crossing of x, y, z — run as ONE call, on lanes 0..3 of the ray's group (a wave pays
+        // for a call once, however many of its lanes are in it).  (Folding the segment-start jump
+        // into phase B instead — every part starting its lattice at `near` — was measured slower:
+        // all parts then pay the many short binades next to zero.)
+        const float h = dt * 0.5f;
+        float adv_t = near, adv_d = dt;
+        int64_t adv_j = 0;
+        bool jump = false;
+        if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
+            const float est = (seg_lo - h - near) / dt;
+            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - 2 - (guess >> 6); jump = true; }
+        }
+        if (part >= 1 && part <= 3) {
+            adv_t = part == 1 ? s.tx : (part == 2 ? s.ty : s.tz);
+            adv_d = part == 1 ? s.dx : (part == 2 ? s.dy : s.dz);
+            adv_j = (part == 1 ? nx : (part == 2 ? ny : nz)) - 1;
+            jump = live;
+        }
+        float adv_v = adv_t;
+        if (jump) adv_v = nfa_lattice_advance(adv_t, adv_d, adv_j, nullptr);
+        if (live && part == 0) {
+            float t = near;
+            if (jump && adv_v + h < seg_lo) t = adv_v;
+            while (t + h < seg_lo) {
+                const float nt = t + dt;
+                if (nt == t) { stuck_any = true; break; }
+                t = nt;
+            }
+            t_seg = t;
+        }
+        t_seg = __shfl(t_seg, group_base, 64);
+        Tx = __shfl(adv_v, group_base + 1, 64);
+        Ty = __shfl(adv_v, group_base + 2, 64);
+        Tz = __shfl(adv_v, group_base + 3, 64);
     } else {
+        if (live && part == 0) { t_seg = nfa_lattice_until(near, dt, seg_lo, &k_tmp, &stuck); stuck_any = stuck; }
+        t_seg = __shfl(t_seg, group_base, 64);
         Tx = nfa_lattice_advance(s.tx, s.dx, nx - 1, nullptr);
         Ty = nfa_lattice_advance(s.ty, s.dy, ny - 1, nullptr);
         Tz = nfa_lattice_advance(s.tz, s.dz, nz - 1, nullptr);
@@ -981,10 +1005,18 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         const float T_seam = nfa_lattice_advance(t0m, dm, j_begin - 1, nullptr);    // time of major crossing j_begin
         if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;
         else {
-            float pend;
-            if (m_rank != 2) { const int c = crossings_before(s.tx, s.dx, 2, T_seam, m_rank, nx, pend); s.cx += c * s.sx; s.tx = pend; }
-            if (m_rank != 1) { const int c = crossings_before(s.ty, s.dy, 1, T_seam, m_rank, ny, pend); s.cy += c * s.sy; s.ty = pend; }
-            if (m_rank != 0) { const int c = crossings_before(s.tz, s.dz, 0, T_seam, m_rank, nz, pend); s.cz += c * s.sz; s.tz = pend; }
+            // the two minor axes, picked with selects so that every lane of the wave runs the SAME two
+            // closed-form counts whatever its ray's major axis is (three `if (m_rank != k)` blocks made
+            // a wave with mixed major axes execute all three): minor 1 is x (y for an x-major ray),
+            // minor 2 is z (y for a z-major ray)
+            const bool xm = m_rank == 2, zm = m_rank == 0;
+            float pend1, pend2;
+            const int c1 = crossings_before(xm ? s.ty : s.tx, xm ? s.dy : s.dx, xm ? 1 : 2, T_seam, m_rank, xm ? ny : nx, pend1);
+            const int c2 = crossings_before(zm ? s.ty : s.tz, zm ? s.dy : s.dz, zm ? 1 : 0, T_seam, m_rank, zm ? ny : nz, pend2);
+            if (!xm) { s.cx += c1 * s.sx; s.tx = pend1; }
+            if (xm) { s.cy += c1 * s.sy; s.ty = pend1; }
+            if (zm) { s.cy += c2 * s.sy; s.ty = pend2; }
+            if (!zm) { s.cz += c2 * s.sz; s.tz = pend2; }
             // the voxel just before the seam: occupancy state the part inherits
             int px = s.cx, py = s.cy, pz = s.cz;
             if (m_rank == 2) { px += (j_begin - 1) * s.sx; s.cx += j_begin * s.sx; s.tx = T_seam + s.dx; }
@@ -1049,18 +1081,18 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         int64_t K = 0, K_prev = 0;
         float T = t_seg;
         n_ev = 0;
-        walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
-                           [&](float t_exit, bool o) {
-                               int64_t k; bool st;
-                               T = nfa_lattice_until(T, dt, t_exit, &k, &st);
-                               stuck_any = stuck_any || st;
-                               K += k;
-                               if (n_ev == 0) { K_first = K; occ_first = o; }
-                               else if (o && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; }
-                               K_prev = K;
-                               ++n_ev;
-                               return true;
-                           });
+        auto on_boundary = [&](float t_exit, bool o) {
+            int64_t k; bool st;
+            T = nfa_lattice_until(T, dt, t_exit, &k, &st);
+            stuck_any = stuck_any || st;
+            K += k;
+            if (n_ev == 0) { K_first = K; occ_first = o; }
+            else if (o && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; }
+            K_prev = K;
+            ++n_ev;
+            return true;
+        };
+        walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi, on_boundary);
         K_last = K;
         T_last = T;
     }
@@ -1144,21 +1176,21 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
             int64_t K = 0, K_prev = K_before, first = sm_before;
             float T = t_seg, T_prev = T_before;
             int idx = fresh_before;
-            walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
-                               [&](float t_exit, bool o) {
-                                   int64_t k; bool st;
-                                   T = nfa_lattice_until(T, dt, t_exit, &k, &st);
-                                   K += k;
-                                   if (o && K > K_prev) {
-                                       rs.t0[(int64_t)idx * R + r] = T_prev;
-                                       rs.first[(int64_t)idx * R + r] = (int32_t)first;
-                                       first += K - K_prev;
-                                       ++idx;
-                                   }
-                                   K_prev = K;
-                                   T_prev = T;
-                                   return true;
-                               });
+            auto on_boundary = [&](float t_exit, bool o) {
+                int64_t k; bool st;
+                T = nfa_lattice_until(T, dt, t_exit, &k, &st);
+                K += k;
+                if (o && K > K_prev) {
+                    rs.t0[(int64_t)idx * R + r] = T_prev;
+                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
+                    first += K - K_prev;
+                    ++idx;
+                }
+                K_prev = K;
+                T_prev = T;
+                return true;
+            };
+                walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi, on_boundary);
         }
     }
     NFA_PHASE_MARK(6);
@@ -1186,7 +1218,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         a.sm_cnts[r] = out_sm;
     }
     NFA_PHASE_MARK(7);
-    publish_block_sums(out_iv, out_sm, out_ovf, block_sums);     // this block's kBlock / P rays
+    publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);      // this wave's 64 / P rays
     NFA_PHASE_MARK(8);
     NFA_PHASE_END();
 }
@@ -1432,8 +1464,8 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
 }
 
 // workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: max_runs*R f32 ][ run first: max_runs*R i32 ][ n_runs: R u16 ]
-// one triple per 16 rays is the finest granularity any count kernel publishes
-inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * ceil_div(n_rays > 0 ? n_rays : 1, 16); }
+// one triple per wave; the finest granularity any count kernel publishes is 4 rays per wave (P = 16)
+inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * (ceil_div(n_rays > 0 ? n_rays : 1, 4) + kWavesPerBlock); }
 RunStore make_runs(void *workspace, int64_t n_rays) {
     RunStore rs;
     uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
@@ -1617,9 +1649,9 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     NFA_REQUIRE(workspace != nullptr, "traverse_offsets: workspace is NULL");
     const int P = plan_split(a).P;
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    const int64_t n_sums = ceil_div(a->n_rays, kBlock / P);
+    const int64_t n_sums = ceil_div(a->n_rays, kBlock / P) * kWavesPerBlock;      // one triple per wave of the count launch
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
-                       a->sm_starts, a->n_rays, (const int64_t *)workspace, P, n_sums, a->totals);
+                       a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals);
     return check_launch("traverse_offsets_kernel");
 }
 
