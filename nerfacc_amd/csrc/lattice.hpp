@@ -46,44 +46,42 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
         const float small = d * 32.0f;
         while (j > 0 && t < small && t > -small) { t = t + d; --j; }
     }
+    // One trip = either n >= 1 steps inside the current binade (integer multiply-add) or one real
+    // fp32 add (binade crossings, ties on an odd mantissa, anything irregular).  Both candidates
+    // are computed and one is selected: on the GPU a wave whose lanes disagree would execute both
+    // sides of a branch anyway, and straight-line code keeps a lone wave's pipeline full.
     while (j > 0) {
         const uint32_t tb = nfa_f2u(t);
         const int e = (int)((tb >> 23) & 0xffu);
         const int sh = e - ed;
-        bool fast = d_ok && (tb >> 31) == 0 && e >= 1 && e < 254 && sh >= 0 && sh <= 24;
-        uint32_t c = 0, c0 = 0, m = 0;
-        if (fast) {
-            m = (tb & 0x7fffffu) | 0x800000u;
-            c0 = D >> sh;
-            const uint32_t rem = D & ((1u << sh) - 1u);
-            const uint32_t half = sh ? (1u << (sh - 1)) : 0u;
-            if (rem == 0u || rem < half) c = c0;
-            else if (rem > half) c = c0 + 1u;
-            else if (m & 1u) fast = false;             // tie with odd m: one real step makes m even
-            else c = c0 + (c0 & 1u);
-            if (fast && c == 0u) break;                // t + d rounds back to t: stuck
-            if (fast && m > (1u << 24) - c0 - 1u) fast = false;   // next sum may pass 2^(e+1)
-        }
-        if (!fast) {
-            const float nt = t + d;
-            if (nt == t) break;
-            t = nt;
-            --j;
-            continue;
-        }
+        const bool ok = d_ok && (tb >> 31) == 0 && e >= 1 && e < 254 && sh >= 0 && sh <= 24;
+        const uint32_t shc = ok ? (uint32_t)sh : 0u;
+        const uint32_t m = (tb & 0x7fffffu) | 0x800000u;
+        const uint32_t c0 = D >> shc;
+        const uint32_t rem = D & ((1u << shc) - 1u);
+        const uint32_t half = (1u << shc) >> 1;
+        const bool tie = rem == half && rem != 0u;               // d / u exactly half-way
+        const bool tie_odd = tie && (m & 1u);                     // one real step makes m even
+        // round to nearest; on a tie round-half-even makes the increment c0 + (c0 & 1) once m is even
+        const uint32_t c = c0 + (rem > half ? 1u : 0u) + ((tie && !(m & 1u)) ? (c0 & 1u) : 0u);
+        if (ok && !tie_odd && c == 0u) break;                     // t + d rounds back to t: stuck
+        const uint32_t lim = (1u << 24) - c0 - 1u;                // next sum may pass 2^(e+1) beyond this
+        const bool fast = ok && !tie_odd && m <= lim;
+        const float nt = t + d;
+        if (!fast && nt == t) break;
         // steps that provably stay inside the binade: floor((lim - m) / c) + 1.  The quotient is
-        // taken in fp32 and corrected downwards (never upwards: a smaller count is always safe,
-        // it only costs one more trip through this loop) — an integer divide is ~40 instructions
-        // on the GPU.
-        const uint32_t lim = (1u << 24) - c0 - 1u;
-        const uint32_t x = lim - m;
-        uint32_t q = (uint32_t)((float)x / (float)c);
-        while ((uint64_t)q * c > x) --q;
+        // taken in fp32 (both operands < 2^24: exact, and the correctly rounded quotient truncates
+        // to floor or floor + 1) and corrected once — an integer divide is ~40 instructions on the GPU.
+        const uint32_t cd = fast ? c : 1u;
+        const uint32_t x = fast ? lim - m : 0u;
+        uint32_t q = (uint32_t)((float)x / (float)cd);
+        q -= ((uint64_t)q * cd > x) ? 1u : 0u;
         const uint64_t jmax = (uint64_t)q + 1u;
-        const uint64_t n = jmax < (uint64_t)j ? jmax : (uint64_t)j;
-        m += (uint32_t)n * c;                          // <= 2^24
+        const uint64_t n = fast ? (jmax < (uint64_t)j ? jmax : (uint64_t)j) : 1u;
+        const uint32_t m2 = m + (uint32_t)n * cd;                  // <= 2^24
+        const float tf = (m2 >> 24) ? nfa_u2f((uint32_t)(e + 1) << 23) : nfa_u2f(((uint32_t)e << 23) | (m2 & 0x7fffffu));
+        t = fast ? tf : nt;
         j -= (int64_t)n;
-        t = (m >> 24) ? nfa_u2f((uint32_t)(e + 1) << 23) : nfa_u2f(((uint32_t)e << 23) | (m & 0x7fffffu));
     }
     if (taken) *taken = j0 - j;
     return t;
