@@ -1558,6 +1558,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         if (a->n_rays <= 8192) P = sparse ? 8 : 16;
         else if (a->n_rays <= 16384) P = 8;
         else if (a->n_rays <= 36864) P = 4;
+        else if (a->n_rays <= 65536) P = 2;
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
