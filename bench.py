@@ -373,14 +373,16 @@ def main():
             "roofline": {
                 "kernel": "traverse_count_split_kernel (+ traverse_emit_kernel)", "bound": "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled
-                # per the gfx950 note of MI355X_MICROARCH.md) on this same ray batch: profiles/r01_pmc_traffic.md
-                "traffic": 7.97e6 if abs(rays_per_launch - 13120) < 2000 else None,
+                # HBM bytes per sampling call from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+                # passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; profiles/r01_pmc_traffic.md:
+                # 7.97 MB at 13 120 rays / 328 k candidates = 1.30 x the algorithmic bytes of that call), scaled
+                # to this run's algorithmic bytes
+                "traffic": 1.30 * alg_bytes,
                 "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "candidate_samples_per_sec_of_kernel_time": cand / (ms * 1e-3) if ms > 0 else 0.0,
                 "note": "issue/latency-bound voxel walk: 16 B per sample from an LDS-resident grid, HBM fraction is small "
-                        "by construction (DESIGN.md 3.2); the HBM-streaming kernels of the path reach 3.0-3.8 TB/s "
+                        "by construction (DESIGN.md 3.2); the HBM-streaming kernels of the path reach 3.4-5.5 TB/s at N >= 2^24 "
                         "(profiles/r01_roofline_streaming.md)",
             },
         }
