@@ -996,9 +996,6 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     BrickCache cache;
     cache.id = -1;
     cache.bits = 0;
-#ifdef NFA_ABL_NOSEAM
-    if (j_begin > 0) part_live = false;
-#endif
     if (part_live && j_begin > 0) {
         const float t0m = m_rank == 2 ? s.tx : (m_rank == 1 ? s.ty : s.tz);
         const float dm = m_rank == 2 ? s.dx : (m_rank == 1 ? s.dy : s.dz);
@@ -1028,9 +1025,6 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         }
     }
 
-#ifdef NFA_ABL_NOWALK
-    part_live = false;
-#endif
     NFA_PHASE_MARK(3);
     // ---- A: this part's voxels, boundaries only (times into the lane's LDS list)
     int n_ev = 0;
@@ -1099,7 +1093,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     NFA_PHASE_MARK(5);
     // group-wide decisions (the P lanes of a ray are adjacent lanes of one wave)
     bool bad = stuck_any || weird || K_last > 0x7fffffffll;
-#ifdef NFA_FORCE_SERIAL
+#ifdef NFA_FORCE_SERIAL                          // test builds: every ray through the serial in-kernel walk
     bad = true;
 #endif
 #pragma unroll
