@@ -83,3 +83,47 @@ for case in range(n_cases):
             print(f"MISMATCH case {case} P={p or 'auto'} res={res} kind={kind} mode={mode} R={R} step={step} samples {len(r_ri)} vs {ri.shape[0]}", flush=True)
     os.environ.pop("NFA_SPLIT_P", None)
 print(f"{n_cases} cases x 6 lane settings ({nonempty} with samples, {total_samples} oracle samples in total), {bad} mismatches, {time.time() - t_begin:.0f} s")
+
+# ---- second campaign: the reference-API call (traverse_grids) on multi-level grids, with cone angles,
+# per-voxel mode (step <= 0), step limits + over-allocation and ray masks
+from nerfacc_amd.grid import traverse_grids
+bad2 = 0
+tot2 = 0
+t_begin = time.time()
+for case in range(n_cases // 4):
+    g = np.random.default_rng(seed0 * 7919 + 5000 + case)
+    levels = int(g.integers(1, 5))
+    res = int(g.choice([8, 16, 32, 64]))
+    occ = g.random((levels, res, res, res)) > g.choice([0.5, 0.8, 0.97])
+    base = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    aabbs = np.stack([base * 2.0**l for l in range(levels)]).astype(np.float32)
+    R = int(g.choice([3, 100, 2000, 12000]))
+    o = (g.normal(size=(R, 3)) * g.choice([0.3, 1.5, 6.0])).astype(np.float32)
+    d = g.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True); d = d.astype(np.float32)
+    step = float(np.float32(g.choice([-1.0, 2e-2, 5e-3])))
+    cone = float(g.choice([0.0, 0.0, 0.004, 0.02]))
+    near = (g.random(R) * 0.2).astype(np.float32)
+    far = np.full(R, float(g.choice([1e10, 3.0])), np.float32)
+    kw = {}
+    if g.random() < 0.35:
+        kw = dict(traverse_steps_limit=int(g.integers(1, 20)), over_allocate=bool(g.random() < 0.5))
+        if kw["over_allocate"]:
+            kw["rays_mask"] = g.random(R) < 0.7
+    r_iv, r_sm, r_term = oracle.traverse_grids(o, d, occ, aabbs, near, far, step, cone, **kw)
+    tkw = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    iv, sm, term = traverse_grids(T(o), T(d), T(occ), T(aabbs), T(near), T(far), step, cone, **tkw)
+    tot2 += int(r_sm["packed_info"][:, 1].sum())
+    n_ = lambda x: x.cpu().numpy()
+    ok = (np.array_equal(n_(sm.packed_info), r_sm["packed_info"]) and np.array_equal(n_(iv.packed_info), r_iv["packed_info"])
+          and np.array_equal(n_(iv.vals), r_iv["vals"]) and np.array_equal(n_(sm.vals), r_sm["vals"])
+          and np.array_equal(n_(sm.ray_indices), r_sm["ray_indices"])
+          and np.array_equal(n_(iv.is_left), r_iv["is_left"]) and np.array_equal(n_(iv.is_right), r_iv["is_right"])
+          and np.array_equal(n_(sm.is_valid), r_sm["is_valid"]))
+    live = r_sm["packed_info"][:, 1] > 0
+    if "rays_mask" in kw:
+        live &= kw["rays_mask"]
+    ok = ok and np.array_equal(n_(term)[live], r_term[live])
+    if not ok:
+        bad2 += 1
+        print(f"MISMATCH (API) case {case} levels={levels} res={res} R={R} step={step} cone={cone} kw={ {k: v for k, v in kw.items() if k != 'rays_mask'} }", flush=True)
+print(f"traverse_grids API: {n_cases // 4} cases ({tot2} oracle samples), {bad2} mismatches, {time.time() - t_begin:.0f} s")
