@@ -39,6 +39,7 @@ class _WeightFromDensity(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ray_indices, t_starts, t_ends, sigmas, prefix_trans):
+        ctx.set_materialize_grads(False)     # unused outputs reach backward as None, not as zero-filled tensors
         t_starts, t_ends, sigmas = t_starts.contiguous(), t_ends.contiguous(), sigmas.contiguous()
         if prefix_trans is not None:
             prefix_trans = prefix_trans.contiguous()
@@ -77,6 +78,7 @@ class _Rendering(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, render_bkgd, expected_depths):
+        ctx.set_materialize_grads(False)     # of six outputs a loss usually touches one: no zero fills for the rest
         t_starts, t_ends = t_starts.contiguous(), t_ends.contiguous()
         sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
         bk = None if render_bkgd is None else render_bkgd.detach().to(torch.float32).contiguous()
