@@ -115,6 +115,16 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// sum over the 64 lanes, result in every lane: four row_shr adds inside each 16-lane row on the
+// DPP path, then the four row totals through v_readlane (no LDS crossbar, no barrier)
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+    v += dpp_i64<kDppRowShr + 1>(v);
+    v += dpp_i64<kDppRowShr + 2>(v);
+    v += dpp_i64<kDppRowShr + 4>(v);
+    v += dpp_i64<kDppRowShr + 8>(v);
+    return readlane_i64<15>(v) + readlane_i64<31>(v) + readlane_i64<47>(v) + readlane_i64<63>(v);
+}
+
 // Segmented inclusive scan over the 64 lanes of a wave, forward (towards higher lanes).
 // `dist` = number of lanes between this lane and the first lane of its segment inside this
 // wave-chunk (0 for a segment head).  Four row_shr steps scan each 16-lane row, row_bcast:15

@@ -696,16 +696,6 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
     t_term = t_last;
 }
 
-// sum over the 64 lanes, result in every lane: four row_shr adds inside each 16-lane row on the
-// DPP path, then the four row totals through v_readlane (no LDS crossbar, no barrier)
-__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
-    v += dpp_i64<kDppRowShr + 1>(v);
-    v += dpp_i64<kDppRowShr + 2>(v);
-    v += dpp_i64<kDppRowShr + 4>(v);
-    v += dpp_i64<kDppRowShr + 8>(v);
-    return readlane_i64<15>(v) + readlane_i64<31>(v) + readlane_i64<47>(v) + readlane_i64<63>(v);
-}
-
 // per-WAVE reduction of per-ray {edges, samples, overflow rays} -> wave_sums[3 w + {0,1,2}], w = the
 // wave's global index (lanes that do not own a ray pass zeros).  One triple per wave instead of
 // per workgroup: no LDS, no __syncthreads, so a wave that finished its rays retires at once.

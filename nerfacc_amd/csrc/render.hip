@@ -201,14 +201,33 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     if (lane == 0) tile_cnts[w] = kept;
 }
 
-// 3) stream compaction with ballot ranks
+// 3) stream compaction with ballot ranks.  `tile_offs` = exclusive prefix of the tile counts, or —
+// fused form for up to kVisFusedTiles tiles (every training-size call) — the counts themselves:
+// each wave then sums the counts before its own (<= 64 L2 loads per lane) and the last one
+// stores the total, which saves the single-workgroup prefix-sum launch in between.
+constexpr int64_t kVisFusedTiles = 4096;
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, int64_t n, int64_t tile,
+    const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, int fused, int64_t n_tiles,
+    int64_t *__restrict__ n_out, int64_t n, int64_t tile,
     int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
-    int64_t dst = tile_offs[w_];
+    const int64_t w_ = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w_ >= n_tiles) return;
+    const int lane = lane_id();
+    int64_t dst;
+    if (fused) {
+        int64_t p = 0;
+        for (int64_t j = lane; j < w_; j += 64) p += tile_offs[j];
+        dst = wave_sum_i64(p);
+        if (w_ == n_tiles - 1 && lane == 0) *n_out = dst + tile_offs[w_];
+    } else {
+        dst = tile_offs[w_];
+    }
+    if (!o_keys) return;
+    const TileRange tr = snapped_tile(keys, n, w_, tile);
+    if (tr.begin >= tr.end) return;
+    const int64_t n_chunks = (tr.end - tr.begin + 63) >> 6;
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t i = tr.begin + c * 64 + lane;
         const bool keep = (i < tr.end) && mask[i];
@@ -482,14 +501,16 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
     hipLaunchKernelGGL(visibility_mask_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
                        dens, from_alpha, n, tile, early_stop_eps, alpha_thre, mask, tile_cnts);
     if (int rc = check_launch("visibility_mask_kernel")) return rc;
-    if (int rc = nfa_exclusive_sum_i64(tile_cnts, T, tile_offs, n_out, stream)) return rc;
-    if (out_ray_indices) {
-        NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
-        hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts,
-                           t_ends, mask, tile_offs, n, tile, out_ray_indices, out_t_starts, out_t_ends);
-        return check_launch("visibility_compact_kernel");
+    if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
+    const bool fused = T <= kVisFusedTiles;
+    if (!fused) {
+        if (int rc = nfa_exclusive_sum_i64(tile_cnts, T, tile_offs, n_out, stream)) return rc;
+        if (!out_ray_indices) return NFA_OK;
     }
-    return NFA_OK;
+    hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
+                       mask, fused ? tile_cnts : tile_offs, fused ? 1 : 0, T, n_out, n, tile,
+                       out_ray_indices, out_t_starts, out_t_ends);
+    return check_launch("visibility_compact_kernel");
 }
 
 NFA_EXPORT int nfa_accumulate_along_rays(const int64_t *ray_indices, const float *weights, const float *values,
