@@ -415,17 +415,31 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
 // ----------------------------------------------------------------------------------------
 // pack_info / unpack_info
 // ----------------------------------------------------------------------------------------
+// pack.py:38-46 for ray_indices grouped in ascending order: start[r] = first index with key >= r,
+// count[r] = start[r + 1] - start[r].  One binary search per ray; the next ray's start comes from
+// the neighbouring lane (lane 63 gallops forward from its own start instead: counts are small).
 __global__ __launch_bounds__(kBlock) void pack_info_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t n_rays,
                                                            int64_t *__restrict__ packed)
 {
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * kBlock) {
-        int64_t lo = 0, hi = n;                 // first index with key >= r
+    const int lane = lane_id();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r0 = (int64_t)blockIdx.x * kBlock; r0 < n_rays; r0 += stride) {
+        const int64_t r = r0 + threadIdx.x;
+        int64_t lo = 0, hi = n;                 // first index with key >= r  (n for r >= n_rays: the loop still converges)
         while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (keys[m] < r) lo = m + 1; else hi = m; }
         const int64_t first = lo;
-        hi = n;                                 // first index with key > r
-        while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (keys[m] <= r) lo = m + 1; else hi = m; }
-        packed[2 * r] = first;
-        packed[2 * r + 1] = lo - first;
+        int64_t next = lane_next_i64(first);
+        if (lane == 63) {                       // first index with key > r: gallop, then bisect the last gap
+            int64_t step = 1, a = first, b = first;
+            while (b < n && keys[b] <= r) { a = b + 1; b += step; step <<= 1; }
+            if (b > n) b = n;
+            while (a < b) { const int64_t m = a + ((b - a) >> 1); if (keys[m] <= r) a = m + 1; else b = m; }
+            next = a;
+        }
+        if (r < n_rays) {
+            packed[2 * r] = first;
+            packed[2 * r + 1] = next - first;
+        }
     }
 }
 
