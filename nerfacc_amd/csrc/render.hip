@@ -255,21 +255,43 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(
 #pragma unroll
     for (int c = 0; c < DC; ++c) carry[c] = 0.0f;
     int64_t edge_key = 0;
-    for (int64_t ch = 0; ch < n_chunks; ++ch) {
-        const int64_t i = tr.begin + ch * 64 + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0, nkey = -1;
-        float w = 0.0f;
-        if (active) { key = keys[i]; nkey = load_next_key(keys, i, tr.end, key); w = weights[i]; }
-        const SegFwd s = seg_fwd(key, active, ch == 0, edge_key, lane);
-        const bool tail = active && nkey != key;
-        edge_key = readlane_i64<63>(key);
+    // U chunks per trip, all their loads issued before the first scan: this kernel moves only
+    // 12 + 4 DC bytes per sample, and with one chunk in flight per wave the bytes in flight per CU
+    // (not the HBM) bounded it (Little's law)
+    constexpr int U = 3;
+    for (int64_t ch0 = 0; ch0 < n_chunks; ch0 += U) {
+        int64_t key[U], nkey[U];
+        float w[U], v[U][DC];
 #pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            float v = w;
-            if (values && active) v = w * values[i * D + c0 + c];
-            const float tot = seg_incl_fwd(v, s, carry[c]);
-            if (active && tail && key >= 0 && key < n_rays) unsafeAtomicAdd(out + key * D + c0 + c, tot);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = tr.begin + (ch0 + u) * 64 + lane;
+            key[u] = 0; nkey[u] = -1; w[u] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < DC; ++c) v[u][c] = 1.0f;
+            if (i < tr.end) {
+                key[u] = keys[i];
+                nkey[u] = load_next_key(keys, i, tr.end, key[u]);
+                w[u] = weights[i];
+                if (values) {
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) v[u][c] = values[i * D + c0 + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ch = ch0 + u;
+            if (ch >= n_chunks) break;
+            const int64_t i = tr.begin + ch * 64 + lane;
+            const bool active = i < tr.end;
+            const SegFwd s = seg_fwd(key[u], active, ch == 0, edge_key, lane);
+            const bool tail = active && nkey[u] != key[u];
+            edge_key = readlane_i64<63>(key[u]);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const float tot = seg_incl_fwd(w[u] * v[u][c], s, carry[c]);
+                if (active && tail && key[u] >= 0 && key[u] < n_rays) unsafeAtomicAdd(out + key[u] * D + c0 + c, tot);
+            }
         }
     }
 }
