@@ -201,31 +201,62 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     if (lane == 0) tile_cnts[w] = kept;
 }
 
-// 3) stream compaction with ballot ranks.  `tile_offs` = exclusive prefix of the tile counts, or —
-// fused form for up to kVisFusedTiles tiles (every training-size call) — the counts themselves:
-// each wave then sums the counts before its own (<= 64 L2 loads per lane) and the last one
-// stores the total, which saves the single-workgroup prefix-sum launch in between.
-constexpr int64_t kVisFusedTiles = 4096;
+// 2) (only beyond kVisFusedTiles tiles) one wave per group of 64 tiles: exclusive prefix of the
+// group's tile counts in place + the group total — thousands of independent waves instead of one
+// workgroup crawling through every count
+__global__ __launch_bounds__(kBlock) void visibility_group_scan_kernel(int64_t *__restrict__ tile_cnts, int64_t n_tiles,
+                                                                       int64_t *__restrict__ group_sums)
+{
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int64_t j = g * 64 + lane;
+    if (g * 64 >= n_tiles) return;
+    const int64_t v = j < n_tiles ? tile_cnts[j] : 0;
+    int64_t inc = v;                                  // inclusive scan over the wave (DPP, as wave_seg_scan_fwd)
+    { const int64_t u = dpp_i64<kDppRowShr + 1>(inc); if ((lane & 15) >= 1) inc += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 2>(inc); if ((lane & 15) >= 2) inc += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 4>(inc); if ((lane & 15) >= 4) inc += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 8>(inc); if ((lane & 15) >= 8) inc += u; }
+    { const int64_t u = dpp_i64<kDppRowBcast15>(inc); if (lane & 16) inc += u; }
+    { const int64_t u = dpp_i64<kDppRowBcast31>(inc); if (lane & 32) inc += u; }
+    if (j < n_tiles) tile_cnts[j] = inc - v;
+    if (lane == 63) group_sums[g] = inc;
+}
+
+// 3) stream compaction with ballot ranks.  Where a wave's survivors go:
+//   mode 0  tile_offs[w] is the global exclusive prefix (single-workgroup scan, huge inputs only)
+//   mode 1  fused form for up to kVisFusedTiles tiles (every training-size call): tile_offs holds the
+//           tile COUNTS and each wave sums the ones before its own (<= 64 L2 loads per lane)
+//   mode 2  tile_offs holds the prefix inside the wave's group of 64 tiles (kernel 2) and group_sums the
+//           group totals: the wave adds the totals of the groups before its own
+// The last wave stores the total in modes 1 and 2.
+constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, int fused, int64_t n_tiles,
-    int64_t *__restrict__ n_out, int64_t n, int64_t tile,
+    const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
+    int mode, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t n, int64_t tile,
     int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
     const int64_t w_ = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (w_ >= n_tiles) return;
     const int lane = lane_id();
+    const TileRange tr = snapped_tile(keys, n, w_, tile);
     int64_t dst;
-    if (fused) {
+    if (mode == 1) {
         int64_t p = 0;
         for (int64_t j = lane; j < w_; j += 64) p += tile_offs[j];
         dst = wave_sum_i64(p);
         if (w_ == n_tiles - 1 && lane == 0) *n_out = dst + tile_offs[w_];
+    } else if (mode == 2) {
+        const int64_t g = w_ >> 6;
+        int64_t p = 0;
+        for (int64_t j = lane; j < g; j += 64) p += group_sums[j];
+        dst = wave_sum_i64(p) + tile_offs[w_];
+        if (w_ == n_tiles - 1 && lane == 0) *n_out = dst - tile_offs[w_] + group_sums[g];
     } else {
         dst = tile_offs[w_];
     }
     if (!o_keys) return;
-    const TileRange tr = snapped_tile(keys, n, w_, tile);
     if (tr.begin >= tr.end) return;
     const int64_t n_chunks = (tr.end - tr.begin + 63) >> 6;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -538,13 +569,19 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
                        dens, from_alpha, n, tile, early_stop_eps, alpha_thre, mask, tile_cnts);
     if (int rc = check_launch("visibility_mask_kernel")) return rc;
     if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
-    const bool fused = T <= kVisFusedTiles;
-    if (!fused) {
+    const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
+    int64_t *group_sums = tile_offs;                       // (the second half of the workspace; T / 64 <= T entries)
+    if (mode == 2) {
+        const int64_t groups = ceil_div(T, 64);
+        hipLaunchKernelGGL(visibility_group_scan_kernel, dim3((unsigned)ceil_div(groups, kWavesPerBlock)), dim3(kBlock), 0, s,
+                           tile_cnts, T, group_sums);
+        if (int rc = check_launch("visibility_group_scan_kernel")) return rc;
+    } else if (mode == 0) {
         if (int rc = nfa_exclusive_sum_i64(tile_cnts, T, tile_offs, n_out, stream)) return rc;
         if (!out_ray_indices) return NFA_OK;
     }
     hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       mask, fused ? tile_cnts : tile_offs, fused ? 1 : 0, T, n_out, n, tile,
+                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, mode, T, n_out, n, tile,
                        out_ray_indices, out_t_starts, out_t_ends);
     return check_launch("visibility_compact_kernel");
 }

@@ -270,3 +270,27 @@ def test_accumulate_unsorted_ray_indices_like_index_add():
         out = accumulate_along_rays(t(w_), t(v_), t(ri_), R)
         ref = torch.zeros(R, 3, device=DEV).index_add_(0, t(ri_), t(w_)[:, None] * t(v_))
         assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_rays", [50, 5000, 60000])
+def test_visibility_compact_all_prefix_modes(n_rays):
+    """the compaction's three ways of finding a tile's output offset (fused for <= 4096 tiles, grouped
+    prefix beyond) must give exactly the boolean-mask gather of the inputs, and the mask must follow
+    T >= eps & alpha >= thre"""
+    from nerfacc_amd import cuda as C
+
+    torch.manual_seed(n_rays)
+    cnts = torch.randint(0, 120, (n_rays,), device=DEV)
+    ri = torch.repeat_interleave(torch.arange(n_rays, device=DEV), cnts)
+    N = ri.shape[0]
+    ts = torch.rand(N, device=DEV) * 4
+    te = ts + 5e-3
+    sig = torch.rand(N, device=DEV) * 60
+    o_ri, o_ts, o_te, mask = C.visibility_compact(ri, ts, te, sig, False, 1e-2, 0.05, True)
+    assert mask.dtype == torch.bool and 0 < int(mask.sum()) < N
+    assert torch.equal(o_ri, ri[mask]) and torch.equal(o_ts, ts[mask]) and torch.equal(o_te, te[mask])
+    # the rule itself, away from the thresholds
+    w, T, a = C.render_weight_from_density_fwd(ri, ts, te, sig, None)
+    want = (T >= 1e-2) & (a >= 0.05)
+    near = ((T - 1e-2).abs() < 1e-6) | ((a - 0.05).abs() < 1e-6)
+    assert torch.equal(mask[~near], want[~near])

@@ -68,6 +68,7 @@ bench("rendering_bwd_kernel", 60 * N + 20 * R,
 bench("accumulate_kernel<3>", 24 * N + 12 * R, lambda: C.accumulate_along_rays(ri, w, rgb, R))
 bench("accumulate_kernel<1> (values=None)", 12 * N + 4 * R, lambda: C.accumulate_along_rays(ri, w, None, R))
 bench("scan_keyed_kernel (exclusive sum)", 16 * N, lambda: C.exclusive_sum_cub(ri, x, False))
+bench("scan_keyed_kernel (exclusive sum, reverse walk)", 16 * N, lambda: C.exclusive_sum_cub(ri, x, True))
 bench("scan_packed_kernel (exclusive sum)", 8 * N + 16 * R, lambda: C.exclusive_sum(pk[:, 0].contiguous(), pk[:, 1].contiguous(), x, False, False))
 bench("visibility mask+scan+compact", 37 * N, lambda: C.visibility_compact(ri, ts, te, sig * 0.01, False, 1e-4, 0.0))
 bench("pack_info_kernel", 16 * R, lambda: C.pack_info(ri, R))
