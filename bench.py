@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=1 << 21)
+    ap.add_argument("--occ-res", type=int, default=GRID_RES,
+                    help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,7 +256,7 @@ def main():
     torch.manual_seed(42)
     field = DenseGridField(AABB, GRID_RES).to(device)
     teacher = DenseGridField(AABB, GRID_RES).to(device).eval()
-    est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=GRID_RES, levels=1).to(device)
+    est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
     optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
     loss_scale = 2.0**10
     bkgd = torch.ones(3, device=device)
@@ -351,7 +353,7 @@ def main():
         with torch.no_grad():
             idx = torch.randint(0, args.pool, (int(rays_per_launch),), device=device)
             cand = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
-        alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + GRID_RES**3 / 8
+        alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + args.occ_res**3 / 8
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out = {
             "metric": "training rays/sec (+ samples/sec), NGP+OccGrid Lego 800x800",
@@ -363,7 +365,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "configs[1] lego stand-in: procedural lego-like scene, 100 cams 800x800, 128^3 OccGrid on aabb +-1.5, "
+                "workload": f"configs[1] lego stand-in: procedural lego-like scene, 100 cams 800x800, {args.occ_res}^3 OccGrid on aabb +-1.5, "
                             "render_step 5e-3, ~2^18 rendered samples/iter/GPU, torch dense-grid field (tiny-cuda-nn absent)",
                 "rays_per_iter_per_gpu": rays_per_launch,
                 "samples_per_iter_per_gpu": stats["samples"] / max(args.steps, 1),
