@@ -264,28 +264,52 @@ def _read_ints(buf: torch.Tensor, device: torch.device):
 # --------------------------------------------------------------------------------------
 # occupancy bricks: packed once per distinct `binaries` tensor state
 # --------------------------------------------------------------------------------------
-_brick_cache = {"ref": None, "version": None, "bricks": None, "nonempty": -1}
+_BRICK_CACHE_SLOTS = 4
+_brick_cache: List[dict] = []      # most recently used first: {"ref", "version", "bricks", "nonempty"}
 
 
-def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
-    """bool [G, rx, ry, rz] -> uint64-as-int64 bricks (nfa_pack_binaries), memoised on the
-    tensor object + its in-place version counter so that a grid that has not changed since
-    the last call is not repacked (OccGridEstimator changes it every 16 steps)."""
+def _brick_entry(binaries: torch.Tensor) -> dict:
+    """cache entry of `binaries` (packing it if its state is new).  A few slots, so that a training
+    and an evaluation estimator — or a teacher and a student — used in turn do not repack (and
+    re-read the non-empty count) on every call."""
     _check_input(binaries, "binaries", torch.bool)
     if binaries.dim() != 4:
         raise RuntimeError("binaries must have shape [n_grids, resx, resy, resz]")
-    c = _brick_cache
-    if c["ref"] is not None and c["ref"]() is binaries and c["version"] == binaries._version:
-        return c["bricks"]
-    c["nonempty"] = -1
+    for k, c in enumerate(_brick_cache):
+        if c["ref"]() is binaries and c["version"] == binaries._version:
+            if k:
+                _brick_cache.insert(0, _brick_cache.pop(k))
+            return c
     L = load_library()
     G, rx, ry, rz = binaries.shape
     words = L.nfa_packed_grid_words(G, rx, ry, rz)
     bricks = torch.empty(words, dtype=torch.int64, device=binaries.device)
     with _Guard(binaries):
         _check(L.nfa_pack_binaries(_ptr(binaries), G, rx, ry, rz, _ptr(bricks), _stream(binaries)))
-    c["ref"], c["version"], c["bricks"] = weakref.ref(binaries), binaries._version, bricks
-    return bricks
+    # drop slots whose tensor is gone or has changed, then the oldest
+    _brick_cache[:] = [c for c in _brick_cache if c["ref"]() is not None and not (c["ref"]() is binaries)]
+    entry = {"ref": weakref.ref(binaries), "version": binaries._version, "bricks": bricks, "nonempty": -1}
+    _brick_cache.insert(0, entry)
+    del _brick_cache[_BRICK_CACHE_SLOTS:]
+    return entry
+
+
+def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
+    """bool [G, rx, ry, rz] -> uint64-as-int64 bricks (nfa_pack_binaries), memoised on the
+    tensor object + its in-place version counter so that a grid that has not changed since
+    the last call is not repacked (OccGridEstimator changes it every 16 steps)."""
+    return _brick_entry(binaries)["bricks"]
+
+
+def _nonempty_bricks(binaries: torch.Tensor) -> int:
+    """number of non-empty bricks of the packed grid: one readback per grid state (every 16 training
+    steps); lets the kernels size their LDS occupancy image to the grid instead of to the worst case"""
+    c = _brick_entry(binaries)
+    if c["nonempty"] < 0:
+        G = binaries.shape[0]
+        n_bricks = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
+        c["nonempty"] = int(c["bricks"][n_bricks].item())
+    return c["nonempty"]
 
 
 def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits,
@@ -311,17 +335,8 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
         a.rays_mask = _ptr(rays_mask)
     a.n_grids = G
     a.res[0], a.res[1], a.res[2] = binaries.shape[1], binaries.shape[2], binaries.shape[3]
-    bricks = packed_bricks(binaries)
-    a.bricks = _ptr(bricks)
-    if _brick_cache["bricks"] is bricks:
-        if _brick_cache["nonempty"] < 0:
-            # one readback per grid update (every 16 training steps): lets the kernels size their
-            # LDS occupancy image to the grid instead of to the worst case
-            n_bricks = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
-            _brick_cache["nonempty"] = int(bricks[n_bricks].item())
-        a.n_nonempty_bricks = _brick_cache["nonempty"]
-    else:
-        a.n_nonempty_bricks = -1
+    a.bricks = _ptr(packed_bricks(binaries))
+    a.n_nonempty_bricks = _nonempty_bricks(binaries)
     a.aabbs = _ptr(aabbs)
     if t_sorted is not None:
         _check_input(t_sorted, "t_sorted", torch.float32)
