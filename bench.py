@@ -286,6 +286,11 @@ def main():
 
     def train_step():
         step = state["step"]
+        if state.get("counts") is not None:
+            g_samples, g_rays = sharding.allreduce_counts_end(state["counts"])
+            if g_samples > 0:
+                # train_ngp_nerf_occ.py:187-194, on the global counts so all ranks stay in step
+                state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
         n = state["num_rays"]
         idx = torch.randint(0, args.pool, (n,), device=device)
         rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
@@ -293,10 +298,8 @@ def main():
             with sharding.synchronized_rng(5000 + step, device):
                 est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
         rgb, acc, depth, n_samples = render_rays(field, est, rays_o, rays_d, bkgd, True)
-        g_samples, g_rays = sharding.allreduce_counts(n_samples, n, device)
-        if g_samples > 0:
-            # train_ngp_nerf_occ.py:187-194, on the global counts so all ranks stay in step
-            state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
+        # global (samples, rays) of this step: started here, read at the top of the next step
+        state["counts"] = sharding.allreduce_counts_begin(n_samples, n, device)
         optimizer.zero_grad()
         if n_samples > 0:
             loss = F.smooth_l1_loss(rgb, pixels)

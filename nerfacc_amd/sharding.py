@@ -77,6 +77,34 @@ def allreduce_counts(n_samples: int, n_rays: int, device) -> Tuple[int, int]:
     return s, r
 
 
+class _PendingCounts:
+    __slots__ = ("buf", "work", "local")
+
+    def __init__(self, buf, work, local):
+        self.buf, self.work, self.local = buf, work, local
+
+
+def allreduce_counts_begin(n_samples: int, n_rays: int, device) -> "_PendingCounts":
+    """start the 16-byte all-reduce of this step's (samples, rays) without waiting for it.  Pair with
+    `allreduce_counts_end` at the start of the next step: the host then blocks once — where it would
+    wait for the previous step's GPU work anyway — instead of once more in the middle of the step."""
+    rank, ws = world()
+    if ws == 1:
+        return _PendingCounts(None, None, (int(n_samples), int(n_rays)))
+    buf = torch.tensor([int(n_samples), int(n_rays)], dtype=torch.int64, device=device)
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+    return _PendingCounts(buf, work, None)
+
+
+def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
+    """global (samples, rays) of the step `pending` was started in."""
+    if pending.work is None:
+        return pending.local
+    pending.work.wait()
+    s, r = pending.buf.tolist()
+    return s, r
+
+
 def broadcast_grid(estimator, src: int = 0) -> None:
     """make `occs` and `binaries` of an OccGridEstimator identical to rank `src`'s."""
     rank, ws = world()

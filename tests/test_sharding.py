@@ -46,6 +46,8 @@ def _worker(rank, world, port, out_dir):
         sharding.allreduce_gradients([single])
         # --- counts
         s, r = sharding.allreduce_counts(1000 + rank, e - b, "cpu")
+        pend = sharding.allreduce_counts_begin(10 + rank, 3, "cpu")      # deferred form: begin now, read next step
+        assert sharding.allreduce_counts_end(pend) == (21, 6)
         # --- grid agreement: independent RNG diverges, synchronized_rng / broadcast agree
         from nerfacc_amd import OccGridEstimator
 
@@ -92,6 +94,11 @@ def test_shard_bounds_cover_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_deferred_counts_single_process():
+    pend = sharding.allreduce_counts_begin(5, 7, "cpu")
+    assert sharding.allreduce_counts_end(pend) == (5, 7)
 
 
 def test_single_process_is_a_noop():
