@@ -19,6 +19,11 @@ rays/iter adapted so that ~2^18 samples are rendered per iteration
 smooth-L1 loss.  A step = update_every_n_steps + sampling (traversal, sigma_fn, visibility
 filter) + rendering forward + backward + optimizer step.
 
+Issue order: the traversal of a step's rays depends on the occupancy grid but not on the field's
+parameters, so the NEXT step's rays are drawn and traversed on a side HIP stream right after this
+step's backward pass has been queued (it overlaps with the backward kernels; `--no-overlap` keeps
+everything on one stream in program order).  The work per step is the same either way.
+
 Multi-GPU: each rank draws its own rays (weak scaling: per-GPU work is fixed),
 one flat all-reduce of the field gradients + one 16-byte all-reduce of the step's counts.
 """
@@ -127,13 +132,13 @@ def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
     def sigma_fn(t_starts, t_ends, ray_indices):
         if t_starts.shape[0] == 0:
             return torch.empty((0,), device=t_starts.device)
-        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+        pos = nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
         return field.query_density(pos).squeeze(-1)
 
     def rgb_sigma_fn(t_starts, t_ends, ray_indices):
         if t_starts.shape[0] == 0:
             return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
-        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+        pos = nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
         rgb, sigma = field(pos)            # (this stand-in field has no view dependence)
         return rgb, sigma.squeeze(-1)
 
@@ -240,6 +245,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=1 << 21)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="issue the next step's ray traversal after the optimizer on the main stream instead of "
+                         "on a side stream concurrently with the backward pass")
     ap.add_argument("--occ-res", type=int, default=GRID_RES,
                     help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
     args = ap.parse_args()
@@ -284,31 +292,77 @@ def main():
     state = {"num_rays": INIT_RAYS, "step": 1024}
     stats = {"rays": 0, "samples": 0, "candidates": 0}
 
+    # The traversal of a step (rays -> candidate samples) does not depend on the field's parameters, only
+    # on the occupancy grid.  So the NEXT step's rays are drawn and traversed on a side stream right
+    # after this step's backward pass has been queued: the count kernel and its host read-back (the
+    # first of the two host syncs of a step) overlap with the backward kernels instead of waiting
+    # behind them, and the host can queue the sigma_fn / filter launches while the GPU is still busy.
+    # Steps that refresh the grid (every 16th) traverse after the refresh, on the main stream's heels.
+    side = torch.cuda.Stream(device=device)
+    overlap = not args.no_overlap
+
+    def propose(n, wait_for_main):
+        main = torch.cuda.current_stream(device)
+        if wait_for_main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            idx = torch.randint(0, args.pool, (n,), device=device)
+            rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
+            near = torch.rand(n, device=device) * RENDER_STEP          # near_plane 0 + stratified jitter (occ_grid.py:162-163)
+            far = torch.full((n,), 1e10, device=device)
+            ri, ts, te, _ = nerfacc.cuda.sample_occgrid(rays_o, rays_d, est.binaries, est.aabbs, near, far, RENDER_STEP, 0.0)
+        return dict(n=n, rays_o=rays_o, rays_d=rays_d, pixels=pixels, ri=ri, ts=ts, te=te)
+
+    def render_proposed(prop):
+        """the rest of OccGridEstimator.sampling (visibility filter, occ_grid.py:180-220) + rendering, on the main stream"""
+        main = torch.cuda.current_stream(device)
+        main.wait_stream(side)
+        for t in prop.values():
+            if torch.is_tensor(t):
+                t.record_stream(main)
+        rays_o, rays_d, ri, ts, te = prop["rays_o"], prop["rays_d"], prop["ri"], prop["ts"], prop["te"]
+        if ts.shape[0] > 0:
+            with torch.no_grad():
+                sig = field.query_density(nerfacc.sample_positions(rays_o, rays_d, ri, ts, te)).squeeze(-1)
+            ri, ts, te, _ = nerfacc.cuda.visibility_compact(ri, ts, te, sig.contiguous(), False, 1e-4, 0.0)
+
+        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            if t_starts.shape[0] == 0:
+                return torch.empty((0, 3), device=device), torch.empty((0,), device=device)
+            rgb, sigma = field(nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends))
+            return rgb, sigma.squeeze(-1)
+
+        rgb, opacity, depth, _ = nerfacc.rendering(ts, te, ri, n_rays=prop["n"], rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
+        return rgb, ts.shape[0]
+
     def train_step():
         step = state["step"]
-        if state.get("counts") is not None:
-            g_samples, g_rays = sharding.allreduce_counts_end(state["counts"])
-            if g_samples > 0:
-                # train_ngp_nerf_occ.py:187-194, on the global counts so all ranks stay in step
-                state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
-        n = state["num_rays"]
-        idx = torch.randint(0, args.pool, (n,), device=device)
-        rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
-        if step % 16 == 0:
+        refresh = step % 16 == 0
+        if refresh:
             with sharding.synchronized_rng(5000 + step, device):
                 est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
-        rgb, acc, depth, n_samples = render_rays(field, est, rays_o, rays_d, bkgd, True)
-        # global (samples, rays) of this step: started here, read at the top of the next step
-        state["counts"] = sharding.allreduce_counts_begin(n_samples, n, device)
+        prop = state.pop("proposal", None)
+        if prop is None:
+            prop = propose(state["num_rays"], wait_for_main=True)
+        n = prop["n"]
+        rgb, n_samples = render_proposed(prop)
+        # global (samples, rays) of this step, so that all ranks stay in step (train_ngp_nerf_occ.py:187-194)
+        pending = sharding.allreduce_counts_begin(n_samples, n, device)
         optimizer.zero_grad()
         if n_samples > 0:
-            loss = F.smooth_l1_loss(rgb, pixels)
+            loss = F.smooth_l1_loss(rgb, prop["pixels"])
             (loss * loss_scale).backward()
         # every rank takes part in the exchange every step, samples or not (a rank that skipped
         # the collective would deadlock the others); missing grads count as zeros
         sharding.allreduce_gradients(field.parameters())
         if n_samples > 0 or world_size > 1:
             optimizer.step()
+        with torch.cuda.stream(side):                 # the 16-byte result is read without waiting for the backward pass
+            g_samples, g_rays = sharding.allreduce_counts_end(pending)
+        if g_samples > 0:
+            state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
+        if overlap and (step + 1) % 16 != 0:
+            state["proposal"] = propose(state["num_rays"], wait_for_main=False)
         stats["rays"] += n
         stats["samples"] += n_samples
         state["step"] += 1

@@ -204,6 +204,14 @@ int nfa_render_weight_from_density_bwd(const int64_t *ray_indices, const float *
                                        const float *g_trans, const float *g_alphas, int64_t n,
                                        float *g_sigmas, void *stream);
 
+/* Sample midpoints in world space, positions[i] = rays_o[r_i] + rays_d[r_i] * ((t_starts[i] + t_ends[i]) / 2)
+ * with r_i = ray_indices[i]: what the reference's examples compute with six torch ops at the top of
+ * every sigma_fn / rgb_sigma_fn (examples/utils.py:96-101, 105-118).  Same float operation order
+ * as that expression.  dirs (nullable, [n,3]) receives rays_d[r_i]. */
+int nfa_sample_positions(const float *rays_o, const float *rays_d, int64_t n_rays,
+                         const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                         float *positions, float *dirs, void *stream);
+
 /* render_visibility_from_density + the three mask compactions of OccGridEstimator.sampling
  * (occ_grid.py:194-220, volrend.py:435-494) in one go: keep sample i iff
  * trans_i >= early_stop_eps and (alpha_thre <= 0 or alpha_i >= alpha_thre).

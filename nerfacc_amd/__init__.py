@@ -9,7 +9,7 @@ include/nerfacc_hip.h), built by `python -m nerfacc_amd.build`.
 from .data_specs import RayIntervals, RaySamples
 from .estimators.occ_grid import OccGridEstimator
 from .estimators.prop_net import PropNetEstimator
-from .grid import ray_aabb_intersect, traverse_grids
+from .grid import ray_aabb_intersect, sample_positions, traverse_grids
 from .losses import distortion
 from .pack import pack_info
 from .pdf import importance_sampling, searchsorted
@@ -40,3 +40,5 @@ __all__ = [
     "OccGridEstimator", "PropNetEstimator",
     "distortion",
 ]
+# additions of this implementation (not in the reference's list of 24 names)
+__all__ += ["sample_positions"]

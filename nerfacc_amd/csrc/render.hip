@@ -507,6 +507,29 @@ __global__ __launch_bounds__(kBlock) void unpack_info_kernel(const int64_t *__re
     }
 }
 
+// sample midpoints in world space: p_i = o[r_i] + d[r_i] * ((t0_i + t1_i) / 2) — the line every
+// rgb_sigma_fn / sigma_fn of the reference's examples starts with (examples/utils.py:96-101), six
+// ATen launches there.  One lane per output float (coalesced [N,3] stores); same operation order as
+// the torch expression, no contraction: bit-identical.  `dirs` (nullable) = d[r_i], the view
+// directions handed to the field.
+__global__ __launch_bounds__(kBlock) void sample_positions_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays,
+    const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te, int64_t n,
+    float *__restrict__ positions, float *__restrict__ dirs)
+{
+    const int64_t total = 3 * n;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < total; k += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = k / 3;
+        const int c = (int)(k - 3 * i);
+        const int64_t r = keys[i];
+        float o = 0.0f, d = 0.0f;
+        if (r >= 0 && r < n_rays) { o = rays_o[3 * r + c]; d = rays_d[3 * r + c]; }
+        const float mid = (ts[i] + te[i]) / 2.0f;
+        positions[k] = o + d * mid;
+        if (dirs) dirs[k] = d;
+    }
+}
+
 inline unsigned tile_blocks(int64_t n, int64_t tile) { return (unsigned)ceil_div(ceil_div(n, tile), kWavesPerBlock); }
 
 }  // namespace
@@ -681,4 +704,16 @@ NFA_EXPORT int nfa_unpack_info(const int64_t *chunk_starts, const int64_t *chunk
     NFA_REQUIRE(chunk_starts && chunk_cnts, "unpack_info: NULL pointer");
     hipLaunchKernelGGL(unpack_info_kernel, dim3(blocks_for(n_rays * 16)), dim3(kBlock), 0, s, chunk_starts, chunk_cnts, n_rays, n, ray_indices);
     return check_launch("unpack_info_kernel");
+}
+
+NFA_EXPORT int nfa_sample_positions(const float *rays_o, const float *rays_d, int64_t n_rays,
+                                    const int64_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                                    float *positions, float *dirs, void *stream)
+{
+    NFA_REQUIRE(n >= 0 && n_rays >= 0, "sample_positions: negative size");
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && positions, "sample_positions: NULL pointer");
+    hipLaunchKernelGGL(sample_positions_kernel, dim3(blocks_for(3 * n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       rays_o, rays_d, n_rays, ray_indices, t_starts, t_ends, n, positions, dirs);
+    return check_launch("sample_positions_kernel");
 }

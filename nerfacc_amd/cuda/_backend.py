@@ -79,6 +79,7 @@ _SIGNATURES = {
     "nfa_prod_backward": (ctypes.c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P]),
     "nfa_render_weight_from_density_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "nfa_render_weight_from_density_bwd": (ctypes.c_int, [_P] * 9 + [c_int64, _P, _P]),
+    "nfa_sample_positions": (ctypes.c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
     "nfa_visibility_workspace_bytes": (c_int64, [c_int64]),
     "nfa_visibility_compact": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "nfa_accumulate_along_rays": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P]),
@@ -694,6 +695,25 @@ class _C:
                 _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(trans), _ptr(alphas),
                 _ptr(g_w), _ptr(g_T), _ptr(g_a), n, _ptr(g), _stream(sigmas)))
         return g
+
+    @staticmethod
+    def sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, with_dirs: bool = False):
+        """positions [N,3] = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2)
+        in one launch (bit-identical to that torch expression); with_dirs also returns rays_d[ray_indices]."""
+        _check_input(rays_o, "rays_o", torch.float32)
+        _check_input(rays_d, "rays_d", torch.float32)
+        _check_input(ray_indices, "ray_indices", torch.int64)
+        _check_input(t_starts, "t_starts", torch.float32)
+        _check_input(t_ends, "t_ends", torch.float32)
+        n = ray_indices.shape[0]
+        if t_starts.shape[0] != n or t_ends.shape[0] != n or rays_o.shape != rays_d.shape or rays_o.dim() != 2 or rays_o.shape[1] != 3:
+            raise RuntimeError("sample_positions: rays [R,3] x2 and ray_indices / t_starts / t_ends [N] expected")
+        pos = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device)
+        dirs = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device) if with_dirs else None
+        with _Guard(rays_o):
+            _check(load_library().nfa_sample_positions(_ptr(rays_o), _ptr(rays_d), rays_o.shape[0], _ptr(ray_indices),
+                                                       _ptr(t_starts), _ptr(t_ends), n, _ptr(pos), _ptr(dirs), _stream(rays_o)))
+        return (pos, dirs) if with_dirs else pos
 
     @staticmethod
     def visibility_compact(ray_indices, t_starts, t_ends, dens, from_alpha: bool, early_stop_eps: float,

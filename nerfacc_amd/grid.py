@@ -107,3 +107,23 @@ def _query(x: Tensor, data: Tensor, base_aabb: Tensor) -> Tuple[Tensor, Tensor]:
     idx = torch.minimum((unit_lvl * res).long(), res - 1)
     mip = mip.clamp(max=data.shape[0] - 1)
     return data[mip, idx[:, 0], idx[:, 1], idx[:, 2]] * inside, inside
+
+
+def sample_positions(rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
+                     return_dirs: bool = False):
+    """World-space midpoints of flattened samples (an addition of this implementation):
+
+        positions = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2)
+
+    the first line of every `sigma_fn` / `rgb_sigma_fn` in the reference's examples
+    (examples/utils.py:96-101), as one launch instead of six, bit-identical to the expression.
+    `return_dirs` also returns `rays_d[ray_indices]`.  If an input requires grad (pose or ray
+    optimisation) the torch expression itself is evaluated so that autograd sees it.
+    """
+    needs_grad = torch.is_grad_enabled() and any(x.requires_grad for x in (rays_o, rays_d, t_starts, t_ends))
+    if needs_grad:
+        dirs = rays_d[ray_indices]
+        pos = rays_o[ray_indices] + dirs * ((t_starts + t_ends)[:, None] / 2.0)
+        return (pos, dirs) if return_dirs else pos
+    return _C.sample_positions(rays_o.contiguous(), rays_d.contiguous(), ray_indices.contiguous(),
+                               t_starts.contiguous(), t_ends.contiguous(), return_dirs)

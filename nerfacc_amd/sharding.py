@@ -100,7 +100,9 @@ def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
     """global (samples, rays) of the step `pending` was started in."""
     if pending.work is None:
         return pending.local
-    pending.work.wait()
+    pending.work.wait()              # the CURRENT stream waits for the collective (it may be a side stream)
+    if pending.buf.is_cuda:
+        pending.buf.record_stream(torch.cuda.current_stream(pending.buf.device))
     s, r = pending.buf.tolist()
     return s, r
 

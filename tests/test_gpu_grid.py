@@ -186,3 +186,26 @@ def test_sampling_many_rays_serial_and_split_walks_agree():
         r_ri, r_ts, r_te, r_pk = oracle.sampling(o, d, occ, aabb, render_step_size=5e-3)
         assert np.array_equal(n(ri), r_ri) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
         assert np.array_equal(n(pk), r_pk)
+
+
+def test_sample_positions_bit_identical_to_the_torch_expression():
+    import nerfacc_amd as nerfacc
+
+    torch.manual_seed(3)
+    R, N = 777, 50000
+    o = torch.randn(R, 3, device="cuda:0")
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda:0"), dim=-1)
+    ri = torch.sort(torch.randint(0, R, (N,), device="cuda:0"))[0]
+    ts = torch.rand(N, device="cuda:0") * 5
+    te = ts + torch.rand(N, device="cuda:0") * 0.01
+    want_d = d[ri]
+    want = o[ri] + want_d * ((ts + te)[:, None] / 2.0)
+    pos, dirs = nerfacc.sample_positions(o, d, ri, ts, te, return_dirs=True)
+    assert torch.equal(pos, want) and torch.equal(dirs, want_d)
+    assert torch.equal(nerfacc.sample_positions(o, d, ri, ts, te), want)
+    # rays that require grad go through the torch expression (autograd sees it)
+    o2 = o.clone().requires_grad_(True)
+    p2 = nerfacc.sample_positions(o2, d, ri, ts, te)
+    p2.sum().backward()
+    assert torch.equal(p2.detach(), want) and o2.grad is not None and float(o2.grad.sum()) == float(N * 3)
+    assert nerfacc.sample_positions(o, d, ri[:0], ts[:0], te[:0]).shape == (0, 3)
