@@ -1,0 +1,74 @@
+// Host-execution shim for the reference's CUDA sources (TEST INFRASTRUCTURE, never shipped).
+//
+// Force-included (g++ -include) in front of /root/reference/nerfacc/cuda/csrc/grid.cu so that the
+// reference's own kernel and host wrapper compile as plain C++ against libtorch CPU tensors and run
+// one "thread" after another.  Nothing in here restates the reference's algorithm: it only supplies
+// what nvcc/cuda_runtime.h would (vector types, execution-space keywords, launch geometry).
+#pragma once
+#include <torch/extension.h>
+
+#include <cmath>
+#include <cstdint>
+
+// --- execution-space keywords -------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+
+// --- vector types of cuda_runtime.h (only the members helper_math uses) --------------------------
+#define REF_VEC2(T, N) struct N { T x, y; }; static inline N make_##N(T x, T y) { return N{x, y}; }
+#define REF_VEC3(T, N) struct N { T x, y, z; }; static inline N make_##N(T x, T y, T z) { return N{x, y, z}; }
+#define REF_VEC4(T, N) struct N { T x, y, z, w; }; static inline N make_##N(T x, T y, T z, T w) { return N{x, y, z, w}; }
+REF_VEC2(float, float2) REF_VEC3(float, float3) REF_VEC4(float, float4)
+REF_VEC2(int, int2) REF_VEC3(int, int3) REF_VEC4(int, int4)
+REF_VEC2(unsigned, uint2) REF_VEC3(unsigned, uint3) REF_VEC4(unsigned, uint4)
+
+// CUDA's math overloads for float (cuda_runtime.h / math_functions.hpp): min/max(float, float) are
+// fminf/fmaxf.  Without them `min(tdist.x, ...)` (grid.cu:185) would pick helper_math's int overload.
+static inline float min(float a, float b) { return std::fmin(a, b); }
+static inline float max(float a, float b) { return std::fmax(a, b); }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// launch geometry seen by the "kernel" while it runs on the host
+static thread_local dim3 gridDim, blockDim;
+static thread_local uint3 blockIdx, threadIdx;
+
+// kernel<<<grid, block, shmem, stream>>>(args...) is rewritten by the recipe (sed, in the pipe feeding
+// the compiler; no copy of the source is written anywhere) into REF_LAUNCH(kernel, grid, block, shmem,
+// stream)(args...): every (block, thread) pair runs to completion in order.  Valid for kernels without
+// __syncthreads / shared memory, which is the case for everything in grid.cu.
+template <class K> struct RefLauncher {
+    K k;
+    dim3 g, b;
+    template <class... A> void operator()(A... a) const {
+        gridDim = g;
+        blockDim = b;
+        for (unsigned bx = 0; bx < g.x; ++bx)
+            for (unsigned tx = 0; tx < b.x; ++tx) {
+                blockIdx = uint3{bx, 0, 0};
+                threadIdx = uint3{tx, 0, 0};
+                k(a...);
+            }
+    }
+};
+template <class K, class S0, class S1> static inline RefLauncher<K> ref_launch(K k, dim3 g, dim3 b, S0, S1) {
+    return RefLauncher<K>{k, g, b};
+}
+#define REF_LAUNCH(kernel, ...) ref_launch(kernel, __VA_ARGS__)
+
+// --- the two pieces of at::cuda the host wrappers touch ---------------------------------------------
+namespace at { namespace cuda {
+struct CUDAStream {};
+static inline CUDAStream getCurrentCUDAStream() { return CUDAStream{}; }
+struct OptionalCUDAGuard {
+    template <class T> explicit OptionalCUDAGuard(T&&) {}
+};
+}}  // namespace at::cuda

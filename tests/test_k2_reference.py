@@ -1,0 +1,141 @@
+"""K2 (traverse_grids) exact sample lists pinned by the REFERENCE'S OWN CODE.
+
+tests/golden/k2_reference.npz was produced by /root/reference/nerfacc/cuda/csrc/grid.cu compiled for the
+host (oracle/ref_shim/Makefile -> oracle/_ref/) and driven through the reference's Python layer
+(tests/golden/make_k2_golden.py).  Here:
+  * CPU (-m "not gpu"): the restated oracle must reproduce the fixture bit for bit — counts, pack offsets,
+    ray_indices, flags AND the float edges / midpoints / terminate planes;
+  * GPU (-m gpu): the HIP kernels, through the public API and the C ABI, must reproduce it too;
+  * where oracle/_ref is present (the build container), the reference build itself is re-run against the
+    fixture, so a stale fixture cannot go unnoticed.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import k2_cases as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def k2():
+    return dict(np.load(os.path.join(GOLD, "k2_reference.npz")))
+
+
+def _inputs(name, k2):
+    c = K.build_case(name, k2)
+    assert K.input_digest(c) == str(k2[f"{name}/input_sha"]), f"{name}: regenerated inputs differ from the fixture's"
+    return c
+
+
+def _live(c):
+    return c["extra"].get("rays_mask") if c["kw"].get("over_allocate") else None
+
+
+@pytest.mark.parametrize("name", K.ALL)
+def test_oracle_reproduces_reference_k2(name, k2):
+    import oracle
+
+    c = _inputs(name, k2)
+    iv, sm, term = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], **c["extra"], **c["kw"])
+    n = K.check_against_fixture(name, K.pack_outputs(iv, sm, term, _live(c)), k2)
+    assert n > 1000
+
+
+def test_sensitivity_report_matches_fixture(k2):
+    """the FMA-model numbers quoted in DESIGN.md §3.4 come from this file"""
+    rep = json.load(open(os.path.join(GOLD, "k2_sensitivity.json")))
+    assert sorted(rep) == sorted(K.ALL)
+    for name, r in rep.items():
+        assert r["fixture_build"] == "fma"
+        assert r["rays_differing_oracle_vs_fma"] == 0, name
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/nerfacc") and os.path.isdir(os.path.join(ROOT, "oracle", "_ref"))
+                         and any(f.startswith("nerfacc_ref_fma") for f in os.listdir(os.path.join(ROOT, "oracle", "_ref")))),
+                    reason="oracle/_ref (host build of the reference) only exists in the build container")
+@pytest.mark.parametrize("name", ["ref_test_grid", "m1_sphere", "per_voxel", "over_allocate"])
+def test_reference_build_reproduces_fixture(name, k2):
+    """re-runs the reference's compiled traverse_grids (C++ host wrapper, no Python layer of the reference, which
+    cannot be imported next to this repo's `nerfacc` alias) and compares with the committed fixture"""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    try:
+        ref = importlib.import_module("nerfacc_ref_fma")
+    finally:
+        sys.path.pop(0)
+    c = _inputs(name, k2)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    o, d = tt(c["rays_o"]), tt(c["rays_d"])
+    R = o.shape[0]
+    tmin, tmax, hits = ref.ray_aabb_intersect(o, d, tt(c["aabbs"]), -float("inf"), float("inf"), float("inf"))
+    ts, ti = torch.sort(torch.cat([tmin, tmax], -1), -1)            # grid.py:156-162
+    ex, kw = c["extra"], c["kw"]
+    mask = tt(ex["rays_mask"]) if "rays_mask" in ex else torch.ones(R, dtype=torch.bool)
+    near = tt(ex["near_planes"]) if "near_planes" in ex else torch.zeros(R)
+    far = tt(ex["far_planes"]) if "far_planes" in ex else torch.full((R,), float("inf"))
+    iv, sm, term = ref.traverse_grids(o, d, mask, tt(c["binaries"]), tt(c["aabbs"]), ts, ti, hits, near, far,
+                                      kw.get("step_size", 1e-3), kw.get("cone_angle", 0.0), True, True, True,
+                                      kw.get("traverse_steps_limit", -1), kw.get("over_allocate", False))
+    m = lambda s, keys: {k: getattr(s, k).numpy() for k in keys}
+    out = K.pack_outputs(m(iv, ("vals", "ray_indices", "is_left", "is_right", "chunk_starts", "chunk_cnts")),
+                         m(sm, ("vals", "ray_indices", "is_valid", "chunk_starts", "chunk_cnts")), term.numpy(), _live(c))
+    K.check_against_fixture(name, out, k2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", K.ALL)
+def test_hip_reproduces_reference_k2(name, k2):
+    import torch
+
+    from gpu_utils import n, t
+    from nerfacc_amd.grid import traverse_grids
+
+    c = _inputs(name, k2)
+    extra = {k: t(v) for k, v in c["extra"].items()}
+    iv, sm, term = traverse_grids(t(c["rays_o"]), t(c["rays_d"]), t(c["binaries"]), t(c["aabbs"]), **extra, **c["kw"])
+    torch.cuda.synchronize()
+    as_map = lambda s, flags: dict(vals=n(s.vals), ray_indices=n(s.ray_indices), chunk_starts=n(s.packed_info[:, 0]),
+                                   chunk_cnts=n(s.packed_info[:, 1]), **{f: n(getattr(s, f)) for f in flags})
+    out = K.pack_outputs(as_map(iv, ("is_left", "is_right")), as_map(sm, ("is_valid",)), n(term), _live(c))
+    K.check_against_fixture(name, out, k2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["m1_sphere", "lego_4k", "lego_70k", "near_far", "degenerate"])
+def test_hip_sampling_reproduces_reference_k2(name, k2):
+    """OccGridEstimator.sampling (the fused count/emit kernels, not the general fill kernel) against the same
+    fixture: ray_indices, t_starts = vals[is_left], t_ends = vals[is_right] (occ_grid.py:166-176)"""
+    import torch
+
+    from gpu_utils import n, t
+    from nerfacc_amd import OccGridEstimator
+
+    c = _inputs(name, k2)
+    lvl, res = c["binaries"].shape[0], c["binaries"].shape[1:]
+    est = OccGridEstimator(roi_aabb=c["aabbs"][0].tolist(), resolution=list(res), levels=lvl).to("cuda:0")
+    assert np.array_equal(n(est.aabbs), c["aabbs"])
+    est.binaries = t(c["binaries"])
+    kw = c["kw"]
+    ex = c["extra"]
+    near = t(ex["near_planes"]) if "near_planes" in ex else None
+    far = t(ex["far_planes"]) if "far_planes" in ex else None
+    # near_plane=0 / far_plane=inf are grid.py's defaults, which the fixture call used
+    ri, ts, te = est.sampling(t(c["rays_o"]), t(c["rays_d"]), near_plane=0.0, far_plane=float("inf"),
+                              t_min=near, t_max=far, render_step_size=kw["step_size"], cone_angle=kw.get("cone_angle", 0.0))
+    torch.cuda.synchronize()
+    ri, ts, te = n(ri), n(ts), n(te)
+    assert K.sha(ri.astype(np.int64)) == str(k2[f"{name}/sha/sm_ray_indices"])
+    cnts = np.bincount(ri, minlength=c["rays_o"].shape[0])
+    ref_cnts = k2[f"{name}/cnts/sm_chunk_cnts"] if f"{name}/cnts/sm_chunk_cnts" in k2 else k2[f"{name}/full/sm_chunk_cnts"]
+    assert np.array_equal(cnts, ref_cnts)
+    # midpoints of the fixture = (t_start + t_end) * 0.5 with the same rounding (grid.cu:252)
+    mids = ((te + ts) * np.float32(0.5)).astype(np.float32)
+    assert K.sha(mids) == str(k2[f"{name}/sha/sm_vals"])
