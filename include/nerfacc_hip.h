@@ -151,7 +151,7 @@ int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t
 int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * pack_info (pack.py:10-49): ray_indices [n] (sorted) -> packed_info [n_rays, 2]
+ * pack_info (pack.py:10-49): ray_indices [n] (any order; ascending input takes the one-launch path) -> packed_info [n_rays, 2]
  * ------------------------------------------------------------------------------------- */
 int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, void *stream);
 /* inverse: packed_info -> ray_indices [n]; elements outside every chunk get -1 */
@@ -230,10 +230,11 @@ int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, co
 int nfa_accumulate_along_rays(const int64_t *ray_indices, const float *weights,
                               const float *values /* [n, D] nullable */, int64_t n, int32_t D,
                               int64_t n_rays, float *outputs /* [n_rays, D] */, void *stream);
-/* VJP: g_weights [n] and/or g_values [n, D] (either nullable) from g_outputs [n_rays, D] */
+/* VJP: g_weights [n] and/or g_values [n, D] (either nullable) from g_outputs [n_rays, D]; samples whose
+ * ray index lies outside [0, n_rays) were skipped by the forward pass and get a zero gradient */
 int nfa_accumulate_along_rays_bwd(const int64_t *ray_indices, const float *weights,
                                   const float *values, const float *g_outputs, int64_t n, int32_t D,
-                                  float *g_weights, float *g_values, void *stream);
+                                  int64_t n_rays, float *g_weights, float *g_values, void *stream);
 
 /* rendering() after rgb_sigma_fn (volrend.py:104-164), one kernel: weights/trans/alphas [n],
  * colors [n_rays,3], opacities [n_rays,1], depths [n_rays,1] incl. depth normalisation

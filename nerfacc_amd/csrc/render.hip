@@ -329,14 +329,15 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(
 
 __global__ __launch_bounds__(kBlock) void accumulate_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ weights, const float *__restrict__ values,
-    const float *__restrict__ g_out, int64_t n, int D, float *__restrict__ g_w, float *__restrict__ g_v)
+    const float *__restrict__ g_out, int64_t n, int D, int64_t n_rays, float *__restrict__ g_w, float *__restrict__ g_v)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = keys[i];
+        const bool in = r >= 0 && r < n_rays;     // the forward pass skipped such samples (e.g. the -1 gaps of unpack_info): zero gradient
         const float w = weights[i];
         float acc = 0.0f;
         for (int c = 0; c < D; ++c) {
-            const float g = g_out[r * D + c];
+            const float g = in ? g_out[r * D + c] : 0.0f;
             if (values) { acc += g * values[i * D + c]; if (g_v) g_v[i * D + c] = w * g; }
             else acc += g;
         }
@@ -468,12 +469,26 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
 // ----------------------------------------------------------------------------------------
 // pack_info / unpack_info
 // ----------------------------------------------------------------------------------------
-// pack.py:38-46 for ray_indices grouped in ascending order: start[r] = first index with key >= r,
-// count[r] = start[r + 1] - start[r].  One binary search per ray; the next ray's start comes from
-// the neighbouring lane (lane 63 gallops forward from its own start instead: counts are small).
+// pack.py:38-46: cnt[r] = #{i : ray_indices[i] == r} (index_add_ of ones), start[r] = cumsum(cnt)[r] - cnt[r] — for
+// ANY order of ray_indices.  Ascending input (what every producer on this path emits) takes one launch:
+// start[r] = first index with key >= r by binary search, the next ray's start from the neighbouring lane
+// (lane 63 gallops forward from its own start instead: counts are small).  A descent anywhere in the input is
+// detected first (pack_check_kernel) and switches to the histogram form of the reference: wave-aggregated int64
+// atomics (one per run of equal keys, deterministic: integers) + one exclusive scan.  The flag lives in
+// packed[0] — the start of ray 0, which is 0 in either form — so no workspace is needed; every kernel of the
+// sequence is launched unconditionally and returns at once when the flag says it is not its turn.
+__global__ __launch_bounds__(kBlock) void pack_check_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t *__restrict__ packed)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * kBlock)
+        bad |= keys[i] < keys[i - 1];
+    if (__ballot(bad) && lane_id() == 0) packed[0] = 1;      // plain store: every writer writes the same value
+}
+
 __global__ __launch_bounds__(kBlock) void pack_info_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t n_rays,
                                                            int64_t *__restrict__ packed)
 {
+    if (__builtin_nontemporal_load(packed) != 0) return;      // unsorted input: the histogram kernels do the work
     const int lane = lane_id();
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t r0 = (int64_t)blockIdx.x * kBlock; r0 < n_rays; r0 += stride) {
@@ -489,11 +504,67 @@ __global__ __launch_bounds__(kBlock) void pack_info_kernel(const int64_t *__rest
             while (a < b) { const int64_t m = a + ((b - a) >> 1); if (keys[m] <= r) a = m + 1; else b = m; }
             next = a;
         }
-        if (r < n_rays) {
-            packed[2 * r] = first;
-            packed[2 * r + 1] = next - first;
+        if (r < n_rays && r > 0) packed[2 * r] = first;       // packed[0] (= 0) doubles as the flag and is left alone
+        if (r < n_rays) packed[2 * r + 1] = next - first;
+    }
+}
+
+// the three kernels of the unsorted form; all of them return at once for sorted input (flag 0)
+__global__ __launch_bounds__(kBlock) void pack_hist_zero_kernel(int64_t n_rays, int64_t *__restrict__ packed)
+{
+    if (__builtin_nontemporal_load(packed) == 0) return;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * kBlock) packed[2 * r + 1] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void pack_hist_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t n_rays,
+                                                           int64_t *__restrict__ packed)
+{
+    if (__builtin_nontemporal_load(packed) == 0) return;
+    const int lane = lane_id();
+    const int64_t n64 = (n + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n64; i += (int64_t)gridDim.x * kBlock) {
+        const bool active = i < n;
+        const int64_t k = active ? keys[i] : -1;
+        const int64_t prev = lane_prev_i64(k);
+        const bool head = active && (lane == 0 || prev != k);            // first lane of a run of equal keys in this wave
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long act = __ballot(active);
+        if (head && k >= 0 && k < n_rays) {
+            const unsigned long long later = heads & ~lanes_le(lane);
+            const int end = later ? (__ffsll((long long)later) - 1) : (64 - (int)__clzll((long long)act));
+            atomicAdd((unsigned long long *)(packed + 2 * k + 1), (unsigned long long)(end - lane));
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void pack_hist_scan_kernel(int64_t n_rays, int64_t *__restrict__ packed)
+{
+    if (__builtin_nontemporal_load(packed) == 0) return;
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < n_rays; base += 1024) {
+        const int64_t r = base + threadIdx.x;
+        const int64_t v = r < n_rays ? packed[2 * r + 1] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int64_t t = wsum[w]; if (w < wave) woff += t; tot += t; }
+        const int64_t carry = carry_s;
+        if (r < n_rays && r > 0) packed[2 * r] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[0] = 0;        // clear the flag last: the start of ray 0
 }
 
 __global__ __launch_bounds__(kBlock) void unpack_info_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts,
@@ -632,15 +703,15 @@ NFA_EXPORT int nfa_accumulate_along_rays(const int64_t *ray_indices, const float
 }
 
 NFA_EXPORT int nfa_accumulate_along_rays_bwd(const int64_t *ray_indices, const float *weights, const float *values,
-                                             const float *g_outputs, int64_t n, int32_t D, float *g_weights,
-                                             float *g_values, void *stream)
+                                             const float *g_outputs, int64_t n, int32_t D, int64_t n_rays,
+                                             float *g_weights, float *g_values, void *stream)
 {
-    NFA_REQUIRE(n >= 0 && D >= 1, "accumulate_along_rays_bwd: bad size");
+    NFA_REQUIRE(n >= 0 && D >= 1 && n_rays >= 0, "accumulate_along_rays_bwd: bad size");
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && weights && g_outputs, "accumulate_along_rays_bwd: NULL pointer");
     NFA_REQUIRE(values != nullptr || (D == 1 && g_values == nullptr), "accumulate_along_rays_bwd: values is NULL");
     hipLaunchKernelGGL(accumulate_bwd_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
-                       ray_indices, weights, values, g_outputs, n, D, g_weights, g_values);
+                       ray_indices, weights, values, g_outputs, n, D, n_rays, g_weights, g_values);
     return check_launch("accumulate_bwd_kernel");
 }
 
@@ -688,7 +759,16 @@ NFA_EXPORT int nfa_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_ra
     NFA_REQUIRE(n >= 0 && n_rays >= 0, "pack_info: negative size");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(packed_info && (ray_indices || n == 0), "pack_info: NULL pointer");
-    hipLaunchKernelGGL(pack_info_kernel, dim3(blocks_for(n_rays)), dim3(kBlock), 0, (hipStream_t)stream, ray_indices, n, n_rays, packed_info);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rays == 0) return NFA_OK;
+    if (hipMemsetAsync(packed_info, 0, 2 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "pack_info: memset failed");
+    if (n > 1) hipLaunchKernelGGL(pack_check_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, s, ray_indices, n, packed_info);
+    hipLaunchKernelGGL(pack_info_kernel, dim3(blocks_for(n_rays)), dim3(kBlock), 0, s, ray_indices, n, n_rays, packed_info);
+    if (n > 1) {
+        hipLaunchKernelGGL(pack_hist_zero_kernel, dim3(blocks_for(n_rays)), dim3(kBlock), 0, s, n_rays, packed_info);
+        hipLaunchKernelGGL(pack_hist_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, s, ray_indices, n, n_rays, packed_info);
+        hipLaunchKernelGGL(pack_hist_scan_kernel, dim3(1), dim3(1024), 0, s, n_rays, packed_info);
+    }
     return check_launch("pack_info_kernel");
 }
 

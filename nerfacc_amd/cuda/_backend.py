@@ -15,6 +15,7 @@ device the call raises.  Build with ``python -m nerfacc_amd.build`` (hipcc, a fe
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 import weakref
 from ctypes import c_float, c_int32, c_int64, c_void_p
@@ -83,7 +84,7 @@ _SIGNATURES = {
     "nfa_visibility_workspace_bytes": (c_int64, [c_int64]),
     "nfa_visibility_compact": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "nfa_accumulate_along_rays": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P]),
-    "nfa_accumulate_along_rays_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "nfa_accumulate_along_rays_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P]),
     "nfa_rendering_fwd": (ctypes.c_int, [_P] * 5 + [c_int64, c_int64, _P, c_int32] + [_P] * 7),
     "nfa_rendering_bwd": (ctypes.c_int, [_P] * 10 + [c_int64, c_int64, _P, c_int32] + [_P] * 9),
     "nfa_importance_sampling": (ctypes.c_int, [ctypes.POINTER(_RaySegments), _P, c_int64, _P, _P, _P, _P]),
@@ -246,14 +247,22 @@ class RaySegmentsSpec:
 # stream wait plus a CPU load — no D2H copy to launch.
 # --------------------------------------------------------------------------------------
 _pinned = {}
+_pinned_lock = threading.Lock()
 
 
 def _host_ints(device: torch.device, n: int = 4) -> torch.Tensor:
-    key = (device.index, n)
+    """one pinned slot per (device, stream, host thread): a kernel writes it on the calling thread's current
+    stream and the same thread reads it after synchronising that stream, so neither another host thread
+    nor another stream of the same device (an evaluation stream next to a training stream) can overwrite
+    the totals in between — the reference functions are stateless, this keeps the calls re-entrant"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), n)
     buf = _pinned.get(key)
     if buf is None:
         buf = torch.zeros(n, dtype=torch.int64).pin_memory()
-        _pinned[key] = buf
+        with _pinned_lock:
+            if len(_pinned) > 256:          # streams / threads come and go: do not grow without bound
+                _pinned.clear()
+            _pinned[key] = buf
     return buf
 
 
@@ -266,7 +275,8 @@ def _read_ints(buf: torch.Tensor, device: torch.device):
 # occupancy bricks: packed once per distinct `binaries` tensor state
 # --------------------------------------------------------------------------------------
 _BRICK_CACHE_SLOTS = 4
-_brick_cache: List[dict] = []      # most recently used first: {"ref", "version", "bricks", "nonempty"}
+_brick_cache: List[dict] = []      # most recently used first: {"ref", "version", "bricks", "nonempty", "stream", "event"}
+_brick_lock = threading.RLock()    # the cache is shared by every host thread
 
 
 def _brick_entry(binaries: torch.Tensor) -> dict:
@@ -276,23 +286,30 @@ def _brick_entry(binaries: torch.Tensor) -> dict:
     _check_input(binaries, "binaries", torch.bool)
     if binaries.dim() != 4:
         raise RuntimeError("binaries must have shape [n_grids, resx, resy, resz]")
-    for k, c in enumerate(_brick_cache):
-        if c["ref"]() is binaries and c["version"] == binaries._version:
-            if k:
-                _brick_cache.insert(0, _brick_cache.pop(k))
-            return c
-    L = load_library()
-    G, rx, ry, rz = binaries.shape
-    words = L.nfa_packed_grid_words(G, rx, ry, rz)
-    bricks = torch.empty(words, dtype=torch.int64, device=binaries.device)
-    with _Guard(binaries):
-        _check(L.nfa_pack_binaries(_ptr(binaries), G, rx, ry, rz, _ptr(bricks), _stream(binaries)))
-    # drop slots whose tensor is gone or has changed, then the oldest
-    _brick_cache[:] = [c for c in _brick_cache if c["ref"]() is not None and not (c["ref"]() is binaries)]
-    entry = {"ref": weakref.ref(binaries), "version": binaries._version, "bricks": bricks, "nonempty": -1}
-    _brick_cache.insert(0, entry)
-    del _brick_cache[_BRICK_CACHE_SLOTS:]
-    return entry
+    with _brick_lock:
+        stream = torch.cuda.current_stream(binaries.device)
+        for k, c in enumerate(_brick_cache):
+            if c["ref"]() is binaries and c["version"] == binaries._version:
+                if k:
+                    _brick_cache.insert(0, _brick_cache.pop(k))
+                if c["stream"] != stream.cuda_stream:
+                    stream.wait_event(c["event"])      # packed on another stream: order this one after the pack
+                return c
+        L = load_library()
+        G, rx, ry, rz = binaries.shape
+        words = L.nfa_packed_grid_words(G, rx, ry, rz)
+        bricks = torch.empty(words, dtype=torch.int64, device=binaries.device)
+        with _Guard(binaries):
+            _check(L.nfa_pack_binaries(_ptr(binaries), G, rx, ry, rz, _ptr(bricks), _stream(binaries)))
+            event = torch.cuda.Event()
+            event.record(stream)
+        # drop slots whose tensor is gone or has changed, then the oldest
+        _brick_cache[:] = [c for c in _brick_cache if c["ref"]() is not None and not (c["ref"]() is binaries)]
+        entry = {"ref": weakref.ref(binaries), "version": binaries._version, "bricks": bricks, "nonempty": -1,
+                 "stream": stream.cuda_stream, "event": event}
+        _brick_cache.insert(0, entry)
+        del _brick_cache[_BRICK_CACHE_SLOTS:]
+        return entry
 
 
 def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
@@ -306,6 +323,11 @@ def _nonempty_bricks(binaries: torch.Tensor) -> int:
     """number of non-empty bricks of the packed grid: one readback per grid state (every 16 training
     steps); lets the kernels size their LDS occupancy image to the grid instead of to the worst case"""
     c = _brick_entry(binaries)
+    with _brick_lock:
+        return _nonempty_locked(c, binaries)
+
+
+def _nonempty_locked(c: dict, binaries: torch.Tensor) -> int:
     if c["nonempty"] < 0:
         G = binaries.shape[0]
         n_bricks = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
@@ -762,7 +784,7 @@ class _C:
         g_v = torch.empty_like(values) if (need_v and values is not None) else None
         with _Guard(weights):
             _check(load_library().nfa_accumulate_along_rays_bwd(_ptr(ray_indices), _ptr(weights), _ptr(values), _ptr(g_out),
-                                                                weights.shape[0], D, _ptr(g_w), _ptr(g_v), _stream(weights)))
+                                                                weights.shape[0], D, g_out.shape[0], _ptr(g_w), _ptr(g_v), _stream(weights)))
         return g_w, g_v
 
     # ---- occupancy-grid maintenance (OccGridEstimator._update, occ_grid.py:366-404) ----

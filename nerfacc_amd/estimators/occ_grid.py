@@ -68,6 +68,11 @@ class OccGridEstimator(AbstractEstimator):
         self._occs_mean_cache = (None, None)   # (occs._version, python float)
 
     # ------------------------------------------------------------------ sampling
+    def _occs_changed(self) -> None:
+        """`occs` was written through a raw pointer (grid_ema_update, mark_invisible, a broadcast): the
+        tensor's version counter did not move, so drop the memoised mean explicitly"""
+        self._occs_mean_cache = (None, None)
+
     def _occs_mean(self) -> float:
         """occs.mean() as a python float (occ_grid.py:183), recomputed only when occs changed."""
         ver, val = self._occs_mean_cache
@@ -168,6 +173,7 @@ class OccGridEstimator(AbstractEstimator):
                 too_near = ((uvd[:, 2] < near_plane) & in_image).any(0)
                 valid = (seen_fraction > 0) & (~too_near)
                 self.occs[lvl * self.cells_per_lvl + idx] = torch.where(valid, 0.0, -1.0)
+        self._occs_changed()
 
     @torch.no_grad()
     def _get_all_cells(self) -> List[Tensor]:
@@ -218,6 +224,7 @@ class OccGridEstimator(AbstractEstimator):
             from ..cuda._backend import packed_bricks
 
             packed_bricks(self.binaries)      # the bit-packed form the traversal kernels read
+            self._occs_changed()
             return
         # host tensors: the reference's own composition of torch ops (occ_grid.py:377-404)
         for lvl, indices in enumerate(lvl_indices):
@@ -229,6 +236,7 @@ class OccGridEstimator(AbstractEstimator):
             self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
         self.binaries = (self.occs > thre).view(self.binaries.shape)
+        self._occs_changed()
 
 
 def _meshgrid3d(res: Tensor, device: Union[torch.device, str] = "cpu") -> Tensor:

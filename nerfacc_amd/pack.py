@@ -9,11 +9,13 @@ from . import cuda as _C
 
 @torch.no_grad()
 def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
-    """`ray_indices` [n_samples] (ascending) -> `packed_info` [n_rays, 2] = (start, count).
+    """`ray_indices` [n_samples] -> `packed_info` [n_rays, 2] = (start, count).
 
-    The reference builds it from an atomic histogram plus a cumsum and, like here, supports
-    device tensors only.  This version is one kernel: each ray binary-searches its first and
-    last sample in the sorted index array (no atomics, deterministic).
+    The reference builds it from an atomic histogram plus a cumsum (any order of indices) and,
+    like here, supports device tensors only.  Ascending indices — what every sampler emits —
+    take one kernel here: each ray binary-searches its first and last sample (no atomics);
+    any other order is detected on the device and handled as the reference does (integer
+    histogram + exclusive sum), with the same result as `index_add_` + `cumsum`.
 
         >>> pack_info(torch.tensor([0, 0, 1, 1, 1, 2, 2, 2, 2], device="cuda"), n_rays=3)
         tensor([[0, 2], [2, 3], [5, 4]], device='cuda:0')

@@ -116,6 +116,8 @@ def broadcast_grid(estimator, src: int = 0) -> None:
     b = estimator.binaries.to(torch.uint8)
     dist.broadcast(b, src=src)
     estimator.binaries = b.to(torch.bool)
+    if hasattr(estimator, "_occs_changed"):
+        estimator._occs_changed()           # occs was overwritten in place: drop the memoised mean
 
 
 @contextmanager

@@ -10,9 +10,11 @@ single HIP kernels with hand-written backward kernels (render.hip):
   accumulate_along_rays                                            -> 1 kernel fwd, 1 bwd
 
 Batched inputs ([n_rays, n_samples], no ray_indices) stay plain differentiable torch code,
-as in the reference.  Gradients flow to sigmas / rgbs / alphas / weights / values; like the
-reference's `rendering`, nothing here is differentiable w.r.t. t_starts, t_ends or indices
-on the flattened paths.
+as in the reference.  The fused kernels give gradients for sigmas / rgbs / alphas / weights /
+values.  When t_starts, t_ends or prefix_trans require grad (the reference's expressions are
+differentiable w.r.t. them) the flattened paths switch to the same composition of
+differentiable ops as the reference (per-ray scans from scan.py + elementwise torch), so those
+gradients exist too — at the reference's cost instead of the fused kernels'.
 """
 from typing import Callable, Dict, Optional, Tuple
 
@@ -29,6 +31,21 @@ def _flat_indices(ref: Tensor, packed_info: Optional[Tensor], ray_indices: Optio
         return ray_indices.contiguous()
     starts, cnts = packed_info.unbind(dim=-1)
     return _C.unpack_info(starts.contiguous(), cnts.contiguous(), ref.shape[0])
+
+
+def _needs_torch_composition(*tensors) -> bool:
+    """True when an input the fused kernels have no VJP for (t_starts, t_ends, prefix_trans) wants a gradient"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _density_composition(t_starts, t_ends, sigmas, packed_info, ray_indices, prefix_trans):
+    """volrend.py:266-278 as differentiable ops (keyed / packed exclusive sum from scan.py)"""
+    sigmas_dt = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sigmas_dt)
+    trans = torch.exp(-exclusive_sum(sigmas_dt, packed_info=packed_info, indices=ray_indices))
+    if prefix_trans is not None:
+        trans = trans * prefix_trans
+    return trans, alphas
 
 
 # ----------------------------------------------------------------------------------------
@@ -50,6 +67,8 @@ class _WeightFromDensity(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_w, g_T, g_a):
+        if not ctx.needs_input_grad[3]:
+            return None, None, None, None, None
         ray_indices, t_starts, t_ends, sigmas, T, a = ctx.saved_tensors
         g = [None if x is None else x.contiguous() for x in (g_w, g_T, g_a)]
         g_sig = _C.render_weight_from_density_bwd(ray_indices, t_starts, t_ends, sigmas, T, a, *g)
@@ -130,14 +149,17 @@ def rendering(
         rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
         assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
         assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
-        if ray_indices is not None:
+        if ray_indices is not None and not _needs_torch_composition(t_starts, t_ends):
             assert n_rays is not None, "n_rays must be provided"
+            # the kernel blends ONE background colour; anything else the reference's broadcast accepts
+            # (per-ray [n_rays, 3], [1], ...) is blended below with the reference's own expression
+            fused_bkgd = render_bkgd is not None and render_bkgd.numel() == 3 and not render_bkgd.requires_grad
             colors, opacities, depths, weights, trans, alphas = _Rendering.apply(
-                ray_indices.contiguous(), t_starts, t_ends, sigmas, rgbs, int(n_rays), render_bkgd, bool(expected_depths))
+                ray_indices.contiguous(), t_starts, t_ends, sigmas, rgbs, int(n_rays),
+                render_bkgd.reshape(3) if fused_bkgd else None, bool(expected_depths))
             extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
-            if render_bkgd is not None and render_bkgd.requires_grad:
-                # rare: keep the background differentiable like the reference's torch expression
-                colors = colors + (render_bkgd - render_bkgd.detach()) * (1.0 - opacities.detach())
+            if render_bkgd is not None and not fused_bkgd:
+                colors = colors + render_bkgd * (1.0 - opacities)          # volrend.py:161-162
             return colors, opacities, depths, extras
         weights, trans, alphas = render_weight_from_density(t_starts, t_ends, sigmas, ray_indices=ray_indices, n_rays=n_rays)
         extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
@@ -189,6 +211,8 @@ def render_transmittance_from_density(
         if prefix_trans is not None:
             trans = trans * prefix_trans
         return trans, alphas
+    if _needs_torch_composition(t_starts, t_ends, prefix_trans):
+        return _density_composition(t_starts, t_ends, sigmas, packed_info, ray_indices, prefix_trans)
     idx = _flat_indices(sigmas, packed_info, ray_indices)
     _, trans, alphas = _WeightFromDensity.apply(idx, t_starts, t_ends, sigmas, prefix_trans)
     return trans, alphas
@@ -218,6 +242,9 @@ def render_weight_from_density(
     """
     if packed_info is None and ray_indices is None:
         trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, prefix_trans=prefix_trans)
+        return trans * alphas, trans, alphas
+    if _needs_torch_composition(t_starts, t_ends, prefix_trans):
+        trans, alphas = _density_composition(t_starts, t_ends, sigmas, packed_info, ray_indices, prefix_trans)
         return trans * alphas, trans, alphas
     idx = _flat_indices(sigmas, packed_info, ray_indices)
     return _WeightFromDensity.apply(idx, t_starts, t_ends, sigmas, prefix_trans)
