@@ -9,7 +9,7 @@ examples/train_ngp_nerf_occ.py) with the two things that do not exist on this ma
 replaced and said so in the output (`data`, `config.workload`):
   * dataset  -> procedural "lego-like" scene (union of boxes inside +-1.0 of the +-1.5 aabb),
     100 cameras on a radius-4 sphere, 800x800, focal 1111.1 (nerf_synthetic.py:46-48,68-69),
-    white background; target pixels are rendered from the frozen initial field;
+    white background; target pixels are rendered from the analytic scene sampled on a grid;
   * tiny-cuda-nn hash-grid field -> a torch-native dense voxel field (128^3 density + colour
     grids, trilinear `grid_sample`), 8.4 M parameters.
 Everything else follows the script: 128^3 occupancy grid on aabb +-1.5 refreshed every 16
@@ -19,13 +19,21 @@ rays/iter adapted so that ~2^18 samples are rendered per iteration
 smooth-L1 loss.  A step = update_every_n_steps + sampling (traversal, sigma_fn, visibility
 filter) + rendering forward + backward + optimizer step.
 
-Issue order: the traversal of a step's rays depends on the occupancy grid but not on the field's
-parameters, so the NEXT step's rays are drawn and traversed on a side HIP stream right after this
-step's backward pass has been queued (it overlaps with the backward kernels; `--no-overlap` keeps
-everything on one stream in program order).  The work per step is the same either way.
+What is timed.  The student field starts from fog and is TRAINED, untimed, for `--pretrain` steps of the
+same loop (grid warm-up included) before the W warm-up and K timed steps, so that the timed region sits
+in the steady state of a real run whatever K is (rays/iter and samples/ray are printed).  Two loops exist:
+  * `api` (default, the headline): the step exactly as examples/utils.py:137-155 +
+    train_ngp_nerf_occ.py:166-203 write it — `estimator.sampling(sigma_fn=...)` -> `nerfacc.rendering`;
+  * `overlap`: same work, but the NEXT step's rays are traversed on a side stream while this step's
+    backward pass runs (the traversal depends on the occupancy grid, not on the parameters).
+Both are timed in one run (K steps each, same barriers); `value` is the `--mode` one, the other is
+printed beside it.  A third pass of a few profiled steps (torch.profiler, kernel intervals) gives
+`path_us_per_step` (all nfa:: kernels) and `gpu_idle_frac`.
 
-Multi-GPU: each rank draws its own rays (weak scaling: per-GPU work is fixed),
-one flat all-reduce of the field gradients + one 16-byte all-reduce of the step's counts.
+Multi-GPU: each rank draws its own rays (weak scaling: per-GPU work is fixed; with
+`--rays-per-iter G` the GLOBAL batch is fixed at G rays, G / N per rank — configs[3]: 65536 / 8),
+gradient all-reduce in a few async chunks overlapped with the Adam update (sharding.ExchangeAdam)
++ one 16-byte all-reduce of the step's counts.
 """
 import argparse
 import json
@@ -150,31 +158,64 @@ def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
     return rgb, opacity, depth, t_starts.shape[0]
 
 
-# ------------------------------------------------------------------------------------------
-# CPU baseline: the oracle (single-threaded C port of the reference algorithm) on a bounded
-# sample of the same workload.  Only this function touches oracle/.
-# ------------------------------------------------------------------------------------------
-def cpu_baseline(field, est, pool_o, pool_d, n_rays=16384, budget_s=20.0):
-    """oracle (C port of the reference algorithm) on the host: one thread on `n_rays` rays, then all
-    host cores on a proportionally larger sample (ctypes releases the GIL: one Python thread per
-    core, each running the whole per-ray pipeline on its own contiguous slice of rays)."""
-    import concurrent.futures
-    import oracle
+def render_rays_reference_style(field, est, rays_o, rays_d, bkgd, training: bool):
+    """examples/utils.py:87-155 as written there: the user-side closures index the rays with plain torch ops
+    (`rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0`); only nerfacc's own
+    calls (`estimator.sampling`, `nerfacc.rendering`) reach this package."""
+    def sigma_fn(t_starts, t_ends, ray_indices):
+        if t_starts.shape[0] == 0:
+            return torch.empty((0,), device=t_starts.device)
+        positions = rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+        return field.query_density(positions).squeeze(-1)
 
+    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+        if t_starts.shape[0] == 0:
+            return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
+        positions = rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+        rgb, sigma = field(positions, rays_d[ray_indices])
+        return rgb, sigma.squeeze(-1)
+
+    ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
+                                                 render_step_size=RENDER_STEP, stratified=training, cone_angle=0.0,
+                                                 alpha_thre=0.0)
+    rgb, opacity, depth, _ = nerfacc.rendering(t_starts, t_ends, ray_indices, n_rays=rays_o.shape[0],
+                                               rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
+    return rgb, opacity, depth, t_starts.shape[0]
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline.  Only this function touches oracle/.
+# ------------------------------------------------------------------------------------------
+def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
+    """The CPU side of the same workload on the host cores of this box (count printed):
+
+    * `value` (rays/s): the C oracle (port of the reference algorithm, OpenMP over rays) on all cores, on a bounded
+      sample of the bench's own ray pool and occupancy grid — traversal + visibility + rendering fwd + weight bwd;
+      the radiance field's evaluation (torch CPU) runs between the stages and is EXCLUDED from the time in every leg;
+    * `single_thread`: the same pipeline with one thread (the scalar checker as the tests use it);
+    * `pure_torch`: BASELINE.json configs[0] — pure-PyTorch `render_weight_from_density` forward + backward on CPU
+      tensors (oracle/torch_cpu.py: the reference's batched torch.cumsum branch on the padded layout, and the
+      flattened cumsum form), torch.set_num_threads(all cores), on C1's shapes: 128^3 sphere grid, 4096 rays into the
+      unit cube, step 1/600; 3 warm-ups, median of 10."""
+    import oracle
+    from oracle import torch_cpu
+
+    cores = os.cpu_count() or 1
     binaries = est.binaries.cpu().numpy()
     aabbs = est.aabbs.cpu().numpy()
     field_cpu = DenseGridField(AABB, GRID_RES)
     field_cpu.load_state_dict({k: v.cpu() for k, v in field.state_dict().items()})
-    torch.set_num_threads(1)            # the field is excluded from the timing; keep it from oversubscribing
+    torch.set_num_threads(cores)
+    t_deadline = time.perf_counter() + budget_s
 
-    def once(o, d):
-        """returns (seconds spent outside the radiance field, rendered samples)"""
+    def pipeline(o, d):
+        """returns (seconds outside the radiance field, rendered samples, candidate samples)"""
         R = o.shape[0]
         t_field = 0.0
         t0 = time.perf_counter()
-        iv, sm, _ = oracle.traverse_grids(o, d, binaries, aabbs, np.zeros(R, np.float32),
-                                          np.full(R, 1e10, np.float32), RENDER_STEP, 0.0)
-        ts, te, ri = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], sm["ray_indices"]
+        ri, ts, te, pk = oracle.sample_occgrid(o, d, binaries, aabbs, np.zeros(R, np.float32), np.full(R, 1e10, np.float32),
+                                               RENDER_STEP, 0.0)
+        n_cand = ri.shape[0]
         tf = time.perf_counter()
         with torch.no_grad():
             pos = torch.from_numpy(o[ri] + d[ri] * ((ts + te)[:, None] / 2.0))
@@ -182,74 +223,196 @@ def cpu_baseline(field, est, pool_o, pool_d, n_rays=16384, budget_s=20.0):
         t_field += time.perf_counter() - tf
         _, T, a = oracle.render_weight_from_density(ts, te, sig, ri)
         keep = oracle.visibility(T, a, 1e-4, 0.0)
-        ri, ts, te = ri[keep], ts[keep], te[keep]
+        ri, ts, te, pk = oracle.compact(keep, ri, ts, te, pk)
         tf = time.perf_counter()
         with torch.no_grad():
             pos = torch.from_numpy(o[ri] + d[ri] * ((ts + te)[:, None] / 2.0))
             rgb, sig = field_cpu(pos)
             rgb, sig = rgb.numpy(), sig.squeeze(-1).numpy()
+            gw_src = rgb
         t_field += time.perf_counter() - tf
         col, opa, dep, ex = oracle.rendering(ts, te, ri, R, sig, rgb, np.ones(3, np.float32))
-        gw = np.ascontiguousarray((rgb * col[ri]).sum(-1).astype(np.float32))      # stand-in for dL/dw
+        tf = time.perf_counter()
+        gw = np.ascontiguousarray((gw_src * col[ri]).sum(-1).astype(np.float32))      # stand-in for dL/dw (numpy glue: excluded)
+        t_field += time.perf_counter() - tf
         oracle.render_weight_from_density_bwd(ts, te, sig, ri, g_w=gw)
-        return time.perf_counter() - t0 - t_field, ri.shape[0]
+        return time.perf_counter() - t0 - t_field, ri.shape[0], n_cand
 
-    # ---- one thread
-    o1 = pool_o[:n_rays].cpu().numpy()
-    d1 = pool_d[:n_rays].cpu().numpy()
-    once(o1, d1)
-    times, n_s = [], 0
-    t_begin = time.perf_counter()
-    while len(times) < 10 and time.perf_counter() - t_begin < budget_s / 2:
-        dt, n_s = once(o1, d1)
-        times.append(dt)
-    med1 = float(np.median(times))
-
-    # ---- all cores: `per` rays per thread, slices of the same pool
-    cores = os.cpu_count() or 1
-    per = 2048
-    n_all = min(cores * per, pool_o.shape[0])
-    oa = pool_o[:n_all].cpu().numpy()
-    da = pool_d[:n_all].cpu().numpy()
-    slices = [(i, min(i + per, n_all)) for i in range(0, n_all, per)]
-
-    def run_all(pool):
-        t0 = time.perf_counter()
-        res = list(pool.map(lambda s: once(oa[s[0]:s[1]], da[s[0]:s[1]]), slices))
-        wall = time.perf_counter() - t0       # (the slices' field queries run concurrently and stay in)
-        return wall, sum(r[1] for r in res)
-
-    with concurrent.futures.ThreadPoolExecutor(max_workers=len(slices)) as pool:
-        run_all(pool)
-        walls = []
+    def timed(o, d, reps, share):
+        pipeline(o[:2048], d[:2048])
+        out = []
         t_begin = time.perf_counter()
-        while len(walls) < 5 and time.perf_counter() - t_begin < budget_s / 2:
-            walls.append(run_all(pool))
-    wall, n_s_all = sorted(walls)[len(walls) // 2]
+        while len(out) < reps and (not out or time.perf_counter() - t_begin < budget_s * share):
+            out.append(pipeline(o, d))
+        out.sort()
+        return out[len(out) // 2], len(out)
+
+    n1 = 8192
+    o1, d1 = pool_o[:n1].cpu().numpy(), pool_d[:n1].cpu().numpy()
+    oracle.set_threads(1)
+    (t1, s1, c1), reps1 = timed(o1, d1, 5, 0.3)
+    n_all = int(min(pool_o.shape[0], max(16384, 1024 * cores)))
+    oa, da = pool_o[:n_all].cpu().numpy(), pool_d[:n_all].cpu().numpy()
+    used = oracle.set_threads(cores)
+    try:
+        (ta, sa, ca), repsa = timed(oa, da, 7, 0.3)
+    finally:
+        oracle.set_threads(1)
+
+    # ---- configs[0]: pure-PyTorch render_weight_from_density on CPU, C1 shapes
+    rng = np.random.default_rng(42)
+    R = 4096
+    g = (np.arange(128) + 0.5) / 128
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    sphere = (((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2) < 0.09)[None]
+    o = rng.standard_normal((R, 3))
+    o = (0.5 + 1.5 * o / np.linalg.norm(o, axis=-1, keepdims=True)).astype(np.float32)
+    tgt = rng.random((R, 3)).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    iv, sm, _ = oracle.traverse_grids(o, d, sphere, np.array([[0, 0, 0, 1, 1, 1]], np.float32), step_size=5e-3 / 3)
+    tt = torch.from_numpy
+    ts, te, ri, pk = tt(iv["vals"][iv["is_left"]]), tt(iv["vals"][iv["is_right"]]), tt(sm["ray_indices"]), tt(sm["packed_info"])
+    N = ts.shape[0]
+    sig = tt((rng.random(N) * 20).astype(np.float32))
+    (p_ts, p_te, p_sig), mask = torch_cpu.pad_rays(pk, ts, te, sig)
+
+    def median_ms(fn, cap_s=2.5):
+        fn()
+        xs, t_begin = [], time.perf_counter()
+        while len(xs) < 10 and (len(xs) < 2 or time.perf_counter() - t_begin < cap_s):
+            t0 = time.perf_counter()
+            fn()
+            xs.append(time.perf_counter() - t0)
+        return float(np.median(xs)) * 1e3
+
+    def batched_fwd_bwd():
+        s = p_sig.clone().requires_grad_(True)
+        w, _, _ = torch_cpu.weights_batched(p_ts, p_te, s)
+        w.sum().backward()
+
+    def flat_fwd_bwd():
+        s = sig.clone().requires_grad_(True)
+        w, _, _ = torch_cpu.weights_flat(ts, te, s, ri, pk)
+        w.sum().backward()
+
+    # torch's intra-op pool does not scale to hundreds of threads on tensors this small: sweep and report all
+    sweep = {}
+    for nt in sorted({1, 8, 32, cores}):
+        if nt > cores:
+            continue
+        torch.set_num_threads(nt)
+        sweep[nt] = (median_ms(batched_fwd_bwd), median_ms(flat_fwd_bwd))
+    torch.set_num_threads(cores)
+    best_b = min(sweep, key=lambda k: sweep[k][0])
+    best_f = min(sweep, key=lambda k: sweep[k][1])
+    ms_b, ms_f = sweep[best_b][0], sweep[best_f][1]
+    alg = (32.0 + 28.0) * N                       # weights fwd 32 N + bwd 28 N bytes
     return {
-        "value": n_all / wall, "unit": "rays/s", "cores": len(slices), "kind": "port",
-        "samples_per_sec": n_s_all / wall,
-        "sample": f"{n_all} rays of the same pool/grid in {len(slices)} slices, one thread per host core: oracle traversal + "
-                  f"visibility + rendering fwd + weight bwd per slice, wall clock of the whole batch (includes the "
-                  f"threads' torch-CPU field queries), median of {len(walls)}",
-        "single_thread": {"value": n_rays / med1, "unit": "rays/s", "samples_per_sec": n_s / med1,
-                          "sample": f"{n_rays} rays, median of {len(times)}, radiance-field evaluation excluded"},
+        "value": n_all / ta, "unit": "rays/s", "cores": used, "kind": "port",
+        "samples_per_sec": sa / ta, "candidate_samples_per_sec": ca / ta,
+        "sample": f"{n_all} rays of the bench's pool and occupancy grid, C oracle with OpenMP over rays on {used} threads: traversal + "
+                  f"visibility + rendering fwd + weight bwd; radiance-field evaluation excluded; median of {repsa} runs "
+                  f"({ta * 1e3:.1f} ms each)",
+        "single_thread": {"value": n1 / t1, "unit": "rays/s", "samples_per_sec": s1 / t1,
+                          "sample": f"{n1} rays, same pipeline, 1 thread, median of {reps1}, radiance-field evaluation excluded"},
+        "all_cores_over_single_thread": (n_all / ta) / (n1 / t1),
+        "pure_torch": {
+            "workload": f"configs[0]: 128^3 sphere grid, {R} rays into the unit cube, step 1/600 -> {N} samples "
+                        f"(max {int(pk[:, 1].max())} per ray); render_weight_from_density fwd+bwd, torch CPU, warm-up + median of up to 10, "
+                        f"best thread count of the sweep",
+            "batched_padded_ms": ms_b, "batched_threads": best_b, "flat_ms": ms_f, "flat_threads": best_f,
+            "ms_by_threads": {str(k): {"batched_padded": round(v[0], 2), "flat": round(v[1], 2)} for k, v in sweep.items()},
+            "batched_samples_per_sec": N / (ms_b * 1e-3), "flat_samples_per_sec": N / (ms_f * 1e-3),
+            "flat_GBps_algorithmic": alg / (ms_f * 1e-3) / 1e9,
+            "note": "batched = the reference's only CPU-runnable branch (volrend.py:266-278 on a padded [rays, max_samples] layout, "
+                    f"{p_sig.numel()} padded elements for {N} samples); flat = cumsum minus per-ray offset on the packed layout",
+        },
         "host_cores_available": cores,
     }
+
+
+# ------------------------------------------------------------------------------------------
+# GPU activity of a few profiled steps: union of kernel intervals (idle fraction) and the nfa:: share
+# ------------------------------------------------------------------------------------------
+def profile_steps(step_fn, n_steps):
+    """{'busy_us_per_step', 'nfa_us_per_step', 'kernels_per_step', 'nfa_kernels_per_step', 'top'} from torch.profiler's
+    device-kernel events, or None when the profiler is unavailable"""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n_steps):
+                step_fn()
+            torch.cuda.synchronize()
+        ivals, nfa_us, n_nfa, per_name = [], 0.0, 0, {}
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is None or "cuda" not in str(ev.device_type).lower():
+                continue
+            dur = float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
+            if dur <= 0.0:
+                continue
+            start = float(ev.time_range.start)
+            ivals.append((start, start + dur))
+            short = ev.name.split("(")[0].replace("void ", "")[:70]
+            c = per_name.setdefault(short, [0, 0.0])
+            c[0] += 1
+            c[1] += dur
+            if "nfa::" in ev.name:
+                nfa_us += dur
+                n_nfa += 1
+        if not ivals:
+            return None
+        ivals.sort()
+        busy, (cs, ce) = 0.0, ivals[0]
+        for a, b in ivals[1:]:
+            if a > ce:
+                busy += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        busy += ce - cs
+        top = sorted(per_name.items(), key=lambda kv: -kv[1][1])[:8]
+        return {"busy_us_per_step": busy / n_steps, "nfa_us_per_step": nfa_us / n_steps,
+                "kernels_per_step": len(ivals) / n_steps, "nfa_kernels_per_step": n_nfa / n_steps,
+                "top_kernels_us_per_step": {k: round(v[1] / n_steps, 2) for k, v in top}}
+    except Exception as e:      # noqa: BLE001  (a missing profiler must not cost the bench line)
+        return {"error": repr(e)[:200]}
+
+
+def dda_steps(rays_o, rays_d, aabb, res, near, far):
+    """voxels a ray's DDA walk visits in a one-level grid without early termination: 1 + L1 distance between the
+    first and the last voxel (utils_grid.cuh:58-142: the walk ends when an index passes final_index)"""
+    lo, hi = aabb[:3], aabb[3:]
+    inv = 1.0 / rays_d
+    t0, t1 = (lo - rays_o) * inv, (hi - rays_o) * inv
+    tmin = torch.minimum(t0, t1).amax(-1).clamp_min(near)
+    tmax = torch.maximum(t0, t1).amin(-1).clamp_max(far)
+    ok = tmax > tmin
+    cell = lambda t: (((rays_o + rays_d * t[:, None]) - lo) / (hi - lo) * res).floor().clamp(0, res - 1)
+    steps = 1 + (cell(tmax - 1e-6) - cell(tmin + 1e-6)).abs().sum(-1)
+    return int(steps[ok].sum().item())
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--mode", choices=("api", "overlap"), default="api",
+                    help="which loop `value` is quoted on: api = the reference examples' step through the public API "
+                         "(estimator.sampling -> nerfacc.rendering); overlap = same work, next step's traversal on a side stream")
+    ap.add_argument("--pretrain", type=int, default=1500, help="untimed training steps from the fog initialisation before warm-up")
+    ap.add_argument("--rays-per-iter", type=int, default=0,
+                    help="fixed GLOBAL rays per iteration (configs[3]: 65536, i.e. 8192 per rank on 8 GPUs); 0 = the script's "
+                         "adaptive batch targeting 2^18 rendered samples per iteration per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="time only --mode")
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (gpu_idle_frac, path_us_per_step)")
     ap.add_argument("--pool", type=int, default=1 << 21)
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="issue the next step's ray traversal after the optimizer on the main stream instead of "
-                         "on a side stream concurrently with the backward pass")
     ap.add_argument("--occ-res", type=int, default=GRID_RES,
                     help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
+    ap.add_argument("--grad-chunks", type=int, default=4, help="chunks of the gradient all-reduce (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,47 +423,81 @@ def main():
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         dist.init_process_group("nccl", device_id=device)
+    fixed_rays = args.rays_per_iter // world_size if args.rays_per_iter > 0 else 0
 
     torch.manual_seed(42)
+    teacher = DenseGridField(AABB, GRID_RES).to(device).eval()          # the analytic scene sampled on a grid
     field = DenseGridField(AABB, GRID_RES).to(device)
-    teacher = DenseGridField(AABB, GRID_RES).to(device).eval()
+    with torch.no_grad():                                               # the student starts from fog and grey
+        field.grid[:, :1].fill_(math.log(0.5))
+        field.grid[:, 1:].zero_()
+    est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
     est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
-    optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
+    if world_size > 1:
+        optimizer = sharding.ExchangeAdam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=args.grad_chunks)
+    else:
+        optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
     loss_scale = 2.0**10
     bkgd = torch.ones(3, device=device)
 
     def occ_eval_fn(x):
         return field.query_density(x) * RENDER_STEP
 
-    est.train()
+    est_t.train()
     with sharding.synchronized_rng(1234, device):
-        for _ in range(4):                       # bring the grid to its steady state before timing
-            est._update(step=0, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
-
+        for _ in range(4):
+            est_t._update(step=0, occ_eval_fn=lambda x: teacher.query_density(x) * RENDER_STEP, occ_thre=1e-2)
     pool_o, pool_d = make_ray_pool(args.pool, seed=42 + rank, device=device)
-    est.eval()
-    with torch.no_grad():                        # target pixels from the frozen initial field
+    est_t.eval()
+    with torch.no_grad():                        # target pixels from the analytic scene
         pool_rgb = torch.empty((args.pool, 3), device=device)
         for i in range(0, args.pool, 1 << 16):
-            rgb, _, _, _ = render_rays(teacher, est, pool_o[i:i + (1 << 16)], pool_d[i:i + (1 << 16)], bkgd, False)
+            rgb, _, _, _ = render_rays(teacher, est_t, pool_o[i:i + (1 << 16)], pool_d[i:i + (1 << 16)], bkgd, False)
             pool_rgb[i:i + (1 << 16)] = rgb
+    del est_t
     est.train()
     torch.manual_seed(1000 + rank)
 
-    # steady state of the 20 k-step schedule: past `warmup_steps` (256) the grid update evaluates a
-    # quarter of the cells + the occupied ones instead of all 2 M cells (occ_grid.py:372-376)
-    state = {"num_rays": INIT_RAYS, "step": 1024}
-    stats = {"rays": 0, "samples": 0, "candidates": 0}
-
-    # The traversal of a step (rays -> candidate samples) does not depend on the field's parameters, only
-    # on the occupancy grid.  So the NEXT step's rays are drawn and traversed on a side stream right
-    # after this step's backward pass has been queued: the count kernel and its host read-back (the
-    # first of the two host syncs of a step) overlap with the backward kernels instead of waiting
-    # behind them, and the host can queue the sigma_fn / filter launches while the GPU is still busy.
-    # Steps that refresh the grid (every 16th) traverse after the refresh, on the main stream's heels.
+    state = {"num_rays": fixed_rays or INIT_RAYS, "step": 0}
+    stats = {"rays": 0, "samples": 0}
     side = torch.cuda.Stream(device=device)
-    overlap = not args.no_overlap
 
+    def next_num_rays(g_samples, g_rays):
+        if fixed_rays or g_samples <= 0:
+            return
+        # train_ngp_nerf_occ.py:187-194, on the global counts so that all ranks stay in step
+        state["num_rays"] = min(max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64), args.pool)
+
+    def backward_and_update(rgb, pixels, n_samples):
+        optimizer.zero_grad()
+        if n_samples > 0:
+            loss = F.smooth_l1_loss(rgb, pixels)
+            (loss * loss_scale).backward()
+        # every rank takes part in the exchange every step, samples or not (ExchangeAdam.step all-reduces)
+        if n_samples > 0 or world_size > 1:
+            optimizer.step()
+
+    def refresh_grid(step):
+        with sharding.synchronized_rng(5000 + step, device):
+            est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+
+    # ---- the reference examples' step, through the public API only ------------------------------------------------
+    def step_api():
+        step = state["step"]
+        if step % 16 == 0:
+            refresh_grid(step)
+        n = state["num_rays"]
+        idx = torch.randint(0, args.pool, (n,), device=device)
+        rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
+        rgb, _, _, n_samples = render_rays_reference_style(field, est, rays_o, rays_d, bkgd, True)
+        pending = sharding.allreduce_counts_begin(n_samples, n, device)
+        backward_and_update(rgb, pixels, n_samples)
+        next_num_rays(*sharding.allreduce_counts_end(pending))
+        stats["rays"] += n
+        stats["samples"] += n_samples
+        state["step"] += 1
+
+    # ---- same work, the next step's traversal overlapped with this step's backward pass ------------------------------
     def propose(n, wait_for_main):
         main = torch.cuda.current_stream(device)
         if wait_for_main:
@@ -332,119 +529,166 @@ def main():
             rgb, sigma = field(nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends))
             return rgb, sigma.squeeze(-1)
 
-        rgb, opacity, depth, _ = nerfacc.rendering(ts, te, ri, n_rays=prop["n"], rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
+        rgb, _, _, _ = nerfacc.rendering(ts, te, ri, n_rays=prop["n"], rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
         return rgb, ts.shape[0]
 
-    def train_step():
+    def step_overlap():
         step = state["step"]
-        refresh = step % 16 == 0
-        if refresh:
-            with sharding.synchronized_rng(5000 + step, device):
-                est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+        if step % 16 == 0:
+            state.pop("proposal", None)
+            refresh_grid(step)
         prop = state.pop("proposal", None)
         if prop is None:
             prop = propose(state["num_rays"], wait_for_main=True)
         n = prop["n"]
         rgb, n_samples = render_proposed(prop)
-        # global (samples, rays) of this step, so that all ranks stay in step (train_ngp_nerf_occ.py:187-194)
         pending = sharding.allreduce_counts_begin(n_samples, n, device)
-        optimizer.zero_grad()
-        if n_samples > 0:
-            loss = F.smooth_l1_loss(rgb, prop["pixels"])
-            (loss * loss_scale).backward()
-        # every rank takes part in the exchange every step, samples or not (a rank that skipped
-        # the collective would deadlock the others); missing grads count as zeros
-        sharding.allreduce_gradients(field.parameters())
-        if n_samples > 0 or world_size > 1:
-            optimizer.step()
+        backward_and_update(rgb, prop["pixels"], n_samples)
         with torch.cuda.stream(side):                 # the 16-byte result is read without waiting for the backward pass
-            g_samples, g_rays = sharding.allreduce_counts_end(pending)
-        if g_samples > 0:
-            state["num_rays"] = max(int((g_rays / world_size) * (TARGET_SAMPLES / (g_samples / world_size))), 64)
-        if overlap and (step + 1) % 16 != 0:
+            g = sharding.allreduce_counts_end(pending)
+        next_num_rays(*g)
+        if (step + 1) % 16 != 0:
             state["proposal"] = propose(state["num_rays"], wait_for_main=False)
         stats["rays"] += n
         stats["samples"] += n_samples
         state["step"] += 1
 
+    steps = {"api": step_api, "overlap": step_overlap}
+
+    def timed_region(step_fn, n_steps, with_timer):
+        """barrier + synchronize, exactly n_steps steps, synchronize + barrier; max over ranks"""
+        timer = None
+        if with_timer:
+            timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill"))
+            _backend.set_kernel_timer(timer)
+        stats.update(rays=0, samples=0)
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step_fn()
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        _backend.set_kernel_timer(None)
+        tot = torch.tensor([elapsed, float(stats["rays"]), float(stats["samples"])], dtype=torch.float64, device=device)
+        if world_size > 1:
+            mx = tot.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            elapsed = mx[0].item()
+        return dict(elapsed=elapsed, rays=tot[1].item(), samples=tot[2].item(), timer=timer,
+                    local_rays=stats["rays"], local_samples=stats["samples"])
+
+    # ---- untimed: train from fog into the steady state, then warm up the loop that is timed ---------------------------
+    t_pre = time.perf_counter()
+    for _ in range(args.pretrain):
+        step_api()
+    torch.cuda.synchronize()
+    pretrain_s = time.perf_counter() - t_pre
+    state["step"] = max(state["step"], 1024)             # past the grid's warm-up phase (occ_grid.py:372-376) whatever --pretrain was
+    state["step"] += (-state["step"]) % 16 + 1           # the timed region starts one step after a grid refresh
     for _ in range(args.warmup):
-        train_step()
+        steps[args.mode]()
+    main_run = timed_region(steps[args.mode], args.steps, with_timer=True)
+    state.pop("proposal", None)
 
-    timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill"))
-    _backend.set_kernel_timer(timer)
-    stats.update(rays=0, samples=0)
-    if world_size > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        train_step()
-    torch.cuda.synchronize()
-    if world_size > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    _backend.set_kernel_timer(None)
+    other = None
+    if not args.no_other_mode:
+        other_mode = "overlap" if args.mode == "api" else "api"
+        for _ in range(min(args.warmup, 10)):
+            steps[other_mode]()
+        other = (other_mode, timed_region(steps[other_mode], args.steps, with_timer=False))
+        state.pop("proposal", None)
 
-    tot = torch.tensor([elapsed, float(stats["rays"]), float(stats["samples"])], dtype=torch.float64, device=device)
-    if world_size > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = mx[0].item()
-    total_rays, total_samples = tot[1].item(), tot[2].item()
+    prof = None
+    if not args.no_profile and world_size == 1:
+        for _ in range(3):
+            steps[args.mode]()
+        prof = profile_steps(steps[args.mode], min(args.steps, 32))
+        state.pop("proposal", None)
 
     if rank == 0:
-        # roofline of the dominant kernel of OUR path (profiles/): the traversal count pass
-        # (traverse_count_split_kernel at this ray count), one launch per step, timed with HIP
-        # events on the launch stream around its single-kernel C-ABI call; the emit pass
-        # (traverse_emit_kernel) is timed the same way and its time is charged too, because the
-        # algorithmic bytes below are those of the whole sampling traversal:
-        # 16 B per emitted candidate sample (ray_indices i64 + t_starts + t_ends) + 48 B per ray
-        # (origin, direction, near, far, start, count) + the grid once — at the size this
-        # implementation reads it (V/8 bytes bit-packed instead of V bool bytes).
-        summ = timer.summary()
+        elapsed = main_run["elapsed"]
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the dominant kernel of OUR path (profiles/): the sampling traversal — count pass
+        # (traverse_count_split_kernel at this ray count) + emit pass (traverse_emit_kernel), one launch each per
+        # step, timed live with HIP events on the launch stream around their single-kernel C-ABI calls.
+        # Algorithmic bytes (SURVEY.md 8d): 16 B per emitted candidate sample (ray_indices i64 + t_starts + t_ends)
+        # + 48 B per ray + the grid once, G*V bool bytes as the API hands it over.
+        summ = main_run["timer"].summary()
         n_launch, ms_count = summ.get("traverse_count", (0, 0.0))
         _, ms_emit = summ.get("traverse_fill", (0, 0.0))
         ms = ms_count + ms_emit
-        rays_per_launch = stats["rays"] / max(args.steps, 1)
+        rays_per_launch = main_run["local_rays"] / max(args.steps, 1)
         with torch.no_grad():
             idx = torch.randint(0, args.pool, (int(rays_per_launch),), device=device)
             cand = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
-        alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + args.occ_res**3 / 8
+            walk = dda_steps(pool_o[idx], pool_d[idx], est.aabbs[0], args.occ_res, 0.0, 1e10)
+        alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roof = {
+            "kernel": "traverse_count_split_kernel + traverse_emit_kernel (the sampling traversal)",
+            "bound": "issue/latency", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": None,
+            "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "candidate_samples_per_sec_of_kernel_time": cand / (ms * 1e-3) if ms > 0 else 0.0,
+            "dda_steps_per_launch": walk, "dda_steps_per_sec_of_kernel_time": walk / (ms_count * 1e-3) if ms_count > 0 else 0.0,
+            "note": "a dependent voxel walk over an LDS-resident bit-packed grid: ~16 B of HBM traffic per sample, so the HBM fraction is small "
+                    "by construction; the bound is instruction issue / latency (roofline.issue), the figures of merit are candidate samples/s "
+                    "and DDA steps/s of kernel time.  The HBM-streaming kernels of the path are measured at N >= 2^24 in profiles/.",
+        }
+        # counter-based figures come from a committed rocprofv3 --pmc run of THIS workload (tools/pmc_bench.py); they are
+        # attached only when that run's ray count is within 15 % of this run's
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traverse.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if abs(pmc["rays_per_launch"] - rays_per_launch) <= 0.15 * rays_per_launch:
+                    roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r02_pmc_traverse.json (rocprofv3 --pmc, separate passes; %d rays/launch)" % pmc["rays_per_launch"]
+                    if "issue" in pmc:
+                        roof["issue"] = pmc["issue"]
+            except Exception:      # noqa: BLE001
+                pass
         out = {
             "metric": "training rays/sec (+ samples/sec), NGP+OccGrid Lego 800x800",
-            "value": total_rays / elapsed,
+            "value": main_run["rays"] / elapsed,
             "unit": "rays/s",
-            "samples_per_sec": total_samples / elapsed,
+            "samples_per_sec": main_run["samples"] / elapsed,
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if fixed_rays else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"configs[1] lego stand-in: procedural lego-like scene, 100 cams 800x800, {args.occ_res}^3 OccGrid on aabb +-1.5, "
-                            "render_step 5e-3, ~2^18 rendered samples/iter/GPU, torch dense-grid field (tiny-cuda-nn absent)",
+                            "render_step 5e-3, " + (f"{args.rays_per_iter} rays/iter global (configs[3])" if fixed_rays else "~2^18 rendered samples/iter/GPU")
+                            + ", torch dense-grid field (tiny-cuda-nn absent)",
+                "loop": args.mode + (" (reference examples' step through the public API)" if args.mode == "api" else " (next step's traversal on a side stream)"),
+                "pretrain_steps": args.pretrain, "pretrain_seconds": round(pretrain_s, 2),
                 "rays_per_iter_per_gpu": rays_per_launch,
-                "samples_per_iter_per_gpu": stats["samples"] / max(args.steps, 1),
+                "samples_per_iter_per_gpu": main_run["local_samples"] / max(args.steps, 1),
+                "samples_per_ray": main_run["samples"] / max(main_run["rays"], 1),
                 "candidate_samples_per_iter": cand,
-                "parallelism": f"rays sharded over {world_size} GPU(s), 1 flat grad all-reduce/step",
+                "occupied_fraction": est.binaries.float().mean().item(),
+                "parallelism": f"rays sharded over {world_size} GPU(s)" + (f", gradient all-reduce in {args.grad_chunks} async chunks overlapped with Adam" if world_size > 1 else ""),
             },
-            "roofline": {
-                "kernel": "traverse_count_split_kernel (+ traverse_emit_kernel)", "bound": "hbm", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                # HBM bytes per sampling call from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-                # passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; profiles/r01_pmc_traffic.md:
-                # 7.97 MB at 13 120 rays / 328 k candidates = 1.30 x the algorithmic bytes of that call), scaled
-                # to this run's algorithmic bytes
-                "traffic": 1.30 * alg_bytes,
-                "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "candidate_samples_per_sec_of_kernel_time": cand / (ms * 1e-3) if ms > 0 else 0.0,
-                "note": "issue/latency-bound voxel walk: 16 B per sample from an LDS-resident grid, HBM fraction is small "
-                        "by construction (DESIGN.md 3.2); the HBM-streaming kernels of the path reach 3.4-5.5 TB/s at N >= 2^24 "
-                        "(profiles/r01_roofline_streaming.md)",
-            },
+            "roofline": roof,
         }
+        if other is not None:
+            name, r = other
+            out["other_loop"] = {"loop": name, "ms_per_step": r["elapsed"] / args.steps * 1e3, "rays_per_sec": r["rays"] / r["elapsed"],
+                                 "samples_per_sec": r["samples"] / r["elapsed"]}
+        if prof is not None:
+            if "error" in prof:
+                out["gpu_activity"] = prof
+            else:
+                out["path_us_per_step"] = prof["nfa_us_per_step"]
+                out["gpu_idle_frac"] = max(0.0, 1.0 - prof["busy_us_per_step"] / (ms_per_step * 1e3))
+                out["gpu_activity"] = prof
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(field, est, pool_o, pool_d)
         print(json.dumps(out))

@@ -6,9 +6,11 @@ GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU f
 every rank holds a full replica of the radiance field and of the OccGridEstimator, draws its
 own 1/world of the ray batch, and the only exchange per step is
 
-  * ONE all-reduce (average) of the radiance-field gradients, issued as a single flat fp32
-    bucket (the NGP field is ~12 M parameters = 49 MB; xGMI is point-to-point, 7 links x
-    ~153 GB/s per GPU, so one large message beats many small ones), and
+  * the all-reduce (average) of the radiance-field gradients: one flat fp32 buffer (the NGP field is
+    ~12 M parameters = 49 MB), either as ONE message (`allreduce_gradients`) or — `ExchangeAdam` — cut
+    into a few multi-MB chunks that are reduced asynchronously while the optimizer already updates the
+    chunks that have arrived (xGMI is point-to-point, 7 links x ~153 GB/s per GPU: chunks stay large
+    enough to run at link bandwidth, few enough that launch latency does not add up), and
   * one all-reduce (sum) of two int64 scalars — rendered samples and rays of the step — so that
     every rank derives the same next ray-batch size (train_ngp_nerf_occ.py:187-194).
 
@@ -105,6 +107,79 @@ def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
         pending.buf.record_stream(torch.cuda.current_stream(pending.buf.device))
     s, r = pending.buf.tolist()
     return s, r
+
+
+class ExchangeAdam:
+    """Adam over ONE flat fp32 parameter buffer with the gradient exchange folded in: the flat gradient is cut
+    into `n_chunks` contiguous chunks, every chunk's all-reduce is started at once (async), and the Adam update
+    of chunk k runs as soon as chunk k has arrived — while chunks k+1.. are still on the wire.  With one
+    rank (or no process group) it is a plain chunked Adam.  Same update rule as torch.optim.Adam
+    (L2 weight decay added to the gradient, bias correction, eps outside the square root).
+
+    `params`: parameters whose storage is packed into the flat buffer (their .data / .grad become views of
+    it, so autograd accumulates straight into the exchange buffer: no staging copies)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-2, betas=(0.9, 0.999), eps=1e-15,
+                 weight_decay=0.0, n_chunks: int = 4, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params and all(p.dtype == torch.float32 for p in self.params)
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p.data)
+            p.grad = self.grad[off:off + k].view_as(p.data)
+            off += k
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.lr, self.betas, self.eps, self.weight_decay, self.average = lr, betas, eps, weight_decay, average
+        self.t = 0
+        n_chunks = max(1, min(int(n_chunks), total))
+        size = -(-total // n_chunks)
+        size = -(-size // 1024) * 1024                      # chunk starts stay 4 KiB aligned
+        self.bounds = [(a, min(a + size, total)) for a in range(0, total, size)]
+        self.step_tensor = torch.zeros((), dtype=torch.float32, device=dev)
+        self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def _adam(self, a: int, b: int) -> None:
+        p, g, m, v = self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b]
+        b1, b2 = self.betas
+        if self._fused:
+            # one launch per chunk; state_steps holds the step count BEFORE the update
+            step = self.step_tensor.clone()
+            torch._fused_adam_([p], [g], [m], [v], [], [step], lr=self.lr, beta1=b1, beta2=b2,
+                               weight_decay=self.weight_decay, eps=self.eps, amsgrad=False, maximize=False)
+            return
+        if self.weight_decay:
+            g = g.add(p, alpha=self.weight_decay)
+        m.lerp_(g, 1.0 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        bc1, bc2 = 1.0 - b1**self.t, 1.0 - b2**self.t
+        denom = (v.sqrt() / (bc2**0.5)).add_(self.eps)
+        p.addcdiv_(m, denom, value=-self.lr / bc1)
+
+    def step(self) -> None:
+        """all-reduce (average) the flat gradient chunk by chunk and update every chunk as it arrives"""
+        rank, ws = world()
+        self.t += 1
+        works = []
+        if ws > 1:
+            for a, b in self.bounds:
+                works.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        for k, (a, b) in enumerate(self.bounds):
+            if works:
+                works[k].wait()                              # the current stream waits for this chunk only
+                if self.average:
+                    self.grad[a:b].div_(ws)
+            self._adam(a, b)
+        self.step_tensor += 1
 
 
 def broadcast_grid(estimator, src: int = 0) -> None:

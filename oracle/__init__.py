@@ -10,9 +10,13 @@ mask compaction).
 
 Parity status: pinned against the golden fixtures in ``tests/golden`` (made by
 ``tests/golden/make_golden.py`` from the importable, pure-torch parts of the
-reference) and the reference tests' hand-computed answers.  The exact sample
-lists of ``traverse_grids`` have no reference fixture: "parity unpinned by the
-reference's tests" for that item.
+reference), the reference tests' hand-computed answers, and — for the exact
+sample lists of ``traverse_grids`` — ``tests/golden/k2_reference.npz``, produced
+by the reference's own ``grid.cu`` compiled for the host (``oracle/ref_shim`` ->
+``oracle/_ref``, see ``tests/golden/make_k2_golden.py`` and DESIGN.md §3.4/§4).
+
+``oracle.torch_cpu`` holds the pure-PyTorch CPU composition of the rendering ops
+(the reference's batched branch), timed by bench.py's ``cpu_baseline`` leg.
 """
 from __future__ import annotations
 
@@ -42,6 +46,13 @@ def lib() -> ctypes.CDLL:
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
     return _lib
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads used by the traversal / rendering entry points (default 1: the checker is scalar and
+    single-threaded; bench.py's all-cores CPU baseline raises it).  Results do not depend on it."""
+    lib().orc_set_threads(int(n))
+    return int(lib().orc_get_threads())
 
 
 # ---------------------------------------------------------------- helpers
@@ -180,6 +191,34 @@ def sampling(rays_o, rays_d, binaries, aabbs, near_plane=0.0, far_plane=1e10, t_
         keep = visibility(trans, alphas, early_stop_eps, alpha_thre)
         ray_indices, t_starts, t_ends = ray_indices[keep], t_starts[keep], t_ends[keep]
     return ray_indices, t_starts, t_ends, sm["packed_info"]
+
+
+def sample_occgrid(rays_o, rays_d, binaries, aabbs, near, far, step_size, cone_angle=0.0):
+    """traverse_grids + the two boolean-mask gathers of occ_grid.py:174-176 with the gathers done per ray in C
+    (threaded when set_threads > 1): (ray_indices, t_starts, t_ends, packed_info).  Equal to
+    `traverse_grids` followed by `vals[is_left]`, `vals[is_right]` (tests/test_oracle.py)."""
+    iv, sm, _ = traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, step_size, cone_angle)
+    n = sm["ray_indices"].shape[0]
+    ts, te = np.empty(n, np.float32), np.empty(n, np.float32)
+    lib().orc_intervals_to_samples(_c_i64(iv["chunk_cnts"].shape[0]), _p(_i64(iv["chunk_starts"])), _p(_i64(iv["chunk_cnts"])),
+                                   _p(iv["vals"]), _p(_u8(iv["is_left"])), _p(_u8(iv["is_right"])),
+                                   _p(_i64(sm["chunk_starts"])), _p(ts), _p(te))
+    return sm["ray_indices"], ts, te, sm["packed_info"]
+
+
+def compact(keep, ray_indices, t_starts, t_ends, packed_info):
+    """x = x[keep] for the three sample arrays (occ_grid.py:218-220), per ray in C; returns the new packed_info too"""
+    keep = _u8(keep)
+    starts, cnts = _i64(packed_info[:, 0]), _i64(packed_info[:, 1])
+    R = starts.shape[0]
+    kept = np.empty(R, np.int64)
+    lib().orc_count_kept(_c_i64(R), _p(starts), _p(cnts), _p(keep), _p(kept))
+    out_starts = np.cumsum(kept) - kept
+    n = int(kept.sum())
+    ri, ts, te = np.empty(n, np.int64), np.empty(n, np.float32), np.empty(n, np.float32)
+    lib().orc_compact_samples(_c_i64(R), _p(starts), _p(cnts), _p(keep), _p(out_starts), _p(_i64(ray_indices)),
+                              _p(_f32(t_starts)), _p(_f32(t_ends)), _p(ri), _p(ts), _p(te))
+    return ri, ts, te, np.stack([out_starts, kept], -1)
 
 
 # ---------------------------------------------------------------- pack / scans

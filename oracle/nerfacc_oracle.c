@@ -21,11 +21,18 @@
  *     v_cvt_i32_f32 / CUDA's cvt.rzi.s32.f32 (x86's cvttss2si does not).
  *
  * Pinned against: the tests/golden/ fixtures (generated from the importable parts
- * of the Python reference by tests/golden/make_golden.py) and the hand-computed
- * known answers in the reference's tests.  The exact
- * per-ray sample lists of traverse_grids have NO reference fixture ("parity
- * unpinned by the reference's tests"): they are pinned by property tests and by
- * the pure-torch _query / _ray_aabb_intersect twins only.
+ * of the Python reference by tests/golden/make_golden.py), the hand-computed
+ * known answers in the reference's tests, and — for the
+ * exact per-ray sample lists of traverse_grids, which the reference's tests hold
+ * no vector for — tests/golden/k2_reference.npz: outputs of the reference's OWN
+ * grid.cu compiled for the host (oracle/ref_shim -> oracle/_ref) and driven through
+ * the reference's Python layer (tests/golden/make_k2_golden.py).  14 cases,
+ * 10.2 M samples, bit for bit (tests/test_k2_reference.py).
+ *
+ * Threads: every entry point is single-threaded unless orc_set_threads(n > 1) was
+ * called (bench.py's all-cores CPU baseline does).  Rays are independent, so the
+ * parallel forms split the ray range (or the sample range at ray boundaries) and
+ * run the same scalar code per part: results do not depend on the thread count.
  */
 #include <math.h>
 #include <stdint.h>
@@ -33,6 +40,24 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
+
+static int orc_threads = 1;
+ORC_API void orc_set_threads(int n) { orc_threads = n > 1 ? n : 1; }
+ORC_API int orc_get_threads(void) { return orc_threads; }
+
+/* cut [0, n) into `parts` ranges of about equal size whose boundaries fall on ray boundaries
+ * (keys[i] != keys[i-1]); bounds has parts + 1 entries */
+static void orc_split(int64_t n, const int64_t *keys, int parts, int64_t *bounds)
+{
+    bounds[0] = 0;
+    for (int p = 1; p < parts; ++p) {
+        int64_t i = n * p / parts;
+        if (i < bounds[p - 1]) i = bounds[p - 1];
+        while (i > 0 && i < n && keys[i] == keys[i - 1]) ++i;
+        bounds[p] = i;
+    }
+    bounds[parts] = n;
+}
 
 /* ------------------------------------------------------------------ */
 /* small helpers                                                        */
@@ -272,6 +297,7 @@ ORC_API void orc_traverse_count(
     int64_t *iv_cnts, int64_t *sm_cnts, float *terminate_planes)
 {
     const int r3[3] = {res[0], res[1], res[2]};
+#pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
     for (int64_t r = 0; r < n_rays; ++r) {
         if (rays_mask && !rays_mask[r]) continue;
         int64_t a = 0, b = 0;
@@ -299,6 +325,7 @@ ORC_API void orc_traverse_fill(
 {
     const int r3[3] = {res[0], res[1], res[2]};
     orc_emit_t e = {iv_vals, iv_ray, iv_left, iv_right, sm_vals, sm_ray, sm_valid};
+#pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
     for (int64_t r = 0; r < n_rays; ++r) {
         if (rays_mask && !rays_mask[r]) continue;
         if (iv_cnts && iv_cnts[r] == 0) continue;
@@ -310,6 +337,53 @@ ORC_API void orc_traverse_fill(
                      iv_cnts ? &a : NULL, &b, terminate_planes ? terminate_planes + r : NULL);
         if (iv_cnts) iv_cnts[r] = a;
         if (sm_cnts) sm_cnts[r] = b;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Mask compactions of OccGridEstimator.sampling, occ_grid.py:174-176     */
+/* (t_starts = vals[is_left], t_ends = vals[is_right]) and :218-220       */
+/* (x = x[masks]) — in the reference these are torch boolean-mask         */
+/* gathers; here one loop over rays so that the all-cores baseline of     */
+/* bench.py has no serial numpy pass in it.  Same results as the gathers. */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_intervals_to_samples(
+    int64_t n_rays, const int64_t *iv_starts, const int64_t *iv_cnts, const float *iv_vals,
+    const uint8_t *iv_left, const uint8_t *iv_right, const int64_t *sm_starts,
+    float *t_starts, float *t_ends)
+{
+#pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int64_t a = sm_starts[r], b = sm_starts[r];
+        for (int64_t k = iv_starts[r]; k < iv_starts[r] + iv_cnts[r]; ++k) {
+            if (iv_left[k]) t_starts[a++] = iv_vals[k];
+            if (iv_right[k]) t_ends[b++] = iv_vals[k];
+        }
+    }
+}
+
+/* kept[r] = number of samples of ray r with keep != 0 */
+ORC_API void orc_count_kept(int64_t n_rays, const int64_t *starts, const int64_t *cnts, const uint8_t *keep, int64_t *kept)
+{
+#pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int64_t c = 0;
+        for (int64_t k = starts[r]; k < starts[r] + cnts[r]; ++k) c += keep[k] != 0;
+        kept[r] = c;
+    }
+}
+
+/* out_starts = exclusive sum of the kept counts (caller); stable per-ray scatter of the survivors */
+ORC_API void orc_compact_samples(
+    int64_t n_rays, const int64_t *starts, const int64_t *cnts, const uint8_t *keep, const int64_t *out_starts,
+    const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+    int64_t *o_ray_indices, float *o_t_starts, float *o_t_ends)
+{
+#pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int64_t o = out_starts[r];
+        for (int64_t k = starts[r]; k < starts[r] + cnts[r]; ++k)
+            if (keep[k]) { o_ray_indices[o] = ray_indices[k]; o_t_starts[o] = t_starts[k]; o_t_ends[o] = t_ends[k]; ++o; }
     }
 }
 
@@ -374,13 +448,34 @@ ORC_API void orc_scan_keyed(
 /* ------------------------------------------------------------------ */
 
 /* transmittance / alpha / weight from density; prefix_trans optional */
+static void weight_from_density_range(
+    int64_t b0, int64_t b1, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+    const float *sigmas, const float *prefix_trans, float *weights, float *trans, float *alphas);
+
 ORC_API void orc_render_weight_from_density(
     int64_t n, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
     const float *sigmas, const float *prefix_trans, float *weights, float *trans, float *alphas)
 {
+    if (orc_threads > 1 && n > 4096) {
+        const int P = orc_threads;
+        int64_t *bounds = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1));
+        orc_split(n, ray_indices, P, bounds);
+#pragma omp parallel for schedule(static, 1) num_threads(P)
+        for (int p = 0; p < P; ++p)
+            weight_from_density_range(bounds[p], bounds[p + 1], ray_indices, t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas);
+        free(bounds);
+        return;
+    }
+    weight_from_density_range(0, n, ray_indices, t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas);
+}
+
+static void weight_from_density_range(
+    int64_t b0, int64_t b1, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+    const float *sigmas, const float *prefix_trans, float *weights, float *trans, float *alphas)
+{
     float acc = 0.0f;
-    for (int64_t i = 0; i < n; ++i) {
-        if (i == 0 || ray_indices[i] != ray_indices[i - 1]) acc = 0.0f;
+    for (int64_t i = b0; i < b1; ++i) {
+        if (i == b0 || ray_indices[i] != ray_indices[i - 1]) acc = 0.0f;
         const float sd = sigmas[i] * (t_ends[i] - t_starts[i]);
         const float a = 1.0f - expf(-sd);
         float T = expf(-acc);
@@ -395,31 +490,49 @@ ORC_API void orc_render_weight_from_density(
 /* gradient of sum_i (gw_i w_i + gT_i T_i + ga_i a_i) w.r.t. sigma.
  * Derived from volrend.py:271-278 (T = exp(-excl_sum(sd)) * prefix,
  * a = 1 - exp(-sd), w = T a) — what autograd produces for the reference. */
+static void weight_from_density_bwd_range(
+    int64_t b0, int64_t b1, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+    const float *sigmas, const float *prefix_trans,
+    const float *g_w, const float *g_T, const float *g_a, float *g_sigmas)
+{
+    /* forward recompute in double to keep the oracle's own error negligible */
+    const int64_t n = b1 - b0;
+    if (n <= 0) return;
+    double *T = (double *)malloc(sizeof(double) * (size_t)n);
+    double acc = 0.0;
+    for (int64_t i = b0; i < b1; ++i) {
+        if (i == b0 || ray_indices[i] != ray_indices[i - 1]) acc = 0.0;
+        T[i - b0] = exp(-acc) * (prefix_trans ? (double)prefix_trans[i] : 1.0);
+        acc += (double)sigmas[i] * ((double)t_ends[i] - (double)t_starts[i]);
+    }
+    double suffix = 0.0;
+    for (int64_t i = b1 - 1; i >= b0; --i) {
+        if (i == b1 - 1 || ray_indices[i] != ray_indices[i + 1]) suffix = 0.0;
+        const double dt = (double)t_ends[i] - (double)t_starts[i];
+        const double sd = (double)sigmas[i] * dt;
+        const double one_m_a = exp(-sd), a = 1.0 - one_m_a;
+        const double Ti = T[i - b0];
+        const double gw = g_w ? g_w[i] : 0.0, gT = g_T ? g_T[i] : 0.0, ga = g_a ? g_a[i] : 0.0;
+        const double g_sd = (gw * Ti + ga) * one_m_a - suffix;
+        g_sigmas[i] = (float)(g_sd * dt);
+        suffix += gw * Ti * a + gT * Ti;
+    }
+    free(T);
+}
+
 ORC_API void orc_render_weight_from_density_bwd(
     int64_t n, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
     const float *sigmas, const float *prefix_trans,
     const float *g_w, const float *g_T, const float *g_a, float *g_sigmas)
 {
-    /* forward recompute in double to keep the oracle's own error negligible */
-    double *T = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    double acc = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (i == 0 || ray_indices[i] != ray_indices[i - 1]) acc = 0.0;
-        T[i] = exp(-acc) * (prefix_trans ? (double)prefix_trans[i] : 1.0);
-        acc += (double)sigmas[i] * ((double)t_ends[i] - (double)t_starts[i]);
-    }
-    double suffix = 0.0;
-    for (int64_t i = n - 1; i >= 0; --i) {
-        if (i == n - 1 || ray_indices[i] != ray_indices[i + 1]) suffix = 0.0;
-        const double dt = (double)t_ends[i] - (double)t_starts[i];
-        const double sd = (double)sigmas[i] * dt;
-        const double one_m_a = exp(-sd), a = 1.0 - one_m_a;
-        const double gw = g_w ? g_w[i] : 0.0, gT = g_T ? g_T[i] : 0.0, ga = g_a ? g_a[i] : 0.0;
-        const double g_sd = (gw * T[i] + ga) * one_m_a - suffix;
-        g_sigmas[i] = (float)(g_sd * dt);
-        suffix += gw * T[i] * a + gT * T[i];
-    }
-    free(T);
+    const int P = (orc_threads > 1 && n > 4096) ? orc_threads : 1;
+    int64_t *bounds = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1));
+    orc_split(n, ray_indices, P, bounds);
+#pragma omp parallel for schedule(static, 1) num_threads(P) if (P > 1)
+    for (int p = 0; p < P; ++p)
+        weight_from_density_bwd_range(bounds[p], bounds[p + 1], ray_indices, t_starts, t_ends, sigmas, prefix_trans,
+                                      g_w, g_T, g_a, g_sigmas);
+    free(bounds);
 }
 
 /* from alphas: T = exclusive_prod(1 - a) (* prefix); volrend.py:167-216, 281-323 */
@@ -443,6 +556,7 @@ ORC_API void orc_visibility(
     int64_t n, const float *trans, const float *alphas, float early_stop_eps, float alpha_thre,
     uint8_t *vis)
 {
+#pragma omp parallel for schedule(static) num_threads(orc_threads) if (orc_threads > 1 && n > 4096)
     for (int64_t i = 0; i < n; ++i) {
         int v = trans[i] >= early_stop_eps;
         if (alpha_thre > 0.0f) v = v && (alphas[i] >= alpha_thre);
@@ -476,14 +590,22 @@ ORC_API void orc_rendering(
     memset(colors, 0, sizeof(float) * 3 * (size_t)n_rays);
     memset(opacities, 0, sizeof(float) * (size_t)n_rays);
     memset(depths, 0, sizeof(float) * (size_t)n_rays);
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t r = ray_indices[i];
-        const float w = weights[i];
-        for (int c = 0; c < 3; ++c) colors[3 * r + c] += w * rgbs[3 * i + c];
-        opacities[r] += w;
-        depths[r] += w * ((t_starts[i] + t_ends[i]) / 2.0f);
-    }
+    /* parts end on ray boundaries, so no two parts add into the same ray (sorted ray_indices, as everywhere here) */
+    const int P = (orc_threads > 1 && n > 4096) ? orc_threads : 1;
+    int64_t *bounds = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P + 1));
+    orc_split(n, ray_indices, P, bounds);
+#pragma omp parallel for schedule(static, 1) num_threads(P) if (P > 1)
+    for (int p = 0; p < P; ++p)
+        for (int64_t i = bounds[p]; i < bounds[p + 1]; ++i) {
+            const int64_t r = ray_indices[i];
+            const float w = weights[i];
+            for (int c = 0; c < 3; ++c) colors[3 * r + c] += w * rgbs[3 * i + c];
+            opacities[r] += w;
+            depths[r] += w * ((t_starts[i] + t_ends[i]) / 2.0f);
+        }
+    free(bounds);
     const float eps = 1.1920928955078125e-07f; /* torch.finfo(float32).eps */
+#pragma omp parallel for schedule(static) num_threads(orc_threads) if (orc_threads > 1 && n_rays > 4096)
     for (int64_t r = 0; r < n_rays; ++r) {
         if (expected_depths) depths[r] = depths[r] / fmaxf(opacities[r], eps);
         if (bkgd) for (int c = 0; c < 3; ++c) colors[3 * r + c] += bkgd[c] * (1.0f - opacities[r]);

@@ -290,3 +290,78 @@ def test_grid_maintenance_replays_reference_update(golden):
         binaries, _ = oracle.grid_threshold(occs, 0.01)
     np.testing.assert_array_equal(occs, golden["upd_occs"])
     assert np.array_equal(np.packbits(binaries), golden["upd_bin"])
+
+
+def test_threaded_oracle_equals_scalar_oracle():
+    """orc_set_threads only changes who does the work (bench.py's all-cores CPU baseline)"""
+    import k2_cases as K
+
+    c = K.build_case("lego_4k")
+    a = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], **c["kw"])
+    rng = np.random.default_rng(0)
+    iv, sm, _ = a
+    ts, te, ri = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], sm["ray_indices"]
+    sig = (rng.random(ts.shape[0]) * 20).astype(np.float32)
+    rgb = rng.random((ts.shape[0], 3)).astype(np.float32)
+    gw = rng.standard_normal(ts.shape[0]).astype(np.float32)
+    one = (oracle.rendering(ts, te, ri, 4096, sig, rgb, np.ones(3, np.float32)),
+           oracle.render_weight_from_density_bwd(ts, te, sig, ri, g_w=gw))
+    try:
+        assert oracle.set_threads(4) == 4
+        b = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], **c["kw"])
+        many = (oracle.rendering(ts, te, ri, 4096, sig, rgb, np.ones(3, np.float32)),
+                oracle.render_weight_from_density_bwd(ts, te, sig, ri, g_w=gw))
+    finally:
+        oracle.set_threads(1)
+    for x, y in zip(a[:2], b[:2]):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(one[0][:3], many[0][:3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(one[0][3]["weights"], many[0][3]["weights"]) and np.array_equal(one[1], many[1])
+
+
+def test_pure_torch_cpu_composition_matches_oracle():
+    """the pure-PyTorch CPU path timed by bench.py (oracle/torch_cpu.py) against the C oracle"""
+    import torch
+
+    import k2_cases as K
+    from oracle import torch_cpu
+
+    c = K.build_case("m1_sphere")
+    iv, sm, _ = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], **c["kw"])
+    ts, te, ri, pk = iv["vals"][iv["is_left"]], iv["vals"][iv["is_right"]], sm["ray_indices"], sm["packed_info"]
+    rng = np.random.default_rng(1)
+    sig = (rng.random(ts.shape[0]) * 20).astype(np.float32)
+    rgb = rng.random((ts.shape[0], 3)).astype(np.float32)
+    w, T, a = oracle.render_weight_from_density(ts, te, sig, ri)
+    tt = torch.from_numpy
+    (p_ts, p_te, p_sig), mask = torch_cpu.pad_rays(tt(pk), tt(ts), tt(te), tt(sig))
+    wb, Tb, ab = torch_cpu.weights_batched(p_ts, p_te, p_sig)
+    assert np.allclose(wb[mask].numpy(), w, atol=1e-5) and np.allclose(Tb[mask].numpy(), T, atol=1e-5)
+    wf, Tf, af = torch_cpu.weights_flat(tt(ts), tt(te), tt(sig), tt(ri), tt(pk))
+    assert np.allclose(wf.numpy(), w, atol=1e-5) and np.allclose(af.numpy(), a, atol=1e-6)
+    col, opa, dep, _ = oracle.rendering(ts, te, ri, 4096, sig, rgb, np.ones(3, np.float32))
+    c2, o2, d2, _ = torch_cpu.rendering_flat(tt(ts), tt(te), tt(sig), tt(rgb), tt(ri), tt(pk), 4096, torch.ones(3))
+    assert np.allclose(c2.numpy(), col, atol=1e-5) and np.allclose(o2.numpy(), opa, atol=1e-5)
+    assert np.allclose(d2.numpy(), dep, atol=1e-4)
+
+
+def test_threaded_glue_equals_mask_gathers():
+    import k2_cases as K
+
+    c = K.build_case("lego_4k")
+    R = c["rays_o"].shape[0]
+    near, far = np.zeros(R, np.float32), np.full(R, 1e10, np.float32)
+    iv, sm, _ = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], near, far, 5e-3)
+    try:
+        oracle.set_threads(3)
+        ri, ts, te, pk = oracle.sample_occgrid(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], near, far, 5e-3)
+        keep = np.random.default_rng(0).random(ri.shape[0]) < 0.6
+        ri2, ts2, te2, pk2 = oracle.compact(keep, ri, ts, te, pk)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(ri, sm["ray_indices"]) and np.array_equal(pk, sm["packed_info"])
+    assert np.array_equal(ts, iv["vals"][iv["is_left"]]) and np.array_equal(te, iv["vals"][iv["is_right"]])
+    assert np.array_equal(ri2, ri[keep]) and np.array_equal(ts2, ts[keep]) and np.array_equal(te2, te[keep])
+    assert np.array_equal(pk2, oracle.pack_info(ri2, R))
