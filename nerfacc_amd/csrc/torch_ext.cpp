@@ -1,0 +1,815 @@
+// torch_ext.cpp — the PyTorch-ROCm C++ extension in front of libnerfacc_hip.so (module `nerfacc_amd._hip`).
+//
+// Same role as the reference's pybind module `nerfacc.csrc` (nerfacc/cuda/csrc/nerfacc.cpp:126-163): the 21
+// names of that module with the same argument order, plus the fused entry points of this implementation.
+// The reference's functions take torch::Tensor, allocate their outputs from the caching allocator, launch on
+// the current stream under a device guard and block the host only where a size is needed (data_spec.hpp:91);
+// so do these.  All kernels live behind the C ABI of include/nerfacc_hip.h — this file is host plumbing only:
+// argument checks (CHECK_INPUT, utils_cuda.cuh:12-17), allocation, the readback of the few integers that size
+// an output, the cache of the bit-packed occupancy grid.  No CPU path: a host tensor is an error.
+#include <torch/extension.h>
+
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/nerfacc_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+inline void check_rc(int rc) {
+    TORCH_CHECK(rc == NFA_OK, "nerfacc_amd: ", nfa_last_error());
+}
+
+inline void check_input(const Tensor &t, const char *name, std::optional<at::ScalarType> dtype = std::nullopt) {
+    TORCH_CHECK(t.defined(), name, " is undefined");
+    TORCH_CHECK(t.is_cuda(), name, " must be a CUDA/HIP tensor (nerfacc_amd has no CPU kernels)");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+    if (dtype) TORCH_CHECK(t.scalar_type() == *dtype, name, " must have dtype ", *dtype, ", got ", t.scalar_type());
+}
+
+template <class T> inline T *ptr(const Tensor &t) { return t.defined() ? reinterpret_cast<T *>(t.data_ptr()) : nullptr; }
+template <class T> inline T *ptr(const OptTensor &t) { return (t && t->defined()) ? reinterpret_cast<T *>(t->data_ptr()) : nullptr; }
+
+inline hipStream_t stream_of(const Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+using Guard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
+
+inline at::TensorOptions opts(const Tensor &like, at::ScalarType dt) { return like.options().dtype(dt); }
+
+[[noreturn]] void raise_not_implemented(const char *msg) {
+    PyErr_SetString(PyExc_NotImplementedError, msg);
+    throw py::error_already_set();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optional HIP-event timing of named single-kernel calls (bench.py's live roofline measurement).  Events are
+// recorded on the stream the kernel is launched on; nothing is synchronised until timing_summary().
+// ---------------------------------------------------------------------------------------------------
+struct Timing {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::string> names;
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> records;
+} g_timing;
+
+struct Timed {
+    const char *name;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(const char *n, hipStream_t st) : name(n), s(st) {
+        if (!g_timing.on) return;
+        std::lock_guard<std::mutex> l(g_timing.mu);
+        bool want = false;
+        for (auto &x : g_timing.names) want |= (x == n);
+        if (!want) return;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, s);
+    }
+    ~Timed() {
+        if (!e0) return;
+        hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> l(g_timing.mu);
+        g_timing.records[name].emplace_back(e0, e1);
+    }
+};
+
+void set_timing(std::optional<std::vector<std::string>> names) {
+    std::lock_guard<std::mutex> l(g_timing.mu);
+    for (auto &kv : g_timing.records)
+        for (auto &p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    g_timing.records.clear();
+    g_timing.on = names.has_value();
+    g_timing.names = names.value_or(std::vector<std::string>{});
+}
+
+py::dict timing_summary() {
+    hipDeviceSynchronize();
+    std::lock_guard<std::mutex> l(g_timing.mu);
+    py::dict out;
+    for (auto &kv : g_timing.records) {
+        double total = 0.0;
+        for (auto &p : kv.second) { float ms = 0.f; hipEventElapsedTime(&ms, p.first, p.second); total += ms; }
+        const size_t n = kv.second.size();
+        out[py::str(kv.first)] = py::make_tuple(n, n ? total / n : 0.0);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host readback of the few integers a call needs (sample totals, kept counts): the kernels store them straight
+// into pinned host memory, so the readback is a stream wait plus a CPU load.  One slot per (device, stream,
+// host thread): the calls stay re-entrant across threads and streams like the reference's stateless functions.
+// ---------------------------------------------------------------------------------------------------
+int64_t *host_ints(int device, hipStream_t s) {
+    thread_local std::map<std::pair<int, hipStream_t>, int64_t *> slots;
+    auto key = std::make_pair(device, s);
+    auto it = slots.find(key);
+    if (it != slots.end()) return it->second;
+    int64_t *p = nullptr;
+    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+                "nerfacc_amd: hipHostMalloc failed");
+    for (int i = 0; i < 8; ++i) p[i] = 0;
+    if (slots.size() > 64) slots.clear();      // (slots of dead streams are leaked: 64 B each)
+    slots[key] = p;
+    return p;
+}
+
+inline void wait_stream(hipStream_t s) {
+    py::gil_scoped_release nogil;               // other Python threads may run while this one waits for its stream
+    TORCH_CHECK(hipStreamSynchronize(s) == hipSuccess, "nerfacc_amd: hipStreamSynchronize failed");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// occupancy bricks: packed once per distinct state of a `binaries` tensor (identity + in-place version)
+// ---------------------------------------------------------------------------------------------------
+struct BrickEntry {
+    c10::weak_intrusive_ptr<c10::TensorImpl> ref;
+    c10::TensorImpl *impl;
+    uint32_t version;
+    Tensor bricks;
+    int64_t nonempty;
+    hipStream_t stream;
+    hipEvent_t event;
+};
+std::mutex g_brick_mu;
+std::vector<BrickEntry> g_bricks;     // most recently used first
+constexpr size_t kBrickSlots = 4;
+
+// returns (bricks, number of non-empty bricks); reads the count back once per grid state
+std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) {
+    check_input(binaries, "binaries", at::kBool);
+    TORCH_CHECK(binaries.dim() == 4, "binaries must have shape [n_grids, resx, resy, resz]");
+    std::lock_guard<std::mutex> l(g_brick_mu);
+    hipStream_t s = stream_of(binaries);
+    c10::TensorImpl *impl = binaries.unsafeGetTensorImpl();
+    const uint32_t ver = binaries._version();
+    size_t hit = g_bricks.size();
+    for (size_t k = 0; k < g_bricks.size(); ++k) {
+        auto &c = g_bricks[k];
+        if (c.impl == impl && c.version == ver && !c.ref.expired()) { hit = k; break; }
+    }
+    if (hit == g_bricks.size()) {
+        const int G = (int)binaries.size(0), rx = (int)binaries.size(1), ry = (int)binaries.size(2), rz = (int)binaries.size(3);
+        const int64_t words = nfa_packed_grid_words(G, rx, ry, rz);
+        Tensor bricks = at::empty({words}, opts(binaries, at::kLong));
+        {
+            Guard g(device_of(binaries));
+            check_rc(nfa_pack_binaries(ptr<uint8_t>(binaries), G, rx, ry, rz, ptr<uint64_t>(bricks), s));
+        }
+        hipEvent_t ev;
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        hipEventRecord(ev, s);
+        // drop slots whose tensor is gone or is this tensor in an older state, then the oldest
+        std::vector<BrickEntry> keep;
+        for (auto &c : g_bricks) {
+            if (c.ref.expired() || c.impl == impl) { hipEventDestroy(c.event); continue; }
+            keep.push_back(std::move(c));
+        }
+        g_bricks = std::move(keep);
+        BrickEntry e{c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr()), impl, ver, bricks, -1, s, ev};
+        g_bricks.insert(g_bricks.begin(), std::move(e));
+        while (g_bricks.size() > kBrickSlots) { hipEventDestroy(g_bricks.back().event); g_bricks.pop_back(); }
+        hit = 0;
+    } else if (hit != 0) {
+        BrickEntry e = std::move(g_bricks[hit]);
+        g_bricks.erase(g_bricks.begin() + hit);
+        g_bricks.insert(g_bricks.begin(), std::move(e));
+        hit = 0;
+    }
+    auto &c = g_bricks[0];
+    if (c.stream != s) hipStreamWaitEvent(s, c.event, 0);      // packed on another stream: order this one after the pack
+    if (need_count && c.nonempty < 0) {
+        const int64_t nb = binaries.size(0) * ((binaries.size(1) + 3) / 4) * ((binaries.size(2) + 3) / 4) * ((binaries.size(3) + 3) / 4);
+        int64_t *h = host_ints(binaries.device().index(), s);
+        TORCH_CHECK(hipMemcpyAsync(h, ptr<int64_t>(c.bricks) + nb, sizeof(int64_t), hipMemcpyDeviceToHost, s) == hipSuccess,
+                    "nerfacc_amd: readback of the brick count failed");
+        wait_stream(s);
+        c.nonempty = h[0];
+    }
+    return {c.bricks, c.nonempty};
+}
+
+Tensor packed_bricks(const Tensor &binaries) { return brick_entry(binaries, true).first; }
+
+// ---------------------------------------------------------------------------------------------------
+// RaySegmentsSpec (data_spec.hpp:6-14; nerfacc.cpp:128-137): seven optional tensors
+// ---------------------------------------------------------------------------------------------------
+struct RaySegmentsSpec {
+    OptTensor vals, is_left, is_right, is_valid, chunk_starts, chunk_cnts, ray_indices;
+
+    void check() const {      // data_spec.hpp:15-51
+        TORCH_CHECK(vals.has_value(), "RaySegmentsSpec.vals is not set");
+        check_input(*vals, "vals", at::kFloat);
+        if (vals->dim() > 1) return;
+        TORCH_CHECK(chunk_starts && chunk_cnts, "flattened RaySegmentsSpec needs chunk_starts and chunk_cnts");
+        check_input(*chunk_starts, "chunk_starts", at::kLong);
+        check_input(*chunk_cnts, "chunk_cnts", at::kLong);
+        TORCH_CHECK(chunk_starts->dim() == 1 && chunk_cnts->dim() == 1, "chunk_starts / chunk_cnts must be 1-D");
+        TORCH_CHECK(chunk_starts->numel() == chunk_cnts->numel(), "chunk_starts and chunk_cnts differ in length");
+        auto same = [&](const OptTensor &t, const char *n, at::ScalarType dt) {
+            if (!t) return;
+            check_input(*t, n, dt);
+            TORCH_CHECK(t->dim() == 1 && t->numel() == vals->numel(), n, " must be 1-D with as many elements as vals");
+        };
+        same(ray_indices, "ray_indices", at::kLong);
+        same(is_left, "is_left", at::kBool);
+        same(is_right, "is_right", at::kBool);
+        same(is_valid, "is_valid", at::kBool);
+    }
+
+    nfa_ray_segments view() const {
+        nfa_ray_segments s{};
+        s.vals = ptr<float>(vals);
+        s.n_edges = vals->numel();
+        if (vals->dim() > 1) {
+            s.n_edges_per_ray = vals->size(-1);
+            s.n_rays = vals->numel() / std::max<int64_t>(vals->size(-1), 1);
+        } else {
+            s.chunk_starts = ptr<int64_t>(chunk_starts);
+            s.chunk_cnts = ptr<int64_t>(chunk_cnts);
+            s.ray_indices = ptr<int64_t>(ray_indices);
+            s.n_rays = chunk_cnts->numel();
+        }
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// grid
+// ---------------------------------------------------------------------------------------------------
+std::vector<Tensor> ray_aabb_intersect(const Tensor &rays_o, const Tensor &rays_d, const Tensor &aabbs, double near_plane,
+                                       double far_plane, double miss_value) {   // nerfacc.cpp:63-69
+    check_input(rays_o, "rays_o", at::kFloat);
+    check_input(rays_d, "rays_d", at::kFloat);
+    check_input(aabbs, "aabbs", at::kFloat);
+    const int64_t R = rays_o.size(0), G = aabbs.size(0);
+    Tensor t_mins = at::empty({R, G}, rays_o.options()), t_maxs = at::empty({R, G}, rays_o.options());
+    Tensor hits = at::empty({R, G}, opts(rays_o, at::kBool));
+    Guard g(device_of(rays_o));
+    check_rc(nfa_ray_aabb_intersect(ptr<float>(rays_o), ptr<float>(rays_d), R, ptr<float>(aabbs), G, (float)near_plane,
+                                    (float)far_plane, (float)miss_value, ptr<float>(t_mins), ptr<float>(t_maxs), ptr<uint8_t>(hits),
+                                    stream_of(rays_o)));
+    return {t_mins, t_maxs, hits};
+}
+
+nfa_traverse_args traverse_args(const Tensor &rays_o, const Tensor &rays_d, const OptTensor &rays_mask, const Tensor &binaries,
+                                const Tensor &aabbs, const OptTensor &t_sorted, const OptTensor &t_indices, const OptTensor &hits,
+                                const Tensor &near_planes, const Tensor &far_planes, double step_size, double cone_angle,
+                                int64_t limit, Tensor &bricks_keepalive) {
+    check_input(rays_o, "rays_o", at::kFloat);
+    check_input(rays_d, "rays_d", at::kFloat);
+    check_input(aabbs, "aabbs", at::kFloat);
+    check_input(near_planes, "near_planes", at::kFloat);
+    check_input(far_planes, "far_planes", at::kFloat);
+    const int64_t R = rays_o.size(0), G = binaries.size(0);
+    TORCH_CHECK(rays_o.dim() == 2 && rays_o.size(1) == 3 && rays_d.sizes() == rays_o.sizes(), "rays_o / rays_d must have shape [n_rays, 3]");
+    TORCH_CHECK(aabbs.dim() == 2 && aabbs.size(0) == G && aabbs.size(1) == 6, "aabbs must have shape [n_grids, 6]");
+    TORCH_CHECK(near_planes.numel() == R && far_planes.numel() == R, "near_planes / far_planes must have n_rays elements");
+    nfa_traverse_args a{};
+    a.n_rays = R;
+    a.rays_o = ptr<float>(rays_o);
+    a.rays_d = ptr<float>(rays_d);
+    if (rays_mask) {
+        check_input(*rays_mask, "rays_mask", at::kBool);
+        a.rays_mask = ptr<uint8_t>(*rays_mask);
+    }
+    auto be = brick_entry(binaries, true);
+    bricks_keepalive = be.first;
+    a.n_grids = (int32_t)G;
+    a.res[0] = (int32_t)binaries.size(1); a.res[1] = (int32_t)binaries.size(2); a.res[2] = (int32_t)binaries.size(3);
+    a.bricks = ptr<uint64_t>(be.first);
+    a.n_nonempty_bricks = be.second;
+    a.aabbs = ptr<float>(aabbs);
+    if (t_sorted) {
+        TORCH_CHECK(t_indices && hits, "t_sorted, t_indices and hits must be given together");
+        check_input(*t_sorted, "t_sorted", at::kFloat);
+        check_input(*t_indices, "t_indices", at::kLong);
+        check_input(*hits, "hits", at::kBool);
+        TORCH_CHECK(t_sorted->dim() == 2 && t_sorted->size(0) == R && t_sorted->size(1) == 2 * G && t_indices->sizes() == t_sorted->sizes()
+                        && hits->dim() == 2 && hits->size(0) == R && hits->size(1) == G,
+                    "t_sorted/t_indices must be [n_rays, 2*n_grids], hits [n_rays, n_grids]");
+        a.t_sorted = ptr<float>(*t_sorted);
+        a.t_indices = ptr<int64_t>(*t_indices);
+        a.hits = ptr<uint8_t>(*hits);
+    }
+    a.near_planes = ptr<float>(near_planes);
+    a.far_planes = ptr<float>(far_planes);
+    a.step_size = (float)step_size;
+    a.cone_angle = (float)cone_angle;
+    a.traverse_steps_limit = (int32_t)limit;
+    return a;
+}
+
+// nerfacc.cpp:71-98 / grid.cu:320-474.  Two-pass mode: count -> offsets (device) -> ONE readback -> allocate -> fill; as
+// in the reference it ignores rays_mask (grid.cu:418,450).
+std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
+    const Tensor &rays_o, const Tensor &rays_d, const Tensor &rays_mask, const Tensor &binaries, const Tensor &aabbs,
+    const OptTensor &t_sorted, const OptTensor &t_indices, const OptTensor &hits, const Tensor &near_planes, const Tensor &far_planes,
+    double step_size, double cone_angle, bool compute_intervals, bool compute_samples, bool compute_terminate_planes,
+    int64_t traverse_steps_limit, bool over_allocate) {
+    TORCH_CHECK(!over_allocate || traverse_steps_limit > 0, "traverse_steps_limit must be > 0 when over_allocate is true");   // grid.cu:345
+    check_input(rays_o, "rays_o", at::kFloat);
+    const int64_t R = rays_o.size(0);
+    const auto i64 = opts(rays_o, at::kLong), f32 = rays_o.options(), b8 = opts(rays_o, at::kBool);
+    RaySegmentsSpec intervals, samples;
+    OptTensor terminate;
+    if (compute_terminate_planes) terminate = at::empty({R}, f32);
+    Guard g(device_of(rays_o));
+    hipStream_t s = stream_of(rays_o);
+    Tensor keep;
+    nfa_traverse_args a = traverse_args(rays_o, rays_d, over_allocate ? OptTensor(rays_mask) : std::nullopt, binaries, aabbs, t_sorted,
+                                        t_indices, hits, near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep);
+    Tensor iv_cnts, iv_starts, sm_cnts, sm_starts, ws;
+    int64_t n_edges = 0, n_samples = 0, n_overflow = 0;
+    if (over_allocate) {
+        // grid.cu:364-404: fixed-size slots, single pass, then starts from the actual counts
+        Tensor maskl = rays_mask.to(at::kLong);
+        iv_cnts = maskl * (2 * traverse_steps_limit);
+        sm_cnts = maskl * traverse_steps_limit;
+        iv_starts = at::empty_like(iv_cnts);
+        sm_starts = at::empty_like(sm_cnts);
+        int64_t *h = host_ints(rays_o.device().index(), s);
+        check_rc(nfa_exclusive_sum_i64(ptr<int64_t>(iv_cnts), R, ptr<int64_t>(iv_starts), h, s));
+        check_rc(nfa_exclusive_sum_i64(ptr<int64_t>(sm_cnts), R, ptr<int64_t>(sm_starts), h + 1, s));
+        wait_stream(s);
+        n_edges = h[0];
+        n_samples = h[1];
+    } else {
+        if (compute_intervals) { iv_cnts = at::empty({R}, i64); iv_starts = at::empty({R}, i64); }
+        sm_cnts = at::empty({R}, i64);
+        sm_starts = at::empty({R}, i64);
+        ws = at::empty({std::max<int64_t>(nfa_traverse_workspace_bytes(R), 16)}, opts(rays_o, at::kByte));
+        int64_t *h = host_ints(rays_o.device().index(), s);
+        a.iv_cnts = ptr<int64_t>(iv_cnts); a.iv_starts = ptr<int64_t>(iv_starts);
+        a.sm_cnts = ptr<int64_t>(sm_cnts); a.sm_starts = ptr<int64_t>(sm_starts);
+        a.totals = h;
+        a.terminate_planes = ptr<float>(terminate);
+        check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
+        check_rc(nfa_traverse_offsets(&a, ws.data_ptr(), s));
+        wait_stream(s);                                       // the one host sync (data_spec.hpp:91)
+        n_edges = h[0]; n_samples = h[1]; n_overflow = h[2];
+    }
+    a.iv_cnts = ptr<int64_t>(iv_cnts); a.iv_starts = ptr<int64_t>(iv_starts);
+    a.sm_cnts = ptr<int64_t>(sm_cnts); a.sm_starts = ptr<int64_t>(sm_starts);
+    auto alloc = [&](int64_t n, const at::TensorOptions &o) { return over_allocate ? at::zeros({n}, o) : at::empty({n}, o); };
+    if (compute_intervals) {
+        intervals.vals = alloc(n_edges, f32);
+        intervals.ray_indices = alloc(n_edges, i64);
+        Tensor flags = at::zeros({2, n_edges}, b8);
+        intervals.is_left = flags[0];
+        intervals.is_right = flags[1];
+        a.iv_vals = ptr<float>(intervals.vals); a.iv_ray_indices = ptr<int64_t>(intervals.ray_indices);
+        a.iv_is_left = ptr<uint8_t>(intervals.is_left); a.iv_is_right = ptr<uint8_t>(intervals.is_right);
+    }
+    if (compute_samples) {
+        samples.vals = alloc(n_samples, f32);
+        samples.ray_indices = alloc(n_samples, i64);
+        samples.is_valid = alloc(n_samples, b8);
+        a.sm_vals = ptr<float>(samples.vals); a.sm_ray_indices = ptr<int64_t>(samples.ray_indices);
+        a.sm_is_valid = ptr<uint8_t>(samples.is_valid);
+    }
+    a.terminate_planes = ptr<float>(terminate);
+    if (over_allocate) {
+        if (R > 0) check_rc(nfa_traverse_fill(&a, 0, 1, nullptr, 0, 0, s));
+        check_rc(nfa_exclusive_sum_i64(ptr<int64_t>(iv_cnts), R, ptr<int64_t>(iv_starts), nullptr, s));
+        check_rc(nfa_exclusive_sum_i64(ptr<int64_t>(sm_cnts), R, ptr<int64_t>(sm_starts), nullptr, s));
+    } else if (R > 0 && (compute_intervals || compute_samples) && n_samples > 0) {
+        check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n_samples, n_overflow, s));
+    }
+    if (compute_intervals) { intervals.chunk_cnts = iv_cnts; intervals.chunk_starts = iv_starts; }
+    if (compute_samples) { samples.chunk_cnts = sm_cnts; samples.chunk_starts = sm_starts; }
+    return {intervals, samples, terminate};
+}
+
+// traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
+// (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
+// test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
+py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tensor &binaries, const Tensor &aabbs,
+                         const Tensor &near_planes, const Tensor &far_planes, double step_size, double cone_angle,
+                         const OptTensor &rays_mask, int64_t traverse_steps_limit, bool with_terminate_planes) {
+    check_input(rays_o, "rays_o", at::kFloat);
+    const int64_t R = rays_o.size(0);
+    const auto i64 = opts(rays_o, at::kLong), f32 = rays_o.options();
+    Guard g(device_of(rays_o));
+    hipStream_t s = stream_of(rays_o);
+    Tensor keep;
+    nfa_traverse_args a = traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, std::nullopt, std::nullopt, std::nullopt,
+                                        near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep);
+    Tensor packed = at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
+    Tensor ws = at::empty({std::max<int64_t>(nfa_traverse_workspace_bytes(R), 16)}, opts(rays_o, at::kByte));
+    int64_t *h = host_ints(rays_o.device().index(), s);
+    a.sm_starts = ptr<int64_t>(packed);
+    a.sm_cnts = ptr<int64_t>(packed) + R;
+    a.totals = h;
+    Tensor term;
+    if (with_terminate_planes) {
+        term = near_planes.clone();
+        a.terminate_planes = ptr<float>(term);
+    }
+    {
+        Timed t("traverse_count", s);
+        check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
+    }
+    check_rc(nfa_traverse_offsets(&a, ws.data_ptr(), s));
+    wait_stream(s);
+    const int64_t n = h[1], n_overflow = h[2];
+    Tensor ray_indices = at::empty({n}, i64);
+    Tensor ts = at::empty({2, n}, f32);
+    a.sm_ray_indices = ptr<int64_t>(ray_indices);
+    a.t_starts = ptr<float>(ts);
+    a.t_ends = ptr<float>(ts) + n;
+    a.terminate_planes = nullptr;                     // written by the count pass only
+    if (n > 0) {
+        Timed t("traverse_fill", s);
+        check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n, n_overflow, s));
+    }
+    if (with_terminate_planes) return py::make_tuple(ray_indices, ts[0], ts[1], packed.t(), term);
+    return py::make_tuple(ray_indices, ts[0], ts[1], packed.t());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scans (nerfacc.cpp:17-60)
+// ---------------------------------------------------------------------------------------------------
+Tensor scan_packed(const Tensor &chunk_starts, const Tensor &chunk_cnts, const Tensor &inputs, int op, bool inclusive, bool reverse,
+                   bool normalize) {
+    check_input(chunk_starts, "chunk_starts", at::kLong);
+    check_input(chunk_cnts, "chunk_cnts", at::kLong);
+    check_input(inputs, "inputs", at::kFloat);
+    TORCH_CHECK(chunk_starts.dim() == 1 && chunk_cnts.dim() == 1 && inputs.dim() == 1, "chunk_starts, chunk_cnts and inputs must be 1-D");
+    TORCH_CHECK(chunk_starts.size(0) == chunk_cnts.size(0), "chunk_starts and chunk_cnts differ in length");
+    Tensor out = at::empty_like(inputs);
+    Guard g(device_of(inputs));
+    check_rc(nfa_scan_packed(ptr<int64_t>(chunk_starts), ptr<int64_t>(chunk_cnts), chunk_cnts.size(0), ptr<float>(inputs), ptr<float>(out),
+                             inputs.size(0), op, inclusive, reverse, normalize, stream_of(inputs)));
+    return out;
+}
+
+Tensor scan_keyed(const Tensor &indices, const Tensor &inputs, int op, bool inclusive, bool reverse) {
+    check_input(indices, "indices", at::kLong);
+    check_input(inputs, "inputs", at::kFloat);
+    TORCH_CHECK(indices.dim() == 1 && inputs.dim() == 1 && indices.size(0) == inputs.size(0), "indices and inputs must be 1-D with the same length");
+    Tensor out = at::empty_like(inputs);
+    Guard g(device_of(inputs));
+    check_rc(nfa_scan_keyed(ptr<int64_t>(indices), ptr<float>(inputs), ptr<float>(out), inputs.size(0), op, inclusive, reverse, stream_of(inputs)));
+    return out;
+}
+
+Tensor prod_bwd(const OptTensor &indices, const OptTensor &chunk_starts, const OptTensor &chunk_cnts, const Tensor &inputs,
+                const Tensor &outputs, const Tensor &grad_outputs, bool inclusive) {
+    if (indices) check_input(*indices, "indices", at::kLong);
+    if (chunk_starts) check_input(*chunk_starts, "chunk_starts", at::kLong);
+    if (chunk_cnts) check_input(*chunk_cnts, "chunk_cnts", at::kLong);
+    check_input(inputs, "inputs", at::kFloat);
+    check_input(outputs, "outputs", at::kFloat);
+    check_input(grad_outputs, "grad_outputs", at::kFloat);
+    Tensor gin = at::empty_like(grad_outputs);
+    Guard g(device_of(inputs));
+    check_rc(nfa_prod_backward(ptr<int64_t>(indices), ptr<int64_t>(chunk_starts), ptr<int64_t>(chunk_cnts), chunk_cnts ? chunk_cnts->size(0) : 0,
+                               ptr<float>(inputs), ptr<float>(outputs), ptr<float>(grad_outputs), ptr<float>(gin), inputs.size(0), inclusive,
+                               stream_of(inputs)));
+    return gin;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pdf (nerfacc.cpp:100-117)
+// ---------------------------------------------------------------------------------------------------
+std::vector<RaySegmentsSpec> importance_sampling(const RaySegmentsSpec &seg, const Tensor &cdfs, const py::object &n_intervals, bool stratified) {
+    if (!py::isinstance<py::int_>(n_intervals))
+        raise_not_implemented("importance_sampling with a per-ray Tensor count is broken in the reference (pdf.cu:324 allocates 0 "
+                              "elements) and is not provided; pass an int.");
+    seg.check();
+    check_input(cdfs, "cdfs", at::kFloat);
+    TORCH_CHECK(cdfs.numel() == seg.vals->numel(), "cdfs and ray_segments.vals must have the same number of elements");
+    const int64_t n = n_intervals.cast<int64_t>();
+    nfa_ray_segments view = seg.view();
+    std::vector<int64_t> lead;
+    if (seg.vals->dim() > 1) lead.assign(seg.vals->sizes().begin(), seg.vals->sizes().end() - 1);
+    else lead = {view.n_rays};
+    auto with_last = [&](int64_t k) { auto v = lead; v.push_back(k); return v; };
+    RaySegmentsSpec samples, intervals;
+    samples.vals = at::empty(with_last(n), cdfs.options());
+    intervals.vals = at::empty(with_last(n + 1), cdfs.options());
+    Tensor jitter;
+    // one uniform per ray from torch's generator (the reference draws it with Philox inside the kernel, pdf.cu:138-144)
+    if (stratified) jitter = at::rand({view.n_rays}, cdfs.options());
+    Guard g(device_of(cdfs));
+    check_rc(nfa_importance_sampling(&view, ptr<float>(cdfs), n, ptr<float>(jitter), ptr<float>(intervals.vals), ptr<float>(samples.vals),
+                                     stream_of(cdfs)));
+    return {intervals, samples};
+}
+
+std::vector<Tensor> searchsorted(const RaySegmentsSpec &query, const RaySegmentsSpec &key) {
+    query.check();
+    key.check();
+    Tensor l = at::empty(query.vals->sizes(), opts(*query.vals, at::kLong)), r = at::empty_like(l);
+    nfa_ray_segments q = query.view(), k = key.view();
+    Guard g(device_of(*query.vals));
+    check_rc(nfa_searchsorted(&q, &k, ptr<int64_t>(l), ptr<int64_t>(r), stream_of(*query.vals)));
+    return {l, r};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack / rendering (fused entry points: chains of ATen ops in the reference)
+// ---------------------------------------------------------------------------------------------------
+Tensor pack_info(const Tensor &ray_indices, int64_t n_rays) {
+    check_input(ray_indices, "ray_indices", at::kLong);
+    Tensor out = at::empty({n_rays, 2}, ray_indices.options());
+    Guard g(device_of(ray_indices));
+    check_rc(nfa_pack_info(ptr<int64_t>(ray_indices), ray_indices.size(0), n_rays, ptr<int64_t>(out), stream_of(ray_indices)));
+    return out;
+}
+
+Tensor unpack_info(const Tensor &chunk_starts, const Tensor &chunk_cnts, int64_t n) {
+    check_input(chunk_starts, "chunk_starts", at::kLong);
+    check_input(chunk_cnts, "chunk_cnts", at::kLong);
+    Tensor out = at::empty({n}, chunk_starts.options());
+    Guard g(device_of(chunk_starts));
+    check_rc(nfa_unpack_info(ptr<int64_t>(chunk_starts), ptr<int64_t>(chunk_cnts), chunk_cnts.size(0), ptr<int64_t>(out), n, stream_of(chunk_starts)));
+    return out;
+}
+
+py::tuple render_weight_from_density_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
+                                         const OptTensor &prefix_trans) {
+    check_input(ray_indices, "ray_indices", at::kLong);
+    check_input(t_starts, "t_starts", at::kFloat);
+    check_input(t_ends, "t_ends", at::kFloat);
+    check_input(sigmas, "sigmas", at::kFloat);
+    if (prefix_trans) check_input(*prefix_trans, "prefix_trans", at::kFloat);
+    const int64_t n = sigmas.size(0);
+    Tensor out = at::empty({3, n}, sigmas.options());
+    Guard g(device_of(sigmas));
+    check_rc(nfa_render_weight_from_density_fwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas),
+                                                ptr<float>(prefix_trans), n, ptr<float>(out), ptr<float>(out) + n, ptr<float>(out) + 2 * n,
+                                                stream_of(sigmas)));
+    return py::make_tuple(out[0], out[1], out[2]);
+}
+
+Tensor render_weight_from_density_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
+                                      const Tensor &trans, const Tensor &alphas, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a) {
+    for (auto *t : {&g_w, &g_T, &g_a})
+        if (*t) check_input(**t, "grad", at::kFloat);
+    Tensor gs = at::empty_like(sigmas);
+    Guard g(device_of(sigmas));
+    check_rc(nfa_render_weight_from_density_bwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas),
+                                                ptr<float>(trans), ptr<float>(alphas), ptr<float>(g_w), ptr<float>(g_T), ptr<float>(g_a),
+                                                sigmas.size(0), ptr<float>(gs), stream_of(sigmas)));
+    return gs;
+}
+
+py::object sample_positions(const Tensor &rays_o, const Tensor &rays_d, const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends,
+                            bool with_dirs) {
+    check_input(rays_o, "rays_o", at::kFloat);
+    check_input(rays_d, "rays_d", at::kFloat);
+    check_input(ray_indices, "ray_indices", at::kLong);
+    check_input(t_starts, "t_starts", at::kFloat);
+    check_input(t_ends, "t_ends", at::kFloat);
+    const int64_t n = ray_indices.size(0);
+    TORCH_CHECK(t_starts.size(0) == n && t_ends.size(0) == n && rays_o.sizes() == rays_d.sizes() && rays_o.dim() == 2 && rays_o.size(1) == 3,
+                "sample_positions: rays [R,3] x2 and ray_indices / t_starts / t_ends [N] expected");
+    Tensor pos = at::empty({n, 3}, rays_o.options()), dirs;
+    if (with_dirs) dirs = at::empty({n, 3}, rays_o.options());
+    Guard g(device_of(rays_o));
+    check_rc(nfa_sample_positions(ptr<float>(rays_o), ptr<float>(rays_d), rays_o.size(0), ptr<int64_t>(ray_indices), ptr<float>(t_starts),
+                                  ptr<float>(t_ends), n, ptr<float>(pos), ptr<float>(dirs), stream_of(rays_o)));
+    if (with_dirs) return py::make_tuple(pos, dirs);
+    return py::cast(pos);
+}
+
+// (ray_indices', t_starts', t_ends', mask or None); ONE host sync (the count)
+py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &dens, bool from_alpha,
+                             double early_stop_eps, double alpha_thre, bool want_mask) {
+    check_input(ray_indices, "ray_indices", at::kLong);
+    check_input(t_starts, "t_starts", at::kFloat);
+    check_input(t_ends, "t_ends", at::kFloat);
+    check_input(dens, "sigmas/alphas", at::kFloat);
+    const int64_t n = dens.size(0);
+    Tensor o_idx = at::empty({n}, ray_indices.options());
+    Tensor o_t = at::empty({2, n}, dens.options());
+    Tensor mask;
+    if (want_mask) mask = at::empty({n}, opts(dens, at::kBool));
+    Tensor ws = at::empty({std::max<int64_t>(nfa_visibility_workspace_bytes(n), 16)}, opts(dens, at::kByte));
+    Guard g(device_of(dens));
+    hipStream_t s = stream_of(dens);
+    int64_t *h = host_ints(dens.device().index(), s);
+    {
+        Timed t("visibility", s);
+        check_rc(nfa_visibility_compact(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha, n,
+                                        (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), ptr<float>(o_t), ptr<float>(o_t) + n,
+                                        ptr<uint8_t>(mask), h, ws.data_ptr(), s));
+    }
+    wait_stream(s);
+    const int64_t k = n > 0 ? h[0] : 0;
+    py::object m = want_mask ? py::cast(mask) : py::none();
+    return py::make_tuple(o_idx.narrow(0, 0, k), o_t[0].narrow(0, 0, k), o_t[1].narrow(0, 0, k), m);
+}
+
+Tensor accumulate_along_rays(const Tensor &ray_indices, const Tensor &weights, const OptTensor &values, int64_t n_rays, const OptTensor &outputs) {
+    check_input(ray_indices, "ray_indices", at::kLong);
+    check_input(weights, "weights", at::kFloat);
+    int64_t D = 1;
+    if (values) { check_input(*values, "values", at::kFloat); D = values->size(-1); }
+    Tensor out;
+    if (outputs) { check_input(*outputs, "outputs", at::kFloat); out = *outputs; }
+    else out = at::zeros({n_rays, D}, weights.options());
+    Guard g(device_of(weights));
+    check_rc(nfa_accumulate_along_rays(ptr<int64_t>(ray_indices), ptr<float>(weights), ptr<float>(values), weights.size(0), (int32_t)D,
+                                       out.size(0), ptr<float>(out), stream_of(weights)));
+    return out;
+}
+
+py::tuple accumulate_along_rays_bwd(const Tensor &ray_indices, const Tensor &weights, const OptTensor &values, const Tensor &g_out, bool need_w,
+                                    bool need_v) {
+    check_input(g_out, "g_outputs", at::kFloat);
+    const int64_t D = g_out.size(-1);
+    Tensor g_w, g_v;
+    if (need_w) g_w = at::empty_like(weights);
+    if (need_v && values) g_v = at::empty_like(*values);
+    Guard g(device_of(weights));
+    check_rc(nfa_accumulate_along_rays_bwd(ptr<int64_t>(ray_indices), ptr<float>(weights), ptr<float>(values), ptr<float>(g_out), weights.size(0),
+                                           (int32_t)D, g_out.size(0), ptr<float>(g_w), ptr<float>(g_v), stream_of(weights)));
+    return py::make_tuple(g_w.defined() ? py::cast(g_w) : py::none(), g_v.defined() ? py::cast(g_v) : py::none());
+}
+
+py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
+                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
+    check_input(ray_indices, "ray_indices", at::kLong);
+    check_input(t_starts, "t_starts", at::kFloat);
+    check_input(t_ends, "t_ends", at::kFloat);
+    check_input(sigmas, "sigmas", at::kFloat);
+    check_input(rgbs, "rgbs", at::kFloat);
+    if (bkgd) { check_input(*bkgd, "render_bkgd", at::kFloat); TORCH_CHECK(bkgd->numel() == 3, "render_bkgd must hold 3 floats"); }
+    const int64_t n = sigmas.size(0);
+    Tensor per = at::empty({3, n}, sigmas.options());
+    Tensor colors = at::empty({n_rays, 3}, sigmas.options());
+    Tensor od = at::empty({2, n_rays, 1}, sigmas.options());
+    Guard g(device_of(sigmas));
+    hipStream_t s = stream_of(sigmas);
+    {
+        Timed t("rendering_fwd", s);
+        check_rc(nfa_rendering_fwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas), ptr<float>(rgbs), n,
+                                   n_rays, ptr<float>(bkgd), expected_depths, ptr<float>(per), ptr<float>(per) + n, ptr<float>(per) + 2 * n,
+                                   ptr<float>(colors), ptr<float>(od), ptr<float>(od) + n_rays, s));
+    }
+    return py::make_tuple(colors, od[0], od[1], per[0], per[1], per[2]);
+}
+
+py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
+                        const Tensor &weights, const Tensor &trans, const Tensor &alphas, const Tensor &opacities, const Tensor &depths,
+                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths, const OptTensor &g_colors, const OptTensor &g_opac,
+                        const OptTensor &g_depth, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a, bool need_sigma, bool need_rgb) {
+    for (auto *t : {&g_colors, &g_opac, &g_depth, &g_w, &g_T, &g_a})
+        if (*t) check_input(**t, "grad", at::kFloat);
+    Tensor g_sig, g_rgb;
+    if (need_sigma) g_sig = at::empty_like(sigmas);
+    if (need_rgb) g_rgb = at::empty_like(rgbs);
+    Guard g(device_of(sigmas));
+    hipStream_t s = stream_of(sigmas);
+    {
+        Timed t("rendering_bwd", s);
+        check_rc(nfa_rendering_bwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas), ptr<float>(rgbs),
+                                   ptr<float>(weights), ptr<float>(trans), ptr<float>(alphas), ptr<float>(opacities), ptr<float>(depths),
+                                   sigmas.size(0), n_rays, ptr<float>(bkgd), expected_depths, ptr<float>(g_colors), ptr<float>(g_opac),
+                                   ptr<float>(g_depth), ptr<float>(g_w), ptr<float>(g_T), ptr<float>(g_a), ptr<float>(g_sig), ptr<float>(g_rgb), s));
+    }
+    return py::make_tuple(g_sig.defined() ? py::cast(g_sig) : py::none(), g_rgb.defined() ? py::cast(g_rgb) : py::none());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// occupancy-grid maintenance (OccGridEstimator._update, occ_grid.py:366-404)
+// ---------------------------------------------------------------------------------------------------
+Tensor grid_cell_points(const OptTensor &cell_ids, const Tensor &jitter, const std::vector<int64_t> &resolution, const Tensor &aabb) {
+    check_input(jitter, "jitter", at::kFloat);
+    check_input(aabb, "aabb", at::kFloat);
+    const int64_t n = jitter.size(0);
+    if (cell_ids) {
+        check_input(*cell_ids, "cell_ids", at::kLong);
+        TORCH_CHECK(cell_ids->dim() == 1 && cell_ids->size(0) == n, "cell_ids must have shape [n] matching jitter [n, 3]");
+    }
+    TORCH_CHECK(jitter.dim() == 2 && jitter.size(1) == 3 && aabb.numel() == 6 && resolution.size() == 3, "jitter must be [n, 3] and aabb must hold 6 floats");
+    Tensor points = at::empty({n, 3}, jitter.options());
+    Guard g(device_of(jitter));
+    hipStream_t s = stream_of(jitter);
+    Timed t("grid_cell_points", s);
+    check_rc(nfa_grid_cell_points(ptr<int64_t>(cell_ids), n, ptr<float>(jitter), (int32_t)resolution[0], (int32_t)resolution[1],
+                                  (int32_t)resolution[2], ptr<float>(aabb), ptr<float>(points), s));
+    return points;
+}
+
+void grid_ema_update(const Tensor &occs_level, const OptTensor &cell_ids, const Tensor &occ_new, double ema_decay) {
+    check_input(occs_level, "occs", at::kFloat);
+    check_input(occ_new, "occ_new", at::kFloat);
+    const int64_t n = occ_new.numel();
+    if (cell_ids) {
+        check_input(*cell_ids, "cell_ids", at::kLong);
+        TORCH_CHECK(cell_ids->numel() == n, "cell_ids and occ_new must have the same number of elements");
+    } else {
+        TORCH_CHECK(n <= occs_level.numel(), "occ_new has more elements than the level has cells");
+    }
+    Tensor scratch = at::empty({n}, occs_level.options());
+    Guard g(device_of(occs_level));
+    hipStream_t s = stream_of(occs_level);
+    Timed t("grid_ema_update", s);
+    check_rc(nfa_grid_ema_update(ptr<float>(occs_level), ptr<int64_t>(cell_ids), n, ptr<float>(occ_new), (float)ema_decay, ptr<float>(scratch), s));
+}
+
+py::tuple grid_threshold(const Tensor &occs, double occ_thre) {
+    check_input(occs, "occs", at::kFloat);
+    const int64_t n = occs.numel();
+    Tensor ws = at::empty({nfa_grid_threshold_workspace_bytes() / 8}, opts(occs, at::kDouble));
+    Tensor binaries = at::empty({n}, opts(occs, at::kBool));
+    Tensor thre = at::empty({1}, occs.options());
+    Guard g(device_of(occs));
+    hipStream_t s = stream_of(occs);
+    Timed t("grid_threshold", s);
+    check_rc(nfa_grid_threshold(ptr<float>(occs), n, (float)occ_thre, ws.data_ptr(), ptr<uint8_t>(binaries), ptr<float>(thre), s));
+    return py::make_tuple(binaries, thre);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "nerfacc_amd._hip: torch C++ extension over the C ABI of libnerfacc_hip.so (MI355X / gfx950)";
+    m.def("version", []() { return std::string(nfa_version()); });
+
+    py::class_<RaySegmentsSpec>(m, "RaySegmentsSpec")
+        .def(py::init<>())
+        .def_readwrite("vals", &RaySegmentsSpec::vals)
+        .def_readwrite("is_left", &RaySegmentsSpec::is_left)
+        .def_readwrite("is_right", &RaySegmentsSpec::is_right)
+        .def_readwrite("is_valid", &RaySegmentsSpec::is_valid)
+        .def_readwrite("chunk_starts", &RaySegmentsSpec::chunk_starts)
+        .def_readwrite("chunk_cnts", &RaySegmentsSpec::chunk_cnts)
+        .def_readwrite("ray_indices", &RaySegmentsSpec::ray_indices)
+        .def("check", &RaySegmentsSpec::check);
+
+    using namespace pybind11::literals;
+    // ---- the reference boundary (nerfacc.cpp:126-163), same names and argument order
+    m.def("is_cub_available", []() { return true; });     // scan-by-key is native (scan.hip): the keyed path is always there
+    m.def("ray_aabb_intersect", &ray_aabb_intersect);
+    m.def("traverse_grids", &traverse_grids);
+    m.def("inclusive_sum", [](const Tensor &s, const Tensor &c, const Tensor &x, bool normalize, bool backward) {
+        return scan_packed(s, c, x, NFA_OP_SUM, true, backward, normalize); });
+    m.def("exclusive_sum", [](const Tensor &s, const Tensor &c, const Tensor &x, bool normalize, bool backward) {
+        return scan_packed(s, c, x, NFA_OP_SUM, false, backward, normalize); });
+    m.def("inclusive_prod_forward", [](const Tensor &s, const Tensor &c, const Tensor &x) { return scan_packed(s, c, x, NFA_OP_PROD, true, false, false); });
+    m.def("exclusive_prod_forward", [](const Tensor &s, const Tensor &c, const Tensor &x) { return scan_packed(s, c, x, NFA_OP_PROD, false, false, false); });
+    m.def("inclusive_prod_backward", [](const Tensor &s, const Tensor &c, const Tensor &x, const Tensor &y, const Tensor &gy) {
+        return prod_bwd(std::nullopt, s, c, x, y, gy, true); });
+    m.def("exclusive_prod_backward", [](const Tensor &s, const Tensor &c, const Tensor &x, const Tensor &y, const Tensor &gy) {
+        return prod_bwd(std::nullopt, s, c, x, y, gy, false); });
+    m.def("inclusive_sum_cub", [](const Tensor &k, const Tensor &x, bool backward) { return scan_keyed(k, x, NFA_OP_SUM, true, backward); });
+    m.def("exclusive_sum_cub", [](const Tensor &k, const Tensor &x, bool backward) { return scan_keyed(k, x, NFA_OP_SUM, false, backward); });
+    m.def("inclusive_prod_cub_forward", [](const Tensor &k, const Tensor &x) { return scan_keyed(k, x, NFA_OP_PROD, true, false); });
+    m.def("exclusive_prod_cub_forward", [](const Tensor &k, const Tensor &x) { return scan_keyed(k, x, NFA_OP_PROD, false, false); });
+    m.def("inclusive_prod_cub_backward", [](const Tensor &k, const Tensor &x, const Tensor &y, const Tensor &gy) {
+        return prod_bwd(k, std::nullopt, std::nullopt, x, y, gy, true); });
+    m.def("exclusive_prod_cub_backward", [](const Tensor &k, const Tensor &x, const Tensor &y, const Tensor &gy) {
+        return prod_bwd(k, std::nullopt, std::nullopt, x, y, gy, false); });
+    m.def("importance_sampling", &importance_sampling);
+    m.def("searchsorted", &searchsorted);
+    m.def("opencv_lens_undistortion", [](py::args, py::kwargs) {
+        raise_not_implemented("camera undistortion (camera.cu) is outside the OccGrid hot path and not built"); });
+    m.def("opencv_lens_undistortion_fisheye", [](py::args, py::kwargs) {
+        raise_not_implemented("camera undistortion (camera.cu) is outside the OccGrid hot path and not built"); });
+
+    // ---- fused entry points of this implementation
+    m.def("sample_occgrid", &sample_occgrid, "rays_o"_a, "rays_d"_a, "binaries"_a, "aabbs"_a, "near_planes"_a, "far_planes"_a, "step_size"_a,
+          "cone_angle"_a, "rays_mask"_a = py::none(), "traverse_steps_limit"_a = -1, "with_terminate_planes"_a = false);
+    m.def("pack_info", &pack_info, "ray_indices"_a, "n_rays"_a);
+    m.def("unpack_info", &unpack_info, "chunk_starts"_a, "chunk_cnts"_a, "n"_a);
+    m.def("render_weight_from_density_fwd", &render_weight_from_density_fwd, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "sigmas"_a,
+          "prefix_trans"_a = py::none());
+    m.def("render_weight_from_density_bwd", &render_weight_from_density_bwd);
+    m.def("sample_positions", &sample_positions, "rays_o"_a, "rays_d"_a, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "with_dirs"_a = false);
+    m.def("visibility_compact", &visibility_compact, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "dens"_a, "from_alpha"_a, "early_stop_eps"_a,
+          "alpha_thre"_a, "want_mask"_a = false);
+    m.def("accumulate_along_rays", &accumulate_along_rays, "ray_indices"_a, "weights"_a, "values"_a, "n_rays"_a, "outputs"_a = py::none());
+    m.def("accumulate_along_rays_bwd", &accumulate_along_rays_bwd);
+    m.def("rendering_fwd", &rendering_fwd);
+    m.def("rendering_bwd", &rendering_bwd, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "sigmas"_a, "rgbs"_a, "weights"_a, "trans"_a, "alphas"_a,
+          "opacities"_a, "depths"_a, "n_rays"_a, "bkgd"_a, "expected_depths"_a, "g_colors"_a, "g_opac"_a, "g_depth"_a, "g_w"_a, "g_T"_a, "g_a"_a,
+          "need_sigma"_a = true, "need_rgb"_a = true);
+    m.def("grid_cell_points", &grid_cell_points);
+    m.def("grid_ema_update", &grid_ema_update);
+    m.def("grid_threshold", &grid_threshold);
+    m.def("packed_bricks", &packed_bricks);
+    m.def("set_timing", &set_timing, "names"_a = py::none());
+    m.def("timing_summary", &timing_summary);
+}

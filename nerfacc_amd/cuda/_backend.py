@@ -116,7 +116,10 @@ class KernelTimer:
         return rc
 
     def summary(self):
+        """{name: (launches, average milliseconds per launch)}"""
         torch.cuda.synchronize()
+        if BACKEND == "ext":
+            return {k: (int(n), float(ms)) for k, (n, ms) in _C.timing_summary().items()}
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.records.items()}
 
 
@@ -124,8 +127,12 @@ _timer: Optional[KernelTimer] = None
 
 
 def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
+    """bracket the named single-kernel calls with HIP events on their launch stream (ctypes backend: torch events
+    around the call; torch-extension backend: hipEventRecord inside the extension)"""
     global _timer
     _timer = timer
+    if BACKEND == "ext":
+        _C.set_timing(None if timer is None else sorted(timer.names))
 
 
 def _call(name, fn, *args):
@@ -139,8 +146,10 @@ def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
+            _jit_build()          # like the reference's first-import JIT build (nerfacc/cuda/_backend.py:59-82)
+        if not os.path.exists(LIB_PATH):
             raise ImportError(
-                f"nerfacc_amd: {LIB_PATH} not found. Build the HIP library first: "
+                f"nerfacc_amd: {LIB_PATH} not found and could not be built. Build the HIP library first: "
                 "`python -m nerfacc_amd.build` (needs hipcc; there is no CPU fallback)."
             )
         lib = ctypes.CDLL(LIB_PATH)
@@ -150,6 +159,22 @@ def load_library() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def _jit_build() -> None:
+    """first use without built artefacts: compile them in-tree with hipcc, as the reference JIT-builds its
+    extension on first import when no prebuilt one exists.  Silent no-op when no compiler is around."""
+    import shutil
+
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        return
+    try:
+        from ..build import build
+
+        print("nerfacc_amd: building the HIP library and the torch extension for gfx950 (first use, ~1-2 min) ...", flush=True)
+        build(force=False, verbose=False)
+    except Exception as e:      # noqa: BLE001  (the caller raises ImportError with instructions)
+        print(f"nerfacc_amd: build failed: {e}", flush=True)
 
 
 def _check(rc: int) -> None:
@@ -196,7 +221,7 @@ class _Guard:
             self.ctx.__exit__(*exc)
 
 
-class RaySegmentsSpec:
+class _PyRaySegmentsSpec:
     """Mirror of the pybind class RaySegmentsSpec (nerfacc.cpp:128-137, data_spec.hpp:6-14):
     seven optional tensors with default construction and read/write attributes."""
 
@@ -316,6 +341,8 @@ def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
     """bool [G, rx, ry, rz] -> uint64-as-int64 bricks (nfa_pack_binaries), memoised on the
     tensor object + its in-place version counter so that a grid that has not changed since
     the last call is not repacked (OccGridEstimator changes it every 16 steps)."""
+    if BACKEND == "ext":
+        return _C.packed_bricks(binaries)
     return _brick_entry(binaries)["bricks"]
 
 
@@ -373,10 +400,11 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     return a
 
 
-class _C:
-    """Namespace with the names of the reference's compiled module."""
+class _CtypesC:
+    """ctypes face of the C ABI with the names of the reference's compiled module (the fallback backend:
+    `NERFACC_AMD_BACKEND=ctypes`, or when the torch extension nerfacc_amd/_hip*.so is not built)."""
 
-    RaySegmentsSpec = RaySegmentsSpec
+    RaySegmentsSpec = _PyRaySegmentsSpec
 
     # ---------------------------------------------------------------- misc
     @staticmethod
@@ -418,7 +446,7 @@ class _C:
         dev = rays_o.device
         R = rays_o.shape[0]
         i64 = dict(dtype=torch.int64, device=dev)
-        intervals, samples = RaySegmentsSpec(), RaySegmentsSpec()
+        intervals, samples = _PyRaySegmentsSpec(), _PyRaySegmentsSpec()
         terminate = torch.empty((R,), dtype=torch.float32, device=dev) if compute_terminate_planes else None
         with _Guard(rays_o):
             stream = _stream(rays_o)
@@ -521,61 +549,61 @@ class _C:
 
     @staticmethod
     def inclusive_sum(chunk_starts, chunk_cnts, inputs, normalize: bool, backward: bool):
-        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, True, backward, normalize)
+        return _CtypesC._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, True, backward, normalize)
 
     @staticmethod
     def exclusive_sum(chunk_starts, chunk_cnts, inputs, normalize: bool, backward: bool):
-        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, False, backward, normalize)
+        return _CtypesC._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_SUM, False, backward, normalize)
 
     @staticmethod
     def inclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
-        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, True, False, False)
+        return _CtypesC._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, True, False, False)
 
     @staticmethod
     def exclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
-        return _C._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, False, False, False)
+        return _CtypesC._packed(chunk_starts, chunk_cnts, inputs, NFA_OP_PROD, False, False, False)
 
     @staticmethod
     def inclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
         _check_input(chunk_starts, "chunk_starts", torch.int64)
         _check_input(chunk_cnts, "chunk_cnts", torch.int64)
-        return _C._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, True)
+        return _CtypesC._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, True)
 
     @staticmethod
     def exclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
         _check_input(chunk_starts, "chunk_starts", torch.int64)
         _check_input(chunk_cnts, "chunk_cnts", torch.int64)
-        return _C._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, False)
+        return _CtypesC._prod_bwd(None, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs, False)
 
     @staticmethod
     def inclusive_sum_cub(indices, inputs, backward: bool):
-        return _C._keyed(indices, inputs, NFA_OP_SUM, True, backward)
+        return _CtypesC._keyed(indices, inputs, NFA_OP_SUM, True, backward)
 
     @staticmethod
     def exclusive_sum_cub(indices, inputs, backward: bool):
-        return _C._keyed(indices, inputs, NFA_OP_SUM, False, backward)
+        return _CtypesC._keyed(indices, inputs, NFA_OP_SUM, False, backward)
 
     @staticmethod
     def inclusive_prod_cub_forward(indices, inputs):
-        return _C._keyed(indices, inputs, NFA_OP_PROD, True, False)
+        return _CtypesC._keyed(indices, inputs, NFA_OP_PROD, True, False)
 
     @staticmethod
     def exclusive_prod_cub_forward(indices, inputs):
-        return _C._keyed(indices, inputs, NFA_OP_PROD, False, False)
+        return _CtypesC._keyed(indices, inputs, NFA_OP_PROD, False, False)
 
     @staticmethod
     def inclusive_prod_cub_backward(indices, inputs, outputs, grad_outputs):
         _check_input(indices, "indices", torch.int64)
-        return _C._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, True)
+        return _CtypesC._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, True)
 
     @staticmethod
     def exclusive_prod_cub_backward(indices, inputs, outputs, grad_outputs):
         _check_input(indices, "indices", torch.int64)
-        return _C._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, False)
+        return _CtypesC._prod_bwd(indices, None, None, inputs, outputs, grad_outputs, False)
 
     # ---------------------------------------------------------------- pdf
     @staticmethod
-    def importance_sampling(ray_segments: RaySegmentsSpec, cdfs, n_intervels_per_ray, stratified: bool):
+    def importance_sampling(ray_segments: _PyRaySegmentsSpec, cdfs, n_intervels_per_ray, stratified: bool):
         """nerfacc.cpp:100-112.  Only the int overload exists here: the Tensor-count overload
         of the reference allocates zero elements (pdf.cu:324) and cannot have callers."""
         if isinstance(n_intervels_per_ray, torch.Tensor):
@@ -593,7 +621,7 @@ class _C:
         else:
             lead = [int(view.n_rays)]
         dev = cdfs.device
-        samples, intervals = RaySegmentsSpec(), RaySegmentsSpec()
+        samples, intervals = _PyRaySegmentsSpec(), _PyRaySegmentsSpec()
         samples.vals = torch.empty(lead + [n], dtype=torch.float32, device=dev)
         intervals.vals = torch.empty(lead + [n + 1], dtype=torch.float32, device=dev)
         jitter = None
@@ -607,7 +635,7 @@ class _C:
         return [intervals, samples]
 
     @staticmethod
-    def searchsorted(query: RaySegmentsSpec, key: RaySegmentsSpec):
+    def searchsorted(query: _PyRaySegmentsSpec, key: _PyRaySegmentsSpec):
         """nerfacc.cpp:114-117 -> [ids_left, ids_right] shaped like query.vals."""
         query.check()
         key.check()
@@ -880,4 +908,30 @@ class _C:
         return g_sig, g_rgb
 
 
-__all__ = ["_C", "KernelTimer", "set_kernel_timer", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]
+def _select_backend():
+    """The torch C++ extension (nerfacc_amd/_hip*.so, csrc/torch_ext.cpp) is THE boundary, as the reference's pybind
+    module is; the ctypes face of the same C ABI stays as a fallback (`NERFACC_AMD_BACKEND=ctypes` forces it)."""
+    want = os.environ.get("NERFACC_AMD_BACKEND", "ext").lower()
+    if want not in ("ext", "ctypes"):
+        raise ImportError(f"NERFACC_AMD_BACKEND must be 'ext' or 'ctypes', got {want!r}")
+    if want == "ext":
+        import glob
+        import importlib
+
+        if not glob.glob(os.path.join(_PKG, "_hip*.so")):
+            _jit_build()
+        if glob.glob(os.path.join(_PKG, "_hip*.so")):
+            return importlib.import_module("nerfacc_amd._hip"), "ext"
+        import warnings
+
+        warnings.warn("nerfacc_amd: the torch extension nerfacc_amd/_hip*.so is not built; using the ctypes backend "
+                      "(python -m nerfacc_amd.build builds both)")
+    load_library()
+    return _CtypesC, "ctypes"
+
+
+BACKEND = "ctypes"          # set for real just below (the functions above read it at call time)
+_C, BACKEND = _select_backend()
+RaySegmentsSpec = _C.RaySegmentsSpec
+
+__all__ = ["_C", "BACKEND", "KernelTimer", "set_kernel_timer", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]

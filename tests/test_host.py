@@ -190,3 +190,27 @@ def test_data_specs_roundtrip():
     back = RaySamples._from_cpp(sm._to_cpp())          # (the reference's RaySamples._to_cpp raises: data_specs.py:57)
     assert torch.equal(back.packed_info, pk) and torch.equal(back.ray_indices, sm.ray_indices)
     assert RaySamples._from_cpp(RaySamples(torch.rand(3, 4))._to_cpp()).packed_info is None
+
+
+def test_torch_extension_is_the_default_backend_and_has_the_reference_names():
+    """nerfacc_amd/_hip*.so (csrc/torch_ext.cpp) stands where the reference's pybind module `nerfacc.csrc` does
+    (nerfacc/cuda/csrc/nerfacc.cpp:126-163): same 21 names, plus this implementation's fused entry points"""
+    import os
+
+    from nerfacc_amd import cuda as C
+    from nerfacc_amd.cuda import _backend
+
+    if os.environ.get("NERFACC_AMD_BACKEND", "ext") != "ext":
+        pytest.skip("ctypes backend forced")
+    assert _backend.BACKEND == "ext"
+    ext = _backend._C
+    assert ext.__name__ == "nerfacc_amd._hip" and ext.version().startswith("nerfacc_hip ")
+    for name in C._REFERENCE_NAMES + C._FUSED_NAMES:
+        assert hasattr(ext, name), name
+        assert hasattr(_backend._CtypesC, name), name            # the fallback offers the same surface
+    spec = ext.RaySegmentsSpec()
+    assert all(getattr(spec, k) is None for k in ("vals", "is_left", "is_right", "is_valid", "chunk_starts", "chunk_cnts", "ray_indices"))
+    with pytest.raises(NotImplementedError):
+        ext.opencv_lens_undistortion(1, 2)
+    with pytest.raises(RuntimeError):                                  # CHECK_INPUT: host tensors are refused
+        ext.ray_aabb_intersect(torch.rand(2, 3), torch.rand(2, 3), torch.rand(1, 6), 0.0, 1.0, -1.0)
