@@ -90,11 +90,14 @@ struct Timed {
     }
 };
 
+// names = None stops recording and KEEPS what was recorded (timing_summary reads it); a list starts afresh
 void set_timing(std::optional<std::vector<std::string>> names) {
     std::lock_guard<std::mutex> l(g_timing.mu);
-    for (auto &kv : g_timing.records)
-        for (auto &p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-    g_timing.records.clear();
+    if (names.has_value()) {
+        for (auto &kv : g_timing.records)
+            for (auto &p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        g_timing.records.clear();
+    }
     g_timing.on = names.has_value();
     g_timing.names = names.value_or(std::vector<std::string>{});
 }

@@ -75,7 +75,10 @@ def test_scans_and_pdf_agree(faces):
     s, c = pk[:, 0].contiguous(), pk[:, 1].contiguous()
     for name in ("inclusive_sum", "exclusive_sum"):
         _same(getattr(ext, name)(s, c, x, False, False), getattr(ct, name)(s, c, x, False, False))
-        _same(getattr(ext, name)(s, c, x, True, True), getattr(ct, name)(s, c, x, True, True))
+        _same(getattr(ext, name)(s, c, x, True, False), getattr(ct, name)(s, c, x, True, False))     # normalize
+        _same(getattr(ext, name)(s, c, x, False, True), getattr(ct, name)(s, c, x, False, True))     # backward
+        with pytest.raises(RuntimeError):                                                             # scan.cu:25-26
+            getattr(ext, name)(s, c, x, True, True)
         _same(getattr(ext, name + "_cub")(ri, x, False), getattr(ct, name + "_cub")(ri, x, False))
     for name in ("inclusive_prod", "exclusive_prod"):
         y = getattr(ext, name + "_forward")(s, c, x)
