@@ -108,8 +108,8 @@ typedef struct nfa_traverse_args {
     const float *t_sorted;      /* [n_rays, 2*n_grids] */
     const int64_t *t_indices;   /* [n_rays, 2*n_grids] */
     /* options */
-    const float *near_planes;   /* [n_rays] */
-    const float *far_planes;    /* [n_rays] */
+    const float *near_planes;   /* [n_rays]; nullable: then near_plane (scalar, below) is every ray's near plane */
+    const float *far_planes;    /* [n_rays]; nullable: then far_plane */
     float step_size;
     float cone_angle;
     int32_t traverse_steps_limit; /* <= 0: unlimited */
@@ -124,6 +124,14 @@ typedef struct nfa_traverse_args {
     float *t_starts; float *t_ends; /* [n_samples]: interval of each sample, written directly
                                        (what occ_grid.py:174-175 extracts with is_left/is_right) */
     float *terminate_planes;    /* [n_rays] nullable */
+    /* per-ray planes formed in the kernel exactly as OccGridEstimator.sampling forms them with torch ops
+     * (occ_grid.py:154-163; same float operations, same order): near = [near_planes or near_plane],
+     * clamped from below by t_min, plus jitter * jitter_scale (stratified: rand * render_step_size);
+     * far = [far_planes or far_plane] clamped from above by t_max.  All three pointers nullable. */
+    float near_plane, far_plane;
+    const float *t_min, *t_max; /* [n_rays] */
+    const float *jitter;        /* [n_rays] uniform [0,1) numbers of the caller's generator */
+    float jitter_scale;
 } nfa_traverse_args;
 
 /* pass 1 (grid.cu:413), one kernel: per-ray counts into iv_cnts / sm_cnts, terminate_planes when

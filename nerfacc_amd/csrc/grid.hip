@@ -528,6 +528,24 @@ struct FillSink {
     }
 };
 
+// per-ray near / far plane as OccGridEstimator.sampling forms them (occ_grid.py:154-163) — the same float
+// operations in the same order as the torch expressions, so the result is bit-identical to passing tensors:
+//   near = full_like(near_plane); near = clamp(near, min=t_min); near += rand * render_step_size
+//   far  = full_like(far_plane);  far  = clamp(far, max=t_max)
+// Tensors (near_planes / far_planes) win when given; the scalar + t_min/t_max + jitter form saves the caller five
+// elementwise launches per sampling call.
+__device__ __forceinline__ float ray_near(const nfa_traverse_args &a, int64_t r) {
+    float v = a.near_planes ? a.near_planes[r] : a.near_plane;
+    if (a.t_min) { const float m = a.t_min[r]; v = (m != m) ? m : (v < m ? m : v); }        // torch.clamp(min=): NaN bound propagates
+    if (a.jitter) v = v + a.jitter[r] * a.jitter_scale;                                        // -ffp-contract=off: mul, then add
+    return v;
+}
+__device__ __forceinline__ float ray_far(const nfa_traverse_args &a, int64_t r) {
+    float v = a.far_planes ? a.far_planes[r] : a.far_plane;
+    if (a.t_max) { const float m = a.t_max[r]; v = (m != m) ? m : (v > m ? m : v); }
+    return v;
+}
+
 // ---- general walk: any step_size / cone_angle; the reference's loop shape (grid.cu:95-281).
 // Used for cone_angle != 0, step_size <= 0, the over-allocated test-time pass and as the
 // pass-2 fallback of rays whose runs did not fit.
@@ -538,7 +556,7 @@ __device__ __forceinline__ void traverse_ray_general(const nfa_traverse_args &a,
     const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
     const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
     const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float near = a.near_planes[r], far = a.far_planes[r];
+    const float near = ray_near(a, r), far = ray_far(a, r);
     const float step_size = a.step_size, cone = a.cone_angle;
     const int limit = a.traverse_steps_limit;
     const int G = a.n_grids;
@@ -610,8 +628,8 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
     if (active) {
         o[0] = a.rays_o[3 * r]; o[1] = a.rays_o[3 * r + 1]; o[2] = a.rays_o[3 * r + 2];
         d[0] = a.rays_d[3 * r]; d[1] = a.rays_d[3 * r + 1]; d[2] = a.rays_d[3 * r + 2];
-        near = a.near_planes[r];
-        far = a.far_planes[r];
+        near = ray_near(a, r);
+        far = ray_far(a, r);
     }
     const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     const float dt = march_dt(0.0f, 0.0f, a.step_size);     // = clamp(step_size, ., 1e10)
@@ -789,7 +807,7 @@ __device__ void traverse_ray_lattice_inline(const nfa_traverse_args &a, const Gr
     const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
     const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
     const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float near = a.near_planes[r], far = a.far_planes[r];
+    const float near = ray_near(a, r), far = ray_far(a, r);
     const float dt = march_dt(0.0f, 0.0f, a.step_size);
     const int G = a.n_grids;
     Events<EV> ev;
@@ -900,7 +918,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
     const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
     const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float near = a.near_planes[rr], far = a.far_planes[rr];
+    const float near = ray_near(a, rr), far = ray_far(a, rr);
     const float dt = march_dt(0.0f, 0.0f, a.step_size);
 
     // the single segment (grid.cu:129-150 with one level)
@@ -1395,7 +1413,7 @@ int validate_traverse(const nfa_traverse_args *a) {
     NFA_REQUIRE(a->n_grids >= 1 && a->n_grids <= NFA_MAX_GRID_LEVELS, "traverse: n_grids=%d not in [1,%d]", a->n_grids, NFA_MAX_GRID_LEVELS);
     NFA_REQUIRE(a->res[0] > 0 && a->res[1] > 0 && a->res[2] > 0, "traverse: bad resolution");
     if (a->n_rays == 0) return NFA_OK;
-    NFA_REQUIRE(a->rays_o && a->rays_d && a->bricks && a->aabbs && a->near_planes && a->far_planes, "traverse: NULL input");
+    NFA_REQUIRE(a->rays_o && a->rays_d && a->bricks && a->aabbs, "traverse: NULL input");
     const int given = (a->hits != nullptr) + (a->t_sorted != nullptr) + (a->t_indices != nullptr);
     NFA_REQUIRE(given == 0 || given == 3, "traverse: hits/t_sorted/t_indices must be given together");
     NFA_REQUIRE(a->sm_cnts && a->sm_starts, "traverse: sm_cnts/sm_starts are required");

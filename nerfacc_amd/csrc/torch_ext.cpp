@@ -14,6 +14,7 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <limits>
 #include <map>
 #include <mutex>
 #include <optional>
@@ -274,18 +275,33 @@ std::vector<Tensor> ray_aabb_intersect(const Tensor &rays_o, const Tensor &rays_
 
 nfa_traverse_args traverse_args(const Tensor &rays_o, const Tensor &rays_d, const OptTensor &rays_mask, const Tensor &binaries,
                                 const Tensor &aabbs, const OptTensor &t_sorted, const OptTensor &t_indices, const OptTensor &hits,
-                                const Tensor &near_planes, const Tensor &far_planes, double step_size, double cone_angle,
-                                int64_t limit, Tensor &bricks_keepalive) {
+                                const OptTensor &near_planes, const OptTensor &far_planes, double step_size, double cone_angle,
+                                int64_t limit, Tensor &bricks_keepalive, double near_plane = 0.0,
+                                double far_plane = std::numeric_limits<double>::infinity(), const OptTensor &t_min = std::nullopt,
+                                const OptTensor &t_max = std::nullopt, const OptTensor &jitter = std::nullopt, double jitter_scale = 0.0) {
     check_input(rays_o, "rays_o", at::kFloat);
     check_input(rays_d, "rays_d", at::kFloat);
     check_input(aabbs, "aabbs", at::kFloat);
-    check_input(near_planes, "near_planes", at::kFloat);
-    check_input(far_planes, "far_planes", at::kFloat);
     const int64_t R = rays_o.size(0), G = binaries.size(0);
+    auto per_ray = [&](const OptTensor &t, const char *name) {
+        if (!t) return;
+        check_input(*t, name, at::kFloat);
+        TORCH_CHECK(t->numel() == R, name, " must have n_rays elements");
+    };
+    per_ray(near_planes, "near_planes");
+    per_ray(far_planes, "far_planes");
+    per_ray(t_min, "t_min");
+    per_ray(t_max, "t_max");
+    per_ray(jitter, "jitter");
     TORCH_CHECK(rays_o.dim() == 2 && rays_o.size(1) == 3 && rays_d.sizes() == rays_o.sizes(), "rays_o / rays_d must have shape [n_rays, 3]");
     TORCH_CHECK(aabbs.dim() == 2 && aabbs.size(0) == G && aabbs.size(1) == 6, "aabbs must have shape [n_grids, 6]");
-    TORCH_CHECK(near_planes.numel() == R && far_planes.numel() == R, "near_planes / far_planes must have n_rays elements");
     nfa_traverse_args a{};
+    a.near_plane = (float)near_plane;
+    a.far_plane = (float)far_plane;
+    a.t_min = ptr<float>(t_min);
+    a.t_max = ptr<float>(t_max);
+    a.jitter = ptr<float>(jitter);
+    a.jitter_scale = (float)jitter_scale;
     a.n_rays = R;
     a.rays_o = ptr<float>(rays_o);
     a.rays_d = ptr<float>(rays_d);
@@ -338,7 +354,8 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
     hipStream_t s = stream_of(rays_o);
     Tensor keep;
     nfa_traverse_args a = traverse_args(rays_o, rays_d, over_allocate ? OptTensor(rays_mask) : std::nullopt, binaries, aabbs, t_sorted,
-                                        t_indices, hits, near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep);
+                                        t_indices, hits, OptTensor(near_planes), OptTensor(far_planes), step_size, cone_angle,
+                                        traverse_steps_limit, keep);
     Tensor iv_cnts, iv_starts, sm_cnts, sm_starts, ws;
     int64_t n_edges = 0, n_samples = 0, n_overflow = 0;
     if (over_allocate) {
@@ -405,8 +422,9 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
 // (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
 // test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
 py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tensor &binaries, const Tensor &aabbs,
-                         const Tensor &near_planes, const Tensor &far_planes, double step_size, double cone_angle,
-                         const OptTensor &rays_mask, int64_t traverse_steps_limit, bool with_terminate_planes) {
+                         const OptTensor &near_planes, const OptTensor &far_planes, double step_size, double cone_angle,
+                         const OptTensor &rays_mask, int64_t traverse_steps_limit, bool with_terminate_planes, double near_plane,
+                         double far_plane, const OptTensor &t_min, const OptTensor &t_max, const OptTensor &jitter, double jitter_scale) {
     check_input(rays_o, "rays_o", at::kFloat);
     const int64_t R = rays_o.size(0);
     const auto i64 = opts(rays_o, at::kLong), f32 = rays_o.options();
@@ -414,7 +432,8 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     hipStream_t s = stream_of(rays_o);
     Tensor keep;
     nfa_traverse_args a = traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, std::nullopt, std::nullopt, std::nullopt,
-                                        near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep);
+                                        near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep, near_plane, far_plane,
+                                        t_min, t_max, jitter, jitter_scale);
     Tensor packed = at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
     Tensor ws = at::empty({std::max<int64_t>(nfa_traverse_workspace_bytes(R), 16)}, opts(rays_o, at::kByte));
     int64_t *h = host_ints(rays_o.device().index(), s);
@@ -423,7 +442,8 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     a.totals = h;
     Tensor term;
     if (with_terminate_planes) {
-        term = near_planes.clone();
+        TORCH_CHECK(near_planes.has_value(), "with_terminate_planes needs near_planes as a tensor");
+        term = near_planes->clone();
         a.terminate_planes = ptr<float>(term);
     }
     {
@@ -785,6 +805,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return prod_bwd(k, std::nullopt, std::nullopt, x, y, gy, true); });
     m.def("exclusive_prod_cub_backward", [](const Tensor &k, const Tensor &x, const Tensor &y, const Tensor &gy) {
         return prod_bwd(k, std::nullopt, std::nullopt, x, y, gy, false); });
+    // the generic forms behind the 14 scan names (op, inclusive, reverse[, normalize]); tests drive every combination
+    m.def("_packed", &scan_packed);
+    m.def("_keyed", &scan_keyed);
     m.def("importance_sampling", &importance_sampling);
     m.def("searchsorted", &searchsorted);
     m.def("opencv_lens_undistortion", [](py::args, py::kwargs) {
@@ -794,7 +817,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
     // ---- fused entry points of this implementation
     m.def("sample_occgrid", &sample_occgrid, "rays_o"_a, "rays_d"_a, "binaries"_a, "aabbs"_a, "near_planes"_a, "far_planes"_a, "step_size"_a,
-          "cone_angle"_a, "rays_mask"_a = py::none(), "traverse_steps_limit"_a = -1, "with_terminate_planes"_a = false);
+          "cone_angle"_a, "rays_mask"_a = py::none(), "traverse_steps_limit"_a = -1, "with_terminate_planes"_a = false, "near_plane"_a = 0.0,
+          "far_plane"_a = std::numeric_limits<double>::infinity(), "t_min"_a = py::none(), "t_max"_a = py::none(), "jitter"_a = py::none(),
+          "jitter_scale"_a = 0.0);
     m.def("pack_info", &pack_info, "ray_indices"_a, "n_rays"_a);
     m.def("unpack_info", &unpack_info, "chunk_starts"_a, "chunk_cnts"_a, "n"_a);
     m.def("render_weight_from_density_fwd", &render_weight_from_density_fwd, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "sigmas"_a,

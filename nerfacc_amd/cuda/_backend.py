@@ -44,6 +44,8 @@ class _TraverseArgs(ctypes.Structure):
         ("iv_vals", c_void_p), ("iv_ray_indices", c_void_p), ("iv_is_left", c_void_p), ("iv_is_right", c_void_p),
         ("sm_vals", c_void_p), ("sm_ray_indices", c_void_p), ("sm_is_valid", c_void_p),
         ("t_starts", c_void_p), ("t_ends", c_void_p), ("terminate_planes", c_void_p),
+        ("near_plane", c_float), ("far_plane", c_float), ("t_min", c_void_p), ("t_max", c_void_p),
+        ("jitter", c_void_p), ("jitter_scale", c_float),
     ]
 
 
@@ -363,21 +365,25 @@ def _nonempty_locked(c: dict, binaries: torch.Tensor) -> int:
 
 
 def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits,
-                   near_planes, far_planes, step_size, cone_angle, limit) -> _TraverseArgs:
+                   near_planes, far_planes, step_size, cone_angle, limit, near_plane=0.0, far_plane=float("inf"),
+                   t_min=None, t_max=None, jitter=None, jitter_scale=0.0) -> _TraverseArgs:
     _check_input(rays_o, "rays_o", torch.float32)
     _check_input(rays_d, "rays_d", torch.float32)
     _check_input(aabbs, "aabbs", torch.float32)
-    _check_input(near_planes, "near_planes", torch.float32)
-    _check_input(far_planes, "far_planes", torch.float32)
     n_rays = rays_o.shape[0]
+    for t, nm in ((near_planes, "near_planes"), (far_planes, "far_planes"), (t_min, "t_min"), (t_max, "t_max"), (jitter, "jitter")):
+        if t is not None:
+            _check_input(t, nm, torch.float32)
+            if t.numel() != n_rays:
+                raise RuntimeError(f"{nm} must have n_rays elements")
     G = binaries.shape[0]
     if rays_o.shape != (n_rays, 3) or rays_d.shape != (n_rays, 3):
         raise RuntimeError("rays_o / rays_d must have shape [n_rays, 3]")
     if aabbs.shape != (G, 6):
         raise RuntimeError("aabbs must have shape [n_grids, 6]")
-    if near_planes.numel() != n_rays or far_planes.numel() != n_rays:
-        raise RuntimeError("near_planes / far_planes must have n_rays elements")
     a = _TraverseArgs()
+    a.near_plane, a.far_plane, a.jitter_scale = near_plane, far_plane, jitter_scale
+    a.t_min, a.t_max, a.jitter = _ptr(t_min), _ptr(t_max), _ptr(jitter)
     a.n_rays = n_rays
     a.rays_o, a.rays_d = _ptr(rays_o), _ptr(rays_d)
     if rays_mask is not None:
@@ -661,7 +667,8 @@ class _CtypesC:
     @staticmethod
     def sample_occgrid(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float,
                        cone_angle: float, rays_mask=None, traverse_steps_limit: int = -1,
-                       with_terminate_planes: bool = False):
+                       with_terminate_planes: bool = False, near_plane: float = 0.0, far_plane: float = float("inf"),
+                       t_min=None, t_max=None, jitter=None, jitter_scale: float = 0.0):
         """traverse_grids + the two is_left/is_right compactions of occ_grid.py:164-177 in
         one count pass and one fill pass: returns (ray_indices, t_starts, t_ends, packed_info).
         Ray/AABB tests and the per-ray event sort run inside the kernel.
@@ -678,13 +685,16 @@ class _CtypesC:
         with _Guard(rays_o):
             stream = _stream(rays_o)
             a = _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, None, None, None, near_planes, far_planes,
-                               step_size, cone_angle, traverse_steps_limit)
+                               step_size, cone_angle, traverse_steps_limit, near_plane, far_plane, t_min, t_max, jitter,
+                               jitter_scale)
             packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
             totals = _host_ints(dev)
             ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
             a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
             term = None
             if with_terminate_planes:
+                if near_planes is None:
+                    raise RuntimeError("with_terminate_planes needs near_planes as a tensor")
                 term = near_planes.clone()
                 a.terminate_planes = _ptr(term)
             _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))

@@ -100,18 +100,16 @@ class OccGridEstimator(AbstractEstimator):
         the marching lattice by U[0,1) steps.  Returns (ray_indices, t_starts, t_ends), sorted
         by ray then distance.  Not differentiable.
         """
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
-        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
-        if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
-        if t_max is not None:
-            far_planes = torch.clamp(far_planes, max=t_max)
-        if stratified:
-            near_planes += torch.rand_like(near_planes) * render_step_size
-
+        # occ_grid.py:154-163 builds near_planes / far_planes with five elementwise torch launches (full_like x2,
+        # clamp x2, rand * step added in place); here the scalars, t_min / t_max and the uniform numbers go to the
+        # kernel, which forms the same floats with the same operations (bit-identical; tests/test_gpu_estimator.py)
+        jitter = torch.rand_like(rays_o[..., 0]) if stratified else None       # same generator call as the reference
         ray_indices, t_starts, t_ends, _ = _C.sample_occgrid(
             rays_o.contiguous(), rays_d.contiguous(), self.binaries.contiguous(), self.aabbs.contiguous(),
-            near_planes.contiguous(), far_planes.contiguous(), render_step_size, cone_angle)
+            None, None, render_step_size, cone_angle, near_plane=float(near_plane), far_plane=float(far_plane),
+            t_min=None if t_min is None else t_min.contiguous().float(),
+            t_max=None if t_max is None else t_max.contiguous().float(),
+            jitter=jitter, jitter_scale=float(render_step_size))
 
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             if alpha_thre > 0.0:   # min(alpha_thre, mean) can only matter when alpha_thre > 0
