@@ -413,6 +413,9 @@ def main():
     ap.add_argument("--occ-res", type=int, default=GRID_RES,
                     help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
     ap.add_argument("--grad-chunks", type=int, default=4, help="chunks of the gradient all-reduce (N > 1)")
+    ap.add_argument("--dump-sampling-state", default="",
+                    help="write the occupancy grid and one ray batch of the timed steady state to this .npz "
+                         "(tools/traverse_replay.py replays the sampling call on it under rocprofv3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -627,6 +630,11 @@ def main():
             idx = torch.randint(0, args.pool, (int(rays_per_launch),), device=device)
             cand = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
             walk = dda_steps(pool_o[idx], pool_d[idx], est.aabbs[0], args.occ_res, 0.0, 1e10)
+        if args.dump_sampling_state:
+            np.savez_compressed(args.dump_sampling_state, binaries_bits=np.packbits(est.binaries.cpu().numpy().ravel()),
+                                res=np.array(est.binaries.shape), aabbs=est.aabbs.cpu().numpy(), rays_o=pool_o[idx].cpu().numpy(),
+                                rays_d=pool_d[idx].cpu().numpy(), jitter=torch.rand(idx.shape[0], device=device).cpu().numpy(),
+                                render_step=np.float32(RENDER_STEP), candidates=np.int64(cand))
         alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {
