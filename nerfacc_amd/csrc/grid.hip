@@ -305,8 +305,9 @@ struct BrickCache {
 //            brick the walk enters — a dependent bitmap -> rank -> brick chain through L2 costs
 //            three latencies per brick.  When the bitmap alone fits in LDS it is staged and
 //            answers the empty bricks without touching memory.
-// LDS image layout: coarse[W4] u32 | prefix[W4] u32 | compact[cap] u64, W4 = lds_words rounded to 4
-// (bitmap-only: just coarse[W4]).
+// LDS image layout: {coarse, prefix}[W4] as uint2 (ONE ds_read_b64 answers "is the brick empty" and gives its
+// rank; as two arrays the rank was a second, dependent LDS latency per non-empty brick) | compact[cap] u64,
+// W4 = lds_words rounded to 4 (bitmap-only: just coarse[W4] u32).
 template <bool LDS_OCC>
 struct Occ {
     const char *smem;
@@ -323,9 +324,9 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
     l.bytes = 0;
     uint32_t *lc = (uint32_t *)smem;
     if (LDS_OCC) {
-        uint32_t *lp = lc + l.w4;
-        uint64_t *lb = (uint64_t *)(lp + l.w4);
-        for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) { lc[i] = g.coarse[i]; lp[i] = g.prefix[i]; }
+        uint2 *lw = (uint2 *)smem;
+        uint64_t *lb = (uint64_t *)(lc + 2 * l.w4);
+        for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) lw[i] = make_uint2(g.coarse[i], g.prefix[i]);
         int n_compact = (int)g.header[0];
         if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
         for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
@@ -351,9 +352,10 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
         uint64_t bits = 0;
         const uint32_t *lc = (const uint32_t *)l.smem;
         if (LDS_OCC) {
-            const uint32_t w = lc[id >> 5];
+            const uint2 wr = ((const uint2 *)l.smem)[id >> 5];
+            const uint32_t w = wr.x;
             if (w & bit) {
-                const int k = (int)lc[l.w4 + (id >> 5)] + __popc(w & (bit - 1u));
+                const int k = (int)wr.y + __popc(w & (bit - 1u));
                 // the LDS image holds ALL non-empty bricks (make_view only selects this variant
                 // when they fit), so there is no global fallback here: a "k < cap ? lds : global"
                 // select is compiled into one flat load, which is what this code avoids

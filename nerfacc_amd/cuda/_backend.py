@@ -24,7 +24,7 @@ from typing import List, Optional, Tuple
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libnerfacc_hip.so")
+LIB_PATH = os.environ.get("NERFACC_AMD_LIB") or os.path.join(_PKG, "libnerfacc_hip.so")   # (the override is for instrumented builds, tools/phase_cycles.py)
 
 NFA_OP_SUM, NFA_OP_PROD = 0, 1
 

@@ -179,3 +179,21 @@ def test_sampling_is_reentrant_across_host_threads():
     [th.start() for th in threads]
     [th.join() for th in threads]
     assert not errors, errors[:3]
+
+
+def test_exchange_adam_fused_path_matches_torch_adam_on_device():
+    """sharding.ExchangeAdam (per-chunk torch._fused_adam_ on views of one flat buffer) vs torch.optim.Adam(fused=True)"""
+    from nerfacc_amd.sharding import ExchangeAdam
+
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(4, 33, 33, 33, device=DEV))]
+    b = [torch.nn.Parameter(a[0].detach().clone())]
+    oa = torch.optim.Adam(a, lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
+    ob = ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=4)
+    assert ob._fused
+    for it in range(5):
+        for ps, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            ((ps[0] * 0.7 - 0.1).square().sum() * (it + 1) * 1024.0).backward()
+            o.step()
+    assert torch.allclose(a[0], b[0], atol=1e-6, rtol=1e-5)

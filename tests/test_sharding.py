@@ -60,7 +60,17 @@ def _worker(rank, world, port, out_dir):
         est_b = OccGridEstimator([-1.0, -1, -1, 1, 1, 1], resolution=8, levels=1)
         est_b._update(step=0, occ_eval_fn=occ_fn)           # diverges between ranks
         sharding.broadcast_grid(est_b, src=0)
-        torch.save(dict(grad=flat, single=single.grad.clone(), counts=(s, r), occs=est.occs, occs_b=est_b.occs, bin_b=est_b.binaries, own=own_stream),
+        # --- ExchangeAdam: chunked async all-reduce with the Adam update of a chunk as soon as it has arrived
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.Tanh(), torch.nn.Linear(32, 3))
+        opt = sharding.ExchangeAdam(net.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=3)
+        for it in range(4):
+            opt.zero_grad()
+            if not (rank == 1 and it == 2):                  # a rank without samples still joins the exchange (zero grads)
+                torch.nn.functional.smooth_l1_loss(net(rays[b:e]), target[b:e]).mul(1024.0).backward()
+            opt.step()
+        chunked = torch.cat([p.detach().flatten() for p in net.parameters()])
+        torch.save(dict(grad=flat, single=single.grad.clone(), counts=(s, r), chunked=chunked, occs=est.occs, occs_b=est_b.occs, bin_b=est_b.binaries, own=own_stream),
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -84,6 +94,27 @@ def test_two_rank_step_exchange(tmp_path):
     assert torch.equal(r0["occs"], r1["occs"]) and (r0["occs"] > 0).any()
     assert torch.equal(r0["occs_b"], r1["occs_b"]) and torch.equal(r0["bin_b"], r1["bin_b"])
     assert r0["own"] != r1["own"]
+    # ExchangeAdam on 2 ranks == torch.optim.Adam on the averaged shard gradients, and the replicas stay identical
+    assert torch.equal(r0["chunked"], r1["chunked"])
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.Tanh(), torch.nn.Linear(32, 3))
+    ref_opt = torch.optim.Adam(net.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6)
+    for it in range(4):
+        ref_opt.zero_grad()
+        grads = None
+        for rk in range(world):
+            b, e = sharding.shard_bounds(64, rk, world)
+            for p in net.parameters():
+                p.grad = None
+            if not (rk == 1 and it == 2):
+                torch.nn.functional.smooth_l1_loss(net(rays[b:e]), target[b:e]).mul(1024.0).backward()
+            g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
+            grads = g if grads is None else [a + c for a, c in zip(grads, g)]
+        for p, g in zip(net.parameters(), grads):
+            p.grad = g / world
+        ref_opt.step()
+    want = torch.cat([p.detach().flatten() for p in net.parameters()])
+    assert torch.allclose(r0["chunked"], want, atol=1e-6, rtol=1e-5)
 
 
 def test_shard_bounds_cover_exactly():
@@ -108,3 +139,18 @@ def test_single_process_is_a_noop():
     assert torch.equal(p.grad, torch.full((3,), 2.0))
     assert sharding.allreduce_counts(5, 2, "cpu") == (5, 2)
     assert sharding.world() == (0, 1)
+
+
+def test_exchange_adam_single_process_matches_torch_adam():
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(300, 3)), torch.nn.Parameter(torch.randn(77))]
+    b = [torch.nn.Parameter(x.detach().clone()) for x in a]
+    oa = torch.optim.Adam(a, lr=1e-2, eps=1e-15, weight_decay=1e-6)
+    ob = sharding.ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=5)
+    for it in range(6):
+        for ps, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            (sum(((p * 1.3 - 0.2) ** 2).sum() for p in ps) * (it + 1)).backward()
+            o.step()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)

@@ -3,6 +3,7 @@ library (-DNFA_PHASE_CYCLES: shader-clock stamps between the phases of the kerne
 waves), runs the count pass on bench.py's ray batch and prints average cycles per wave and phase.
 
     python tools/phase_cycles.py [n_rays] [iters]        (NFA_SPLIT_P=<P> selects lanes per ray)
+    python tools/phase_cycles.py --state=profiles/r02_sampling_state.npz [iters]     (bench.py's steady state)
 """
 import ctypes, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,19 +17,32 @@ if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for 
                            "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", "-shared", *srcs, "-o", so])
 if "--build-only" in sys.argv:
     sys.exit(0)
+os.environ["NERFACC_AMD_BACKEND"] = "ctypes"     # the instrumented copy is loaded through the ctypes face
+os.environ["NERFACC_AMD_LIB"] = so
 import torch
 from nerfacc_amd.cuda import _backend
-_backend.LIB_PATH = so
+assert _backend.LIB_PATH == so and _backend.BACKEND == "ctypes"
 import bench
 import nerfacc_amd as nerfacc
 from nerfacc_amd import cuda as C
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-n = int(args[0]) if len(args) > 0 else 13120
-iters = int(args[1]) if len(args) > 1 else 20
+state = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--state=")]
+n = int(args[0]) if len(args) > 0 and not state else 13120
+iters = int(args[-1]) if args and (state or len(args) > 1) else 20
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
-if os.environ.get("NFA_PHASE_WORKLOAD") == "m1-random":      # rand > 0.5 grid, 4096 rays
+if state:
+    import numpy as np
+    st = np.load(state[0])
+    res = tuple(int(x) for x in st["res"])
+    binaries = torch.from_numpy(np.unpackbits(st["binaries_bits"])[: int(np.prod(res))].astype(bool).reshape(res)).to(dev)
+    aabbs = torch.from_numpy(st["aabbs"]).to(dev)
+    pool_o, pool_d = torch.from_numpy(st["rays_o"]).to(dev), torch.from_numpy(st["rays_d"]).to(dev)
+    step = float(st["render_step"])
+    n = pool_o.shape[0]
+    near = torch.from_numpy(st["jitter"]).to(dev) * step
+elif os.environ.get("NFA_PHASE_WORKLOAD") == "m1-random":      # rand > 0.5 grid, 4096 rays
     import numpy as np
     g = np.random.default_rng(42)
     v = g.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
