@@ -77,6 +77,19 @@ struct OpProd {
     static __device__ __forceinline__ float apply(float a, float b) { return a * b; }
 };
 
+// store of a per-sample output that a LATER kernel reads.  Non-temporal stores (-DNFA_NT_STORES) were measured and
+// are NOT the default: at N = 2^24 weight_fwd drops from 3.93 to 3.35 TB/s and rendering_fwd from 3.53 to 3.40 with
+// them (profiles/r02_streaming.md) — the 1.15-1.22x write traffic of these kernels is not a write-allocate effect
+// that bypassing the cache removes.
+template <class T>
+__device__ __forceinline__ void st_stream(T *p, T v) {
+#ifdef NFA_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // --- cross-lane moves on the DPP path ----------------------------------------------------
 // ds_bpermute shuffles go through the LDS crossbar (~100+ cycles each, and a scan is a chain of
 // dependent ones); DPP operand modifiers move data inside the VALU in a few cycles.  gfx950

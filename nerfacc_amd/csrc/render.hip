@@ -112,9 +112,9 @@ __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
             const float a = 1.0f - expf(-sd);
             float T = expf(-acc);
             if (prefix) T = T * prefix[i];
-            if (alphas) alphas[i] = a;
-            if (trans) trans[i] = T;
-            if (weights) weights[i] = T * a;
+            if (alphas) st_stream(alphas + i, a);
+            if (trans) st_stream(trans + i, T);
+            if (weights) st_stream(weights + i, T * a);
         }
     }
 }
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
         const unsigned long long b = __ballot(keep);
         if (keep) {
             const int64_t k = dst + __popcll(b & lanes_lt(lane));
-            o_keys[k] = keys[i];
-            o_ts[k] = ts[i];
-            o_te[k] = te[i];
+            st_stream(o_keys + k, keys[i]);
+            st_stream(o_ts + k, ts[i]);
+            st_stream(o_te + k, te[i]);
         }
         dst += __popcll(b);
     }
@@ -394,9 +394,9 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
             const float a = 1.0f - expf(-sd);
             const float T = expf(-acc);
             w = T * a;
-            alphas[i] = a;
-            trans[i] = T;
-            weights[i] = w;
+            st_stream(alphas + i, a);
+            st_stream(trans + i, T);
+            st_stream(weights + i, w);
         }
         const float sr = seg_incl_fwd(w * r, s, c_r);
         const float sg = seg_incl_fwd(w * g, s, c_g);

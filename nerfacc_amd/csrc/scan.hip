@@ -10,7 +10,8 @@
 //            8+4 bytes read and 4 written per element, no LDS, no atomics, no inter-workgroup
 //            traffic, results independent of scheduling.
 //   chunked: a row (ray) per 16-lane quarter wave — arbitrary (start,count) rows, as the
-//            reference allows — four rows per wave, 16-wide shuffle scans with a carry.
+//            reference allows — four rows per wave, 64 elements per row and trip in flight, 16-wide DPP
+//            scans with a carry.
 #include "common.hpp"
 
 namespace nfa {
@@ -88,39 +89,70 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
 // ----------------------------------------------------------------------------------------
 // chunked by (start, count): 16 lanes per row
 // ----------------------------------------------------------------------------------------
+// Each quarter wave (one DPP row) owns a row; per trip it takes 4 x 16 elements with the four loads issued before the
+// first scan (one 64-byte request per row and trip kept the HBM queues nearly empty: 2.1 TB/s), scans each 16-group
+// on the DPP path (row_shr 1/2/4/8 — no ds_bpermute) and carries the row total through v_readlane.
+template <class Op>
+__device__ __forceinline__ float row16_incl_scan(float v) {
+    v = Op::apply(dpp_f<kDppRowShr + 1>(Op::identity(), v), v);
+    v = Op::apply(dpp_f<kDppRowShr + 2>(Op::identity(), v), v);
+    v = Op::apply(dpp_f<kDppRowShr + 4>(Op::identity(), v), v);
+    v = Op::apply(dpp_f<kDppRowShr + 8>(Op::identity(), v), v);
+    return v;
+}
+// value of lane 15 of this lane's 16-lane row, in every lane of the row
+__device__ __forceinline__ float row16_last(float v, int lane) {
+    const float a = readlane_f<15>(v), b = readlane_f<31>(v), c = readlane_f<47>(v), d = readlane_f<63>(v);
+    return (lane & 32) ? ((lane & 16) ? d : c) : ((lane & 16) ? b : a);
+}
+
 template <class Op, bool INCL>
 __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
     const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts, int64_t n_rows,
     const float *__restrict__ in, const float *__restrict__ mul, const float *__restrict__ div,
     float *__restrict__ out, int reverse, int normalize)
 {
-    const int sub = threadIdx.x & 15;
+    const int lane = lane_id(), sub = lane & 15;
     const int64_t rows_per_block = kBlock / 16;
-    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < n_rows;
-         row += (int64_t)gridDim.x * rows_per_block) {
-        const int64_t start = starts[row], cnt = cnts[row];
-        if (cnt <= 0) continue;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4);
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    // all four rows of a wave iterate together (the DPP / readlane steps are wave-wide): trips = the longest row
+    for (int64_t rbase = row0 - (lane >> 4); rbase < n_rows; rbase += stride) {
+        const int64_t row = rbase + (lane >> 4);
+        const bool row_ok = row < n_rows;
+        const int64_t start = row_ok ? starts[row] : 0, cnt = row_ok ? cnts[row] : 0;
+        int64_t cmax = cnt;
+        cmax = max(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = max(cmax, __shfl_xor(cmax, 32, 64));
         float carry = Op::identity();
-        for (int64_t c = 0; c < cnt; c += 16) {
-            const int64_t k = c + sub;
-            const bool active = k < cnt;
-            const int64_t i = reverse ? (start + cnt - 1 - k) : (start + k);
-            float v = Op::identity();
-            if (active) { v = in[i]; if (mul) v *= mul[i]; }
-            float incl = v;
+        constexpr int U = 4;
+        for (int64_t c = 0; c < cmax; c += 16 * U) {
+            float v[U], dv[U];
+            int64_t idx[U];
+            bool act[U];
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float u = __shfl_up(incl, off, 16);
-                if (sub >= off) incl = Op::apply(u, incl);
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = c + 16 * u + sub;
+                act[u] = k < cnt;
+                idx[u] = reverse ? (start + cnt - 1 - k) : (start + k);
+                v[u] = Op::identity();
+                dv[u] = 1.0f;
+                if (act[u]) {
+                    v[u] = in[idx[u]];
+                    if (mul) v[u] *= mul[idx[u]];
+                    if (div) dv[u] = div[idx[u]];
+                }
             }
-            incl = Op::apply(carry, incl);
-            float excl = __shfl_up(incl, 1, 16);
-            if (sub == 0) excl = carry;
-            carry = __shfl(incl, 15, 16);
-            if (active) {
-                float r = INCL ? incl : excl;
-                if (div) r = r / fmaxf(div[i], 1e-10f);
-                out[i] = r;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float incl = Op::apply(carry, row16_incl_scan<Op>(v[u]));
+                float excl = dpp_f<kDppRowShr + 1>(carry, incl);          // lane 0 of the row has no source: keeps `carry`
+                carry = row16_last(incl, lane);
+                if (act[u]) {
+                    float r = INCL ? incl : excl;
+                    if (div) r = r / fmaxf(dv[u], 1e-10f);
+                    out[idx[u]] = r;
+                }
             }
         }
         if (normalize) {  // utils_scan.cuh:101-109 / 228-236: divide by the row total
