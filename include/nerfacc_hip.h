@@ -79,6 +79,13 @@ int nfa_grid_cell_points(const int64_t *cell_ids, int64_t n, const float *jitter
                          int32_t rx, int32_t ry, int32_t rz, const float *aabb, float *points, void *stream);
 int nfa_grid_ema_update(float *occs, const int64_t *cell_ids, int64_t n, const float *occ_new,
                         float ema_decay, float *scratch, void *stream);
+/* nfa_grid_mark_invisible :262-332  occs[id_i] = (some camera sees the cell at depth >= near_plane and none sees it nearer) ? 0 : -1
+ *                        for the cells of ONE level (`occs` points at the level's first cell, `aabb` = its 6 floats, ids
+ *                        level-local, nullable = cells 0..n-1).  w2c_R [n_cams,9] / w2c_T [n_cams,3]: world-to-camera rotation
+ *                        and translation (row-major); K [n_cams,9], or [1,9] shared by all cameras when k_shared != 0. */
+int nfa_grid_mark_invisible(float *occs, const int64_t *cell_ids, int64_t n, int32_t rx, int32_t ry, int32_t rz,
+                            const float *aabb, const float *w2c_R, const float *w2c_T, const float *K,
+                            int32_t n_cams, int32_t k_shared, float width, float height, float near_plane, void *stream);
 int64_t nfa_grid_threshold_workspace_bytes(void);
 int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_thre, void *workspace,
                        uint8_t *binaries, float *threshold_out, void *stream);

@@ -106,10 +106,63 @@ __global__ __launch_bounds__(kBlock) void grid_threshold_kernel(
         binaries[i] = occs[i] > thre ? 1 : 0;
 }
 
+// OccGridEstimator.mark_invisible_cells (occ_grid.py:262-332; ~15 ATen ops per 32^3-cell chunk there, incl. two
+// batched matmuls that materialise [n_cams, 3, chunk] tensors): one lane per cell, cameras in a loop.
+//   x = coords / (res - 1); xyz = lo + x * (hi - lo); p = R_c xyz + T_c; uvd = K_c p; uv = uvd.xy / uvd.z
+//   in_image = uvd.z >= 0 & 0 <= u < width & 0 <= v < height
+//   valid = any_c(uvd.z >= near & in_image) & !any_c(uvd.z < near & in_image);  occs[cell] = valid ? 0 : -1
+// Dot products are accumulated left to right without contraction; a BLAS may order / fuse them differently, which
+// can only matter for a cell whose projection lies within an ulp of an image border.
+__global__ __launch_bounds__(kBlock) void grid_mark_invisible_kernel(
+    float *__restrict__ occs, const int64_t *__restrict__ cell_ids, int64_t n, int rx, int ry, int rz,
+    const float *__restrict__ aabb, const float *__restrict__ w2c_R, const float *__restrict__ w2c_T,
+    const float *__restrict__ K, int n_cams, int k_stride, float width, float height, float near_plane)
+{
+    const float lo[3] = {aabb[0], aabb[1], aabb[2]};
+    const float ext[3] = {aabb[3] - lo[0], aabb[4] - lo[1], aabb[5] - lo[2]};
+    const float den[3] = {(float)(rx - 1), (float)(ry - 1), (float)(rz - 1)};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t id = cell_ids ? cell_ids[i] : i;
+        const int64_t yz = (int64_t)ry * rz;
+        const int c[3] = {(int)(id / yz), (int)((id / rz) % ry), (int)(id % rz)};
+        float w[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) w[a] = lo[a] + ((float)c[a] / den[a]) * ext[a];
+        bool covered = false, too_near = false;
+        for (int cam = 0; cam < n_cams; ++cam) {          // camera data: wave-uniform addresses (scalar loads)
+            const float *R = w2c_R + 9 * cam, *T = w2c_T + 3 * cam, *Kc = K + (int64_t)k_stride * cam;
+            float p[3], u[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) p[r] = ((R[3 * r] * w[0] + R[3 * r + 1] * w[1]) + R[3 * r + 2] * w[2]) + T[r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) u[r] = (Kc[3 * r] * p[0] + Kc[3 * r + 1] * p[1]) + Kc[3 * r + 2] * p[2];
+            const float px = u[0] / u[2], py = u[1] / u[2];
+            const bool in_image = (u[2] >= 0.0f) && (px >= 0.0f) && (px < width) && (py >= 0.0f) && (py < height);
+            covered = covered || (in_image && u[2] >= near_plane);
+            too_near = too_near || (in_image && u[2] < near_plane);
+        }
+        occs[id] = (covered && !too_near) ? 0.0f : -1.0f;
+    }
+}
+
 }  // namespace
 }  // namespace nfa
 
 using namespace nfa;
+
+NFA_EXPORT int nfa_grid_mark_invisible(float *occs, const int64_t *cell_ids, int64_t n, int32_t rx, int32_t ry, int32_t rz,
+                                       const float *aabb, const float *w2c_R, const float *w2c_T, const float *K,
+                                       int32_t n_cams, int32_t k_shared, float width, float height, float near_plane, void *stream)
+{
+    NFA_REQUIRE(n >= 0 && n_cams >= 0, "grid_mark_invisible: negative size");
+    NFA_REQUIRE(rx > 0 && ry > 0 && rz > 0, "grid_mark_invisible: bad resolution %d x %d x %d", rx, ry, rz);
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(occs && aabb && (n_cams == 0 || (w2c_R && w2c_T && K)), "grid_mark_invisible: NULL pointer");
+    NFA_REQUIRE(cell_ids || n <= (int64_t)rx * ry * rz, "grid_mark_invisible: n exceeds the cells of one level");
+    hipLaunchKernelGGL(grid_mark_invisible_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, occs, cell_ids, n,
+                       rx, ry, rz, aabb, w2c_R, w2c_T, K, n_cams, k_shared ? 0 : 9, width, height, near_plane);
+    return check_launch("grid_mark_invisible_kernel");
+}
 
 NFA_EXPORT int nfa_grid_cell_points(const int64_t *cell_ids, int64_t n, const float *jitter,
                                     int32_t rx, int32_t ry, int32_t rz, const float *aabb,

@@ -752,6 +752,24 @@ void grid_ema_update(const Tensor &occs_level, const OptTensor &cell_ids, const 
     check_rc(nfa_grid_ema_update(ptr<float>(occs_level), ptr<int64_t>(cell_ids), n, ptr<float>(occ_new), (float)ema_decay, ptr<float>(scratch), s));
 }
 
+void grid_mark_invisible(const Tensor &occs_level, const OptTensor &cell_ids, const std::vector<int64_t> &resolution, const Tensor &aabb,
+                         const Tensor &w2c_R, const Tensor &w2c_T, const Tensor &K, double width, double height, double near_plane) {
+    check_input(occs_level, "occs", at::kFloat);
+    check_input(aabb, "aabb", at::kFloat);
+    check_input(w2c_R, "w2c_R", at::kFloat);
+    check_input(w2c_T, "w2c_T", at::kFloat);
+    check_input(K, "K", at::kFloat);
+    int64_t n = occs_level.numel();
+    if (cell_ids) { check_input(*cell_ids, "cell_ids", at::kLong); n = cell_ids->numel(); }
+    const int64_t C = w2c_R.size(0);
+    TORCH_CHECK(w2c_R.numel() == 9 * C && w2c_T.numel() == 3 * C && (K.numel() == 9 || K.numel() == 9 * C) && resolution.size() == 3,
+                "grid_mark_invisible: w2c_R [C,3,3], w2c_T [C,3,1], K [C or 1,3,3] expected");
+    Guard g(device_of(occs_level));
+    check_rc(nfa_grid_mark_invisible(ptr<float>(occs_level), ptr<int64_t>(cell_ids), n, (int32_t)resolution[0], (int32_t)resolution[1],
+                                     (int32_t)resolution[2], ptr<float>(aabb), ptr<float>(w2c_R), ptr<float>(w2c_T), ptr<float>(K), (int32_t)C,
+                                     (K.numel() == 9 && C != 1) ? 1 : 0, (float)width, (float)height, (float)near_plane, stream_of(occs_level)));
+}
+
 py::tuple grid_threshold(const Tensor &occs, double occ_thre) {
     check_input(occs, "occs", at::kFloat);
     const int64_t n = occs.numel();
@@ -837,6 +855,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("grid_cell_points", &grid_cell_points);
     m.def("grid_ema_update", &grid_ema_update);
     m.def("grid_threshold", &grid_threshold);
+    m.def("grid_mark_invisible", &grid_mark_invisible);
     m.def("packed_bricks", &packed_bricks);
     m.def("set_timing", &set_timing, "names"_a = py::none());
     m.def("timing_summary", &timing_summary);

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nfa_grid_cell_points": (ctypes.c_int, [_P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nfa_grid_ema_update": (ctypes.c_int, [_P, _P, c_int64, _P, c_float, _P, _P]),
+    "nfa_grid_mark_invisible": (ctypes.c_int, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int32, c_int32,
+                                               c_float, c_float, c_float, _P]),
     "nfa_grid_threshold_workspace_bytes": (c_int64, []),
     "nfa_grid_threshold": (ctypes.c_int, [_P, c_int64, c_float, _P, _P, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
@@ -864,6 +866,25 @@ class _CtypesC:
             _check(_call("grid_ema_update", load_library().nfa_grid_ema_update,
                          _ptr(occs_level), _ptr(cell_ids), n, _ptr(occ_new), float(ema_decay), _ptr(scratch),
                          _stream(occs_level)))
+
+    @staticmethod
+    def grid_mark_invisible(occs_level, cell_ids, resolution, aabb, w2c_R, w2c_T, K, width: float, height: float, near_plane: float):
+        """in place on one level: occs_level[cell_ids] = 0 where a camera covers the cell (and none is nearer than
+        near_plane in front of it), -1 elsewhere (occ_grid.py:262-332).  w2c_R [C,3,3], w2c_T [C,3,1], K [C or 1,3,3]."""
+        for t, nm in ((occs_level, "occs"), (aabb, "aabb"), (w2c_R, "w2c_R"), (w2c_T, "w2c_T"), (K, "K")):
+            _check_input(t, nm, torch.float32)
+        n = occs_level.numel()
+        if cell_ids is not None:
+            _check_input(cell_ids, "cell_ids", torch.int64)
+            n = cell_ids.numel()
+        C = w2c_R.shape[0]
+        if w2c_R.numel() != 9 * C or w2c_T.numel() != 3 * C or K.numel() not in (9, 9 * C):
+            raise RuntimeError("grid_mark_invisible: w2c_R [C,3,3], w2c_T [C,3,1], K [C or 1,3,3] expected")
+        rx, ry, rz = (int(r) for r in resolution)
+        with _Guard(occs_level):
+            _check(load_library().nfa_grid_mark_invisible(_ptr(occs_level), _ptr(cell_ids), n, rx, ry, rz, _ptr(aabb), _ptr(w2c_R),
+                                                          _ptr(w2c_T), _ptr(K), C, int(K.numel() == 9 and C != 1), float(width),
+                                                          float(height), float(near_plane), _stream(occs_level)))
 
     @staticmethod
     def grid_threshold(occs, occ_thre: float):

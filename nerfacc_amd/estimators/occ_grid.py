@@ -156,6 +156,19 @@ class OccGridEstimator(AbstractEstimator):
         rot_w2c = c2w[:, :3, :3].transpose(2, 1)
         trans_w2c = -rot_w2c @ c2w[:, :3, 3:]
 
+        if self.occs.is_cuda:
+            # device path: one launch per level (csrc/occgrid.hip) instead of ~15 ATen ops per 32^3-cell chunk
+            res = tuple(self.binaries.shape[1:])
+            K_dev = K.to(self.occs.device, torch.float32).contiguous()
+            R_dev = rot_w2c.to(self.occs.device, torch.float32).contiguous()
+            T_dev = trans_w2c.to(self.occs.device, torch.float32).contiguous()
+            for lvl, indices in enumerate(self._get_all_cells()):
+                lo = lvl * self.cells_per_lvl
+                _C.grid_mark_invisible(self.occs[lo:lo + self.cells_per_lvl], indices.contiguous(), res, self.aabbs[lvl].contiguous(),
+                                       R_dev, T_dev, K_dev, float(width), float(height), float(near_plane))
+            self._occs_changed()
+            return
+
         for lvl, indices in enumerate(self._get_all_cells()):
             coords = self.grid_coords[indices]
             lo, hi = self.aabbs[lvl, :3], self.aabbs[lvl, 3:]

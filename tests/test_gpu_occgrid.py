@@ -136,3 +136,41 @@ def test_update_end_to_end_vs_oracle():
         assert np.array_equal(n(est.binaries).ravel()[~near], binaries[~near])
         binaries = n(est.binaries).ravel().copy()
     assert 0 < binaries.sum() < binaries.size
+
+
+def test_mark_invisible_cells_device_kernel_vs_reference_composition(golden):
+    """device kernel (occgrid.hip) vs the reference's torch composition on host tensors (occ_grid.py:262-332, pinned bit for
+    bit by tests/golden: 77660 / 53412 cells of tests/test_grid.py:232-233)"""
+    from nerfacc_amd import OccGridEstimator
+
+    base = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    K = torch.tensor([[[100.0, 0, 50.0], [0, 100.0, 50.0], [0, 0, 1]]])
+    pose = torch.tensor([[[-1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -1.0, 2.5]]])
+    est = OccGridEstimator(roi_aabb=base, resolution=32, levels=4).to(DEV)
+    est.mark_invisible_cells(K.to(DEV), pose.to(DEV), 100, 100)
+    occs = est.occs.cpu()
+    assert (occs == -1).sum() == 77660 and (occs == 0).sum() == 53412
+    assert np.array_equal(np.packbits((occs == -1).numpy()), golden["mic_occs_bits"])
+    # many cameras, per-camera intrinsics, a near plane, a non-cubic grid: device vs host composition
+    g = torch.Generator().manual_seed(5)
+    C = 37
+    pos = torch.randn(C, 3, generator=g)
+    pos = 3.0 * pos / pos.norm(dim=-1, keepdim=True)
+    fwd = -pos / pos.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm(dim=-1, keepdim=True)
+    tup = torch.linalg.cross(right, fwd)
+    c2w = torch.cat([torch.stack([right, -tup, fwd], -1), pos[:, :, None]], -1)        # OpenCV camera: +z forward
+    Ks = torch.tensor([[60.0, 0, 40.0], [0, 60.0, 30.0], [0, 0, 1]]).repeat(C, 1, 1) * (1 + 0.1 * torch.rand(C, 1, 1, generator=g))
+    Ks[:, 2, 2] = 1.0
+    host = OccGridEstimator(roi_aabb=[-1.0, -0.8, -0.6, 1.0, 0.8, 0.6], resolution=[24, 20, 16], levels=2)
+    host.mark_invisible_cells(Ks, c2w, 80, 60, near_plane=1.4)
+    dev = OccGridEstimator(roi_aabb=[-1.0, -0.8, -0.6, 1.0, 0.8, 0.6], resolution=[24, 20, 16], levels=2).to(DEV)
+    dev.mark_invisible_cells(Ks.to(DEV), c2w.to(DEV), 80, 60, near_plane=1.4)
+    a, b = host.occs, dev.occs.cpu()
+    assert 0.05 < (a == -1).float().mean() < 0.95
+    assert (a != b).sum().item() <= 2, (a != b).sum().item()      # only a projection within an ulp of an image border may flip
+    # cells marked invisible are excluded from the next update
+    dev._update(step=0, occ_eval_fn=lambda x: torch.full((x.shape[0], 1), 0.5, device=DEV))
+    assert (dev.occs[b.to(DEV) == -1] == -1).all() and (dev.occs[b.to(DEV) == 0] > 0).all()
