@@ -152,8 +152,9 @@ class ExchangeAdam:
         p, g, m, v = self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b]
         b1, b2 = self.betas
         if self._fused:
-            # one launch per chunk; state_steps holds the step count BEFORE the update
-            step = self.step_tensor.clone()
+            # one launch per chunk; state_steps holds the 1-based number of THIS step (torch's _fused_adam increments
+            # its step tensors before the call), and the kernel does not modify it
+            step = self.step_tensor
             torch._fused_adam_([p], [g], [m], [v], [], [step], lr=self.lr, beta1=b1, beta2=b2,
                                weight_decay=self.weight_decay, eps=self.eps, amsgrad=False, maximize=False)
             return
@@ -169,6 +170,7 @@ class ExchangeAdam:
         """all-reduce (average) the flat gradient chunk by chunk and update every chunk as it arrives"""
         rank, ws = world()
         self.t += 1
+        self.step_tensor += 1
         works = []
         if ws > 1:
             for a, b in self.bounds:
@@ -179,7 +181,6 @@ class ExchangeAdam:
                 if self.average:
                     self.grad[a:b].div_(ws)
             self._adam(a, b)
-        self.step_tensor += 1
 
 
 def broadcast_grid(estimator, src: int = 0) -> None:
