@@ -148,7 +148,7 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes
     L.orc_traverse_fill(*common, use_mask, *grid,
                         _p(iv_starts), _p(iv_cnts), _p(sm_starts), _p(sm_cnts),
                         _p(iv["vals"]), _p(iv["ray_indices"]), _p(iv["is_left"]), _p(iv["is_right"]),
-                        _p(sm["vals"]), _p(sm["ray_indices"]), _p(sm["is_valid"]), _p(term))
+                        _p(sm["vals"]), _p(sm["ray_indices"]), _p(sm["is_valid"]), _p(term), None, None)
     if over_allocate:
         # grid.cu:402-404: chunk_starts recomputed from the ACTUAL counts
         iv_starts = np.cumsum(iv_cnts) - iv_cnts
@@ -194,16 +194,32 @@ def sampling(rays_o, rays_d, binaries, aabbs, near_plane=0.0, far_plane=1e10, t_
 
 
 def sample_occgrid(rays_o, rays_d, binaries, aabbs, near, far, step_size, cone_angle=0.0):
-    """traverse_grids + the two boolean-mask gathers of occ_grid.py:174-176 with the gathers done per ray in C
-    (threaded when set_threads > 1): (ray_indices, t_starts, t_ends, packed_info).  Equal to
-    `traverse_grids` followed by `vals[is_left]`, `vals[is_right]` (tests/test_oracle.py)."""
-    iv, sm, _ = traverse_grids(rays_o, rays_d, binaries, aabbs, near, far, step_size, cone_angle)
-    n = sm["ray_indices"].shape[0]
-    ts, te = np.empty(n, np.float32), np.empty(n, np.float32)
-    lib().orc_intervals_to_samples(_c_i64(iv["chunk_cnts"].shape[0]), _p(_i64(iv["chunk_starts"])), _p(_i64(iv["chunk_cnts"])),
-                                   _p(iv["vals"]), _p(_u8(iv["is_left"])), _p(_u8(iv["is_right"])),
-                                   _p(_i64(sm["chunk_starts"])), _p(ts), _p(te))
-    return sm["ray_indices"], ts, te, sm["packed_info"]
+    """traverse_grids + the two boolean-mask gathers of occ_grid.py:174-176, with each sample's interval written by
+    the fill pass itself (threaded when set_threads > 1; no edge arrays, no serial numpy passes):
+    (ray_indices, t_starts, t_ends, packed_info).  Equal to `traverse_grids` followed by `vals[is_left]`,
+    `vals[is_right]` (tests/test_oracle.py)."""
+    rays_o, rays_d, aabbs = _f32(rays_o), _f32(rays_d), _f32(aabbs)
+    binaries = _u8(binaries)
+    R, G = rays_o.shape[0], binaries.shape[0]
+    res = np.asarray(binaries.shape[1:], np.int32)
+    near, far = _f32(near), _f32(far)
+    t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+    cat = np.concatenate([t_mins, t_maxs], -1)
+    t_indices = np.argsort(cat, axis=-1, kind="stable").astype(np.int64)
+    t_sorted = _f32(np.take_along_axis(cat, t_indices, -1))
+    hits = _u8(hits)
+    common = (_c_i64(R), _p(rays_o), _p(rays_d))
+    grid = (_c_i32(G), _p(res), _p(binaries), _p(aabbs), _p(hits), _p(t_sorted), _p(t_indices),
+            _p(near), _p(far), _c_f(step_size), _c_f(cone_angle), _c_i32(-1))
+    sm_cnts = np.empty(R, np.int64)
+    L = lib()
+    L.orc_traverse_count(*common, None, *grid, None, _p(sm_cnts), None)
+    sm_starts = np.cumsum(sm_cnts) - sm_cnts
+    n = int(sm_cnts.sum())
+    ri, ts, te = np.empty(n, np.int64), np.empty(n, np.float32), np.empty(n, np.float32)
+    L.orc_traverse_fill(*common, None, *grid, None, None, _p(sm_starts), _p(sm_cnts),
+                        None, None, None, None, None, _p(ri), None, None, _p(ts), _p(te))
+    return ri, ts, te, np.stack([sm_starts, sm_cnts], -1)
 
 
 def compact(keep, ray_indices, t_starts, t_ends, packed_info):

@@ -187,6 +187,9 @@ typedef struct {
     float *iv_vals; int64_t *iv_ray; uint8_t *iv_left; uint8_t *iv_right;
     /* samples (may be NULL) */
     float *sm_vals; int64_t *sm_ray; uint8_t *sm_valid;
+    /* the interval of every sample, written directly: what occ_grid.py:174-175 extracts from the edges with
+     * vals[is_left] / vals[is_right] (may be NULL; needs sm_ray) */
+    float *t_starts; float *t_ends;
 } orc_emit_t;
 
 /* one ray of traverse_grids_kernel; `emit` NULL => counting pass */
@@ -266,6 +269,11 @@ static void traverse_ray(
                             n_iv += 1;
                         }
                     }
+                    if (emit && emit->t_starts) {
+                        const int64_t k = sm_base + n_sm;
+                        emit->t_starts[k] = t_last; emit->t_ends[k] = t_next;
+                        if (!emit->sm_vals) emit->sm_ray[k] = tid;
+                    }
                     if (emit && emit->sm_vals) { /* sample midpoint, grid.cu:248-255 */
                         const int64_t k = sm_base + n_sm;
                         emit->sm_vals[k] = (t_next + t_last) * 0.5f;
@@ -321,10 +329,10 @@ ORC_API void orc_traverse_fill(
     const int64_t *iv_starts, int64_t *iv_cnts, const int64_t *sm_starts, int64_t *sm_cnts,
     float *iv_vals, int64_t *iv_ray, uint8_t *iv_left, uint8_t *iv_right,
     float *sm_vals, int64_t *sm_ray, uint8_t *sm_valid,
-    float *terminate_planes)
+    float *terminate_planes, float *t_starts, float *t_ends)
 {
     const int r3[3] = {res[0], res[1], res[2]};
-    orc_emit_t e = {iv_vals, iv_ray, iv_left, iv_right, sm_vals, sm_ray, sm_valid};
+    orc_emit_t e = {iv_vals, iv_ray, iv_left, iv_right, sm_vals, sm_ray, sm_valid, t_starts, t_ends};
 #pragma omp parallel for schedule(dynamic, 64) num_threads(orc_threads) if (orc_threads > 1)
     for (int64_t r = 0; r < n_rays; ++r) {
         if (rays_mask && !rays_mask[r]) continue;
