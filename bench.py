@@ -42,6 +42,12 @@ import os
 import sys
 import time
 
+# two OpenMP runtimes live in this process during the cpu_baseline leg (torch's bundled one and the oracle's); with
+# the default active wait policy the idle team of one spins on the cores the other needs (measured: 3 s instead of
+# 1 ms for a torch op on 256 threads).  Must be set before either runtime is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -251,7 +257,7 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
     o1, d1 = pool_o[:n1].cpu().numpy(), pool_d[:n1].cpu().numpy()
     oracle.set_threads(1)
     (t1, s1, c1), reps1 = timed(o1, d1, 5, 0.3)
-    n_all = int(min(pool_o.shape[0], max(16384, 1024 * cores)))
+    n_all = int(min(pool_o.shape[0], max(16384, int(os.environ.get('NFA_CPU_RAYS_PER_CORE', '256')) * cores)))
     oa, da = pool_o[:n_all].cpu().numpy(), pool_d[:n_all].cpu().numpy()
     used = oracle.set_threads(cores)
     try:
@@ -317,6 +323,10 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
         "single_thread": {"value": n1 / t1, "unit": "rays/s", "samples_per_sec": s1 / t1,
                           "sample": f"{n1} rays, same pipeline, 1 thread, median of {reps1}, radiance-field evaluation excluded"},
         "all_cores_over_single_thread": (n_all / ta) / (n1 / t1),
+        "scaling_note": "the C stages are OpenMP loops over rays; what does not scale is between them: numpy glue (event sort, cumsum, "
+                        "dtype casts), waking the thread team for each of ~8 stages, and first-touch page faults of freshly mapped output "
+                        "arrays, which serialise in the kernel — a few tens of ms per run against ~2 ms of parallel work at this sample size; "
+                        "larger samples shift the cost to page faults (262144 rays: 326 ms per run, 7x over one thread)",
         "pure_torch": {
             "workload": f"configs[0]: 128^3 sphere grid, {R} rays into the unit cube, step 1/600 -> {N} samples "
                         f"(max {int(pk[:, 1].max())} per ray); render_weight_from_density fwd+bwd, torch CPU, warm-up + median of up to 10, "
