@@ -886,11 +886,17 @@ __device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC>
 // end (one slot per wave, no atomics); read back with nfa_debug_phase_cycles
 constexpr int kPhaseSlots = 16384;
 __device__ unsigned long long g_phase_cycles[kPhaseSlots][16];
+__device__ unsigned long long g_phase_max_wave = 0, g_phase_hist[16] = {0};     // slowest wave; histogram of wave totals in 16 k-cycle bins
 #define NFA_PHASE_BEGIN() unsigned long long ph_[16] = {0}; unsigned long long phase_t_ = __builtin_readcyclecounter(); const unsigned long long phase_t0_ = phase_t_
 #define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
 #define NFA_PHASE_END()                                                                        \
     do {                                                                                      \
         const int slot_ = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);           \
+        if (lane_id() == 0) {                                                                 \
+            const unsigned long long tot_ = __builtin_readcyclecounter() - phase_t0_;          \
+            atomicMax(&g_phase_max_wave, tot_);                                                \
+            atomicAdd(&g_phase_hist[tot_ >> 14 > 15 ? 15 : tot_ >> 14], 1ull);                 \
+        }                                                                                     \
         if (lane_id() == 0 && slot_ < kPhaseSlots) {                                          \
             ph_[14] = phase_t0_; ph_[15] = 1;                                                  \
             for (int i_ = 0; i_ < 16; ++i_) g_phase_cycles[slot_][i_] += ph_[i_];              \
@@ -1559,10 +1565,18 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         // too small to fill the chip with one lane per ray; beyond ~40 k rays the lane-per-ray
         // walk does the same job in fewer instructions.  Dense / noisy grids have a boundary every
         // few voxels, so their parts are kept shorter (more lanes per ray).
-        if (a->n_rays <= 8192) P = sparse ? 8 : 16;
-        else if (a->n_rays <= 16384) P = 8;
-        else if (a->n_rays <= 36864) P = 4;
-        else if (a->n_rays <= 65536) P = 2;
+        if (sparse) {
+            // profiles/r02_split_sweep.md (bench steady state: ~190 voxels and 40 samples per ray): 16 lanes per ray with
+            // 16-entry boundary lists while the launch fits two workgroups per CU (<= 8192 rays), 8 lanes up to ~49 k rays,
+            // lane-per-ray beyond; 4 and 2 lanes per ray never win on a sparse grid
+            if (a->n_rays <= 8192) P = 16;
+            else if (a->n_rays <= 49152) P = 8;
+        } else {
+            if (a->n_rays <= 8192) P = 16;
+            else if (a->n_rays <= 16384) P = 8;
+            else if (a->n_rays <= 36864) P = 4;
+            else if (a->n_rays <= 65536) P = 2;
+        }
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
@@ -1579,7 +1593,8 @@ struct SplitPlan { int P, cap, lds; GridView gv; };
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
     p.P = count_lanes_per_ray(a, true);
-    p.cap = p.P >= 16 ? 8 : 16;
+    p.cap = 16;      // (8-entry lists at P = 16 overflow into the streaming mode on a trained scene: 80 us instead of 44)
+    if (const char *e = getenv("NFA_SPLIT_CAP")) { const int v = atoi(e); if (v == 8 || v == 16) p.cap = v; }   // tuning knob
     p.lds = 0;
     if (p.P <= 1) return p;
     p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
@@ -1615,7 +1630,8 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     } while (0)
         if (lds_occ) {
             if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
-            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
+            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16);
+            else if (plan.cap == 16) NFA_LAUNCH_SPLIT(true, 16, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
         } else {
             if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 32); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 32);
             else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 32); else NFA_LAUNCH_SPLIT(false, 16, 32);
@@ -1721,6 +1737,20 @@ extern "C" __attribute__((visibility("default"))) int nfa_debug_phase_cycles(uns
     static unsigned long long host[nfa::kPhaseSlots][16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(nfa::g_phase_cycles), sizeof(host)) != hipSuccess) return 1;
     for (int i = 0; i < 16; ++i) out16[i] = 0;
+    {
+        unsigned long long mx = 0, hist[16];
+        if (hipMemcpyFromSymbol(&mx, HIP_SYMBOL(nfa::g_phase_max_wave), sizeof(mx)) == hipSuccess &&
+            hipMemcpyFromSymbol(hist, HIP_SYMBOL(nfa::g_phase_hist), sizeof(hist)) == hipSuccess) {
+            fprintf(stderr, "[phase] slowest wave %llu cycles; waves per 16k-cycle bin:", mx);
+            for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hist[i]);
+            fprintf(stderr, "\n");
+        }
+        if (clear) {
+            void *sym = nullptr;
+            if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_max_wave)) == hipSuccess) (void)hipMemset(sym, 0, sizeof(mx));
+            if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_hist)) == hipSuccess) (void)hipMemset(sym, 0, sizeof(hist));
+        }
+    }
     unsigned long long t_min = ~0ull, t_max = 0;
     for (int w = 0; w < nfa::kPhaseSlots; ++w) {
         if (!host[w][15]) continue;

@@ -17,6 +17,11 @@ binaries = torch.from_numpy(np.unpackbits(st["binaries_bits"])[: int(np.prod(res
 aabbs = torch.from_numpy(st["aabbs"]).to(dev)
 O, D = torch.from_numpy(st["rays_o"]).to(dev), torch.from_numpy(st["rays_d"]).to(dev)
 jit = torch.from_numpy(st["jitter"]).to(dev)
+for a in sys.argv:
+    if a.startswith("--rays="):          # tile / truncate the ray batch to this many rays (lanes-per-ray sweeps)
+        n_ = int(a.split("=")[1])
+        rep = -(-n_ // O.shape[0])
+        O, D, jit = O.repeat(rep, 1)[:n_].contiguous(), D.repeat(rep, 1)[:n_].contiguous(), jit.repeat(rep)[:n_].contiguous()
 step = float(st["render_step"])
 C = _backend._C
 def call():
