@@ -887,6 +887,7 @@ __device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC>
 constexpr int kPhaseSlots = 16384;
 __device__ unsigned long long g_phase_cycles[kPhaseSlots][16];
 __device__ unsigned long long g_phase_max_wave = 0, g_phase_hist[16] = {0};     // slowest wave; histogram of wave totals in 16 k-cycle bins
+__device__ unsigned long long g_phase_slow[16] = {0};                           // phase sums over the waves slower than 88 k cycles ([15] = how many)
 #define NFA_PHASE_BEGIN() unsigned long long ph_[16] = {0}; unsigned long long phase_t_ = __builtin_readcyclecounter(); const unsigned long long phase_t0_ = phase_t_
 #define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
 #define NFA_PHASE_END()                                                                        \
@@ -896,6 +897,7 @@ __device__ unsigned long long g_phase_max_wave = 0, g_phase_hist[16] = {0};     
             const unsigned long long tot_ = __builtin_readcyclecounter() - phase_t0_;          \
             atomicMax(&g_phase_max_wave, tot_);                                                \
             atomicAdd(&g_phase_hist[tot_ >> 14 > 15 ? 15 : tot_ >> 14], 1ull);                 \
+            if (tot_ > 88000ull) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_phase_slow[i_], ph_[i_]); atomicAdd(&g_phase_slow[15], 1ull); } \
         }                                                                                     \
         if (lane_id() == 0 && slot_ < kPhaseSlots) {                                          \
             ph_[14] = phase_t0_; ph_[15] = 1;                                                  \
@@ -1760,11 +1762,18 @@ extern "C" __attribute__((visibility("default"))) int nfa_debug_phase_cycles(uns
             fprintf(stderr, "[phase] slowest wave %llu cycles; waves per 16k-cycle bin:", mx);
             for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hist[i]);
             fprintf(stderr, "\n");
+            unsigned long long slow[16];
+            if (hipMemcpyFromSymbol(slow, HIP_SYMBOL(nfa::g_phase_slow), sizeof(slow)) == hipSuccess && slow[15]) {
+                fprintf(stderr, "[phase] %llu waves slower than 88 k cycles, average per phase:", slow[15]);
+                for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", slow[i] / slow[15]);
+                fprintf(stderr, "\n");
+            }
         }
         if (clear) {
             void *sym = nullptr;
             if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_max_wave)) == hipSuccess) (void)hipMemset(sym, 0, sizeof(mx));
             if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_hist)) == hipSuccess) (void)hipMemset(sym, 0, sizeof(hist));
+            if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_phase_slow)) == hipSuccess) (void)hipMemset(sym, 0, 16 * sizeof(unsigned long long));
         }
     }
     unsigned long long t_min = ~0ull, t_max = 0;

@@ -95,6 +95,40 @@ NFA_HD float nfa_lattice_until(float t, float d, float target, int64_t *steps, b
     const float h = d * 0.5f;
     int64_t k = 0;
     *stuck = false;
+    // Same-binade shortcut (most boundaries of a ray lie in the binade the walk is in): inside [2^e, 2^(e+1)) the chain is
+    // m -> m + c (integer ulps, c = RN(d / ulp)) and the test compares integers too, so the step count is ONE division.
+    // Nothing is assumed: the candidate is accepted only if the real fp32 test fails one step earlier and holds at the
+    // candidate, for chain values that are exact by construction (no tie, no binade crossing); anything else takes the
+    // general path below.
+    {
+        const uint32_t tb = nfa_f2u(t), db = nfa_f2u(d), gb = nfa_f2u(target);
+        const int e = (int)((tb >> 23) & 0xffu), ed = (int)((db >> 23) & 0xffu);
+        const int sh = e - ed;
+        if ((tb >> 31) == 0 && (db >> 31) == 0 && (gb >> 31) == 0 && e >= 1 && e < 254 && ed >= 1 && sh >= 1 && sh <= 23 &&
+            (int)((gb >> 23) & 0xffu) == e && t + h < target) {
+            const uint32_t D = (db & 0x7fffffu) | 0x800000u;
+            const uint32_t c0 = D >> sh, rem = D & ((1u << sh) - 1u), half = (1u << sh) >> 1;
+            const uint32_t c = c0 + (rem > half ? 1u : 0u);
+            const uint32_t m = (tb & 0x7fffffu) | 0x800000u, g = (gb & 0x7fffffu) | 0x800000u;
+            if (rem != half && c != 0u && g > m) {
+                // smallest n with m + n c + (h in ulps, about c / 2) >= g: estimate from the real-number inequality, then verify
+                const float need = (float)(g - m) - (float)c * 0.5f;
+                int64_t n = need > 0.0f ? (int64_t)(need / (float)c) : 0;
+                if (n < 1) n = 1;
+                const uint64_t m_prev = (uint64_t)m + (uint64_t)(n - 1) * c, m_n = m_prev + c;
+                if (m_n < (1u << 24)) {                              // both values inside the binade: exact chain values
+                    const float t_prev = nfa_u2f(((uint32_t)e << 23) | ((uint32_t)m_prev & 0x7fffffu));
+                    const float t_n = nfa_u2f(((uint32_t)e << 23) | ((uint32_t)m_n & 0x7fffffu));
+                    if (t_prev + h < target && !(t_n + h < target)) { *steps = n; return t_n; }
+                    const uint64_t m_n1 = m_n + c;                   // the estimate is one short about half of the time
+                    if (m_n1 < (1u << 24)) {
+                        const float t_n1 = nfa_u2f(((uint32_t)e << 23) | ((uint32_t)m_n1 & 0x7fffffu));
+                        if (t_n + h < target && !(t_n1 + h < target)) { *steps = n + 1; return t_n1; }
+                    }
+                }
+            }
+        }
+    }
     if (t + h < target) {
         // jump most of the way: an under-estimate of the step count, verified after the jump
         // (the walk is monotone, so "still short of the target" proves no overshoot)

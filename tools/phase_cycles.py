@@ -12,7 +12,8 @@ out_dir = os.path.join(ROOT, "tools", "_prof")
 os.makedirs(out_dir, exist_ok=True)
 so = os.path.join(out_dir, "libnerfacc_hip_prof.so")
 srcs = sorted(glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hip")))
-if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
+hdrs = glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hpp")) + [os.path.join(ROOT, "include", "nerfacc_hip.h")]
+if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs + hdrs):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                            "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", "-shared", *srcs, "-o", so])
 if "--build-only" in sys.argv:
