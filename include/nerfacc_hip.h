@@ -57,8 +57,9 @@ int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
 /* Packed occupancy.  The traversal kernels do not read the 1-byte-per-voxel `binaries` tensor
  * (occ_grid.py:72-75) directly: it is first packed into 4x4x4 bricks, one uint64 per brick
  * (bit = (x&3)*16 + (y&3)*4 + (z&3)), bricks x-major like the voxels, followed in the same
- * buffer by a bitmap of the non-empty bricks, its rank prefix and the compacted non-empty
- * bricks (the form the kernels stage into LDS).
+ * buffer by a 12-word header (word 0: number of non-empty bricks; words 1..8: occupied voxels of level 0..7 — what
+ * `nonzero(binaries[level])` would count, so that the grid update can size it without a host sync), a bitmap of the
+ * non-empty bricks, its rank prefix and the compacted non-empty bricks (the form the kernels stage into LDS).
  * nfa_packed_grid_words: size of that buffer in uint64 words for [n_grids, rx, ry, rz]. */
 int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t rz);
 int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,

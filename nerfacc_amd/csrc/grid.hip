@@ -183,7 +183,7 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
     L.n_bricks = (int64_t)n_grids * ((rx + 3) / 4) * ((ry + 3) / 4) * ((rz + 3) / 4);
     L.n_words = (L.n_bricks + 31) / 32;
     L.off_header = L.n_bricks;
-    L.off_coarse = L.off_header + 4;
+    L.off_coarse = L.off_header + 12;          // header: [0] non-empty bricks, [1 + g] occupied voxels of level g (g < 8), 3 spare
     L.off_prefix = L.off_coarse + (L.n_words + 1) / 2;
     L.off_compact = L.off_prefix + (L.n_words + 1) / 2;
     L.total_words = L.off_compact + L.n_bricks;
@@ -194,15 +194,16 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
 // wave's ballot of "non-empty" is the coarse bitmap (two u32 words per wave).
 __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
     const uint8_t *__restrict__ binaries, int n_grids, int rx, int ry, int rz,
-    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse)
+    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse, int64_t *__restrict__ level_counts)
 {
     const int64_t per_grid = (int64_t)nbx * nby * nbz;
     const int64_t total = per_grid * n_grids;
     const int64_t rounded = (total + 63) / 64 * 64;
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < rounded; b += (int64_t)gridDim.x * kBlock) {
         uint64_t bits = 0;
+        int64_t g = 0;
         if (b < total) {
-            const int64_t g = b / per_grid;
+            g = b / per_grid;
             int64_t rem = b - g * per_grid;
             const int bx = (int)(rem / ((int64_t)nby * nbz));
             rem -= (int64_t)bx * nby * nbz;
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
                 }
             }
             bricks[b] = bits;
+            // occupied voxels per level (integer atomics: deterministic): lets OccGridEstimator size `nonzero` without a sync
+            if (bits) atomicAdd((unsigned long long *)(level_counts + g), (unsigned long long)__popcll(bits));
         }
         const unsigned long long any = __ballot(bits != 0ull);
         const int lane = lane_id();
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(1024) void rank_bricks_kernel(const uint32_t *__res
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { header[0] = carry_s; header[1] = 0; header[2] = 0; header[3] = 0; }
+    if (threadIdx.x == 0) header[0] = carry_s;          // ([1..8]: per-level voxel counts, accumulated by pack_bricks_kernel)
 }
 
 __global__ __launch_bounds__(kBlock) void compact_bricks_kernel(const uint64_t *__restrict__ bricks, int64_t n_bricks,
@@ -1556,8 +1559,10 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
     hipStream_t s = (hipStream_t)stream;
     uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
     uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
+    int64_t *header = (int64_t *)(bricks + L.off_header);
+    if (hipMemsetAsync(header, 0, 12 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "pack_binaries: memset failed");
     hipLaunchKernelGGL(pack_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
-                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse);
+                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1);
     if (int rc = check_launch("pack_bricks_kernel")) return rc;
     hipLaunchKernelGGL(rank_bricks_kernel, dim3(1), dim3(1024), 0, s, coarse, L.n_words, prefix, (int64_t *)(bricks + L.off_header));
     if (int rc = check_launch("rank_bricks_kernel")) return rc;

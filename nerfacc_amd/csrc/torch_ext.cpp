@@ -149,6 +149,7 @@ struct BrickEntry {
     uint32_t version;
     Tensor bricks;
     int64_t nonempty;
+    int64_t level_counts[8];
     hipStream_t stream;
     hipEvent_t event;
 };
@@ -187,7 +188,7 @@ std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) 
             keep.push_back(std::move(c));
         }
         g_bricks = std::move(keep);
-        BrickEntry e{c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr()), impl, ver, bricks, -1, s, ev};
+        BrickEntry e{c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr()), impl, ver, bricks, -1, {0, 0, 0, 0, 0, 0, 0, 0}, s, ev};
         g_bricks.insert(g_bricks.begin(), std::move(e));
         while (g_bricks.size() > kBrickSlots) { hipEventDestroy(g_bricks.back().event); g_bricks.pop_back(); }
         hit = 0;
@@ -201,16 +202,30 @@ std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) 
     if (c.stream != s) hipStreamWaitEvent(s, c.event, 0);      // packed on another stream: order this one after the pack
     if (need_count && c.nonempty < 0) {
         const int64_t nb = binaries.size(0) * ((binaries.size(1) + 3) / 4) * ((binaries.size(2) + 3) / 4) * ((binaries.size(3) + 3) / 4);
-        int64_t *h = host_ints(binaries.device().index(), s);
-        TORCH_CHECK(hipMemcpyAsync(h, ptr<int64_t>(c.bricks) + nb, sizeof(int64_t), hipMemcpyDeviceToHost, s) == hipSuccess,
-                    "nerfacc_amd: readback of the brick count failed");
+        // header of the packed grid: [0] non-empty bricks, [1..8] occupied voxels per level
+        int64_t hdr[9];
+        TORCH_CHECK(hipMemcpyAsync(hdr, ptr<int64_t>(c.bricks) + nb, sizeof(hdr), hipMemcpyDeviceToHost, s) == hipSuccess,
+                    "nerfacc_amd: readback of the packed-grid header failed");
         wait_stream(s);
-        c.nonempty = h[0];
+        c.nonempty = hdr[0];
+        for (int g = 0; g < 8; ++g) c.level_counts[g] = hdr[1 + g];
     }
     return {c.bricks, c.nonempty};
 }
 
 Tensor packed_bricks(const Tensor &binaries) { return brick_entry(binaries, true).first; }
+
+// occupied voxels per level of `binaries` (what nonzero(binaries[level]) would count), from the packed grid's header: one
+// read-back per grid state, shared with the traversal's
+std::vector<int64_t> grid_occupied_counts(const Tensor &binaries) {
+    brick_entry(binaries, true);
+    std::lock_guard<std::mutex> l(g_brick_mu);
+    c10::TensorImpl *impl = binaries.unsafeGetTensorImpl();
+    for (auto &c : g_bricks)
+        if (c.impl == impl && c.version == binaries._version() && !c.ref.expired())
+            return std::vector<int64_t>(c.level_counts, c.level_counts + std::min<int64_t>(binaries.size(0), 8));
+    TORCH_CHECK(false, "nerfacc_amd: packed grid vanished from the cache");
+}
 
 // ---------------------------------------------------------------------------------------------------
 // RaySegmentsSpec (data_spec.hpp:6-14; nerfacc.cpp:128-137): seven optional tensors
@@ -857,6 +872,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("grid_threshold", &grid_threshold);
     m.def("grid_mark_invisible", &grid_mark_invisible);
     m.def("packed_bricks", &packed_bricks);
+    m.def("grid_occupied_counts", &grid_occupied_counts);
     m.def("set_timing", &set_timing, "names"_a = py::none());
     m.def("timing_summary", &timing_summary);
 }

@@ -39,7 +39,7 @@ _FUSED_NAMES = (
     "render_weight_from_density_fwd", "render_weight_from_density_bwd",
     "visibility_compact", "accumulate_along_rays", "accumulate_along_rays_bwd",
     "rendering_fwd", "rendering_bwd",
-    "grid_cell_points", "grid_ema_update", "grid_threshold", "grid_mark_invisible", "sample_positions",
+    "grid_cell_points", "grid_ema_update", "grid_threshold", "grid_mark_invisible", "grid_occupied_counts", "sample_positions",
 )
 
 for _n in _REFERENCE_NAMES + _FUSED_NAMES:

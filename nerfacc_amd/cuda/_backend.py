@@ -361,8 +361,9 @@ def _nonempty_bricks(binaries: torch.Tensor) -> int:
 def _nonempty_locked(c: dict, binaries: torch.Tensor) -> int:
     if c["nonempty"] < 0:
         G = binaries.shape[0]
-        n_bricks = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
-        c["nonempty"] = int(c["bricks"][n_bricks].item())
+        n_bricks_ = G * ((binaries.shape[1] + 3) // 4) * ((binaries.shape[2] + 3) // 4) * ((binaries.shape[3] + 3) // 4)
+        hdr = c["bricks"][n_bricks_:n_bricks_ + 9].tolist()          # [0] non-empty bricks, [1..8] occupied voxels per level
+        c["nonempty"], c["level_counts"] = int(hdr[0]), [int(x) for x in hdr[1:1 + min(G, 8)]]
     return c["nonempty"]
 
 
@@ -885,6 +886,12 @@ class _CtypesC:
             _check(load_library().nfa_grid_mark_invisible(_ptr(occs_level), _ptr(cell_ids), n, rx, ry, rz, _ptr(aabb), _ptr(w2c_R),
                                                           _ptr(w2c_T), _ptr(K), C, int(K.numel() == 9 and C != 1), float(width),
                                                           float(height), float(near_plane), _stream(occs_level)))
+
+    @staticmethod
+    def grid_occupied_counts(binaries):
+        """occupied voxels per level (what nonzero(binaries[level]) would count), from the packed grid's header"""
+        _nonempty_bricks(binaries)
+        return list(_brick_entry(binaries)["level_counts"])
 
     @staticmethod
     def grid_threshold(occs, occ_thre: float):

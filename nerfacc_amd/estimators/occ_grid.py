@@ -203,7 +203,13 @@ class OccGridEstimator(AbstractEstimator):
         for lvl in range(self.levels):
             uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
             uniform = uniform[self.occs[lvl * self.cells_per_lvl + uniform] >= 0.0]
-            occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if self.binaries.is_cuda and self.levels <= 8:
+                # the number of occupied cells is in the header of the packed grid (read back once per grid state, together
+                # with what the traversal needs): `nonzero` can size its output without its own host sync
+                cnt = _C.grid_occupied_counts(self.binaries)[lvl]
+                occupied = torch.nonzero_static(self.binaries[lvl].flatten(), size=cnt)[:, 0]
+            else:
+                occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
             if n < len(occupied):
                 pick = torch.randint(len(occupied), (n,), device=self.device)
                 occupied = occupied[pick]

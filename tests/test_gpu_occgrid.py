@@ -174,3 +174,30 @@ def test_mark_invisible_cells_device_kernel_vs_reference_composition(golden):
     # cells marked invisible are excluded from the next update
     dev._update(step=0, occ_eval_fn=lambda x: torch.full((x.shape[0], 1), 0.5, device=DEV))
     assert (dev.occs[b.to(DEV) == -1] == -1).all() and (dev.occs[b.to(DEV) == 0] > 0).all()
+
+
+def test_update_cell_selection_without_nonzero_sync_matches_reference_composition():
+    """after warm-up `_update` draws n uniform cells + (at most n of) the occupied ones (occ_grid.py:345-364); the device path
+    sizes `nonzero` from the packed grid's header instead of syncing — same cells, same RNG stream as the torch composition"""
+    from nerfacc_amd import OccGridEstimator
+    from nerfacc_amd.cuda import grid_occupied_counts
+
+    torch.manual_seed(0)
+    est = OccGridEstimator(roi_aabb=[-1.0, -1, -1, 1, 1, 1], resolution=32, levels=3).to(DEV)
+    est.binaries = (torch.rand(3, 32, 32, 32, device=DEV) < torch.tensor([0.02, 0.3, 0.0], device=DEV)[:, None, None, None])
+    cnts = grid_occupied_counts(est.binaries)
+    assert cnts == [int(est.binaries[l].sum().item()) for l in range(3)] and cnts[2] == 0
+    n = est.cells_per_lvl // 4
+    torch.manual_seed(11)
+    got = est._sample_uniform_and_occupied_cells(n)
+    torch.manual_seed(11)
+    want = []
+    for lvl in range(3):                                  # occ_grid.py:345-364 as written there
+        uniform = torch.randint(est.cells_per_lvl, (n,), device=DEV)
+        uniform = uniform[est.occs[lvl * est.cells_per_lvl + uniform] >= 0.0]
+        occupied = torch.nonzero(est.binaries[lvl].flatten())[:, 0]
+        if n < len(occupied):
+            occupied = occupied[torch.randint(len(occupied), (n,), device=DEV)]
+        want.append(torch.cat([uniform, occupied], dim=0))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
