@@ -423,6 +423,9 @@ def main():
     ap.add_argument("--occ-res", type=int, default=GRID_RES,
                     help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
     ap.add_argument("--grad-chunks", type=int, default=4, help="chunks of the gradient all-reduce (N > 1)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="dry run of the N > 1 code path on a single GPU (with --dist-backend gloo): every rank uses cuda:0")
     ap.add_argument("--dump-sampling-state", default="",
                     help="write the occupancy grid and one ray batch of the timed steady state to this .npz "
                          "(tools/traverse_replay.py replays the sampling call on it under rocprofv3)")
@@ -432,10 +435,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     assert world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_size}"
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
     fixed_rays = args.rays_per_iter // world_size if args.rays_per_iter > 0 else 0
 
     torch.manual_seed(42)
