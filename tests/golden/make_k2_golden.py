@@ -110,6 +110,33 @@ def main():
             fixture[f"{name}/cnts/iv_chunk_cnts"] = out["iv_chunk_cnts"].astype(np.int32)
         print(f"{name:20s} rays {R:6d} samples {n_samples:8d}  off!=fma {d_builds:4d}  oracle!=off {d_orc_off:4d}  oracle!=fma {d_orc_fma:4d}  ({'full' if full else 'digests'})")
 
+    # ---- K1 through the reference's own kernel as well (tests/test_grid.py:7-35 generator: seed 42, 1000 rays x 100 boxes) ----
+    torch.manual_seed(42)
+    k1_o = torch.rand((1000, 3))
+    k1_d = torch.randn((1000, 3))
+    k1_d = k1_d / k1_d.norm(dim=-1, keepdim=True)
+    k1_min = torch.rand((100, 3))
+    k1_boxes = torch.cat([k1_min, k1_min + torch.rand_like(k1_min)], dim=-1)
+    k1 = {}
+    for b in builds:
+        backend._C = builds[b]
+        k1[b] = [x.numpy() for x in G.ray_aabb_intersect(k1_o, k1_d, k1_boxes)]            # python defaults: near -inf, far inf, miss inf
+        k1[b + "_nf"] = [x.numpy() for x in G.ray_aabb_intersect(k1_o, k1_d, k1_boxes, 0.1, 0.7, -1.0)]
+    o_tmin, o_tmax, o_hits = oracle.ray_aabb_intersect(k1_o.numpy(), k1_d.numpy(), k1_boxes.numpy())
+    report["k1_ray_aabb"] = dict(pairs=100000, hits=int(k1["fma"][2].sum()),
+                                 values_differing_off_vs_fma=int((k1["off"][0] != k1["fma"][0]).sum() + (k1["off"][1] != k1["fma"][1]).sum()),
+                                 values_differing_oracle_vs_fma=int((o_tmin != k1["fma"][0]).sum() + (o_tmax != k1["fma"][1]).sum()),
+                                 values_differing_oracle_vs_off=int((o_tmin != k1["off"][0]).sum() + (o_tmax != k1["off"][1]).sum()),
+                                 hits_differing_oracle=int((o_hits != k1["off"][2]).sum()))
+    keep_k1 = "off" if report["k1_ray_aabb"]["values_differing_oracle_vs_off"] == 0 else "fma"
+    report["k1_ray_aabb"]["fixture_build"] = keep_k1
+    fixture["k1/rays_o"], fixture["k1/rays_d"], fixture["k1/aabbs"] = k1_o.numpy(), k1_d.numpy(), k1_boxes.numpy()
+    for tag, key in (("", keep_k1), ("_nf", keep_k1 + "_nf")):
+        fixture[f"k1/sha/t_mins{tag}"] = np.array(K.sha(k1[key][0]))
+        fixture[f"k1/sha/t_maxs{tag}"] = np.array(K.sha(k1[key][1]))
+        fixture[f"k1/hits_bits{tag}"] = np.packbits(k1[key][2].ravel())
+    print("k1_ray_aabb", report["k1_ray_aabb"])
+
     np.savez_compressed(os.path.join(HERE, "k2_reference.npz"), **fixture)
     with open(os.path.join(HERE, "k2_sensitivity.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -51,10 +51,38 @@ def test_oracle_reproduces_reference_k2(name, k2):
 def test_sensitivity_report_matches_fixture(k2):
     """the FMA-model numbers quoted in DESIGN.md §3.4 come from this file"""
     rep = json.load(open(os.path.join(GOLD, "k2_sensitivity.json")))
-    assert sorted(rep) == sorted(K.ALL)
+    assert sorted(rep) == sorted(K.ALL + ["k1_ray_aabb"])
     for name, r in rep.items():
+        if name == "k1_ray_aabb":
+            assert r["values_differing_oracle_vs_fma"] == 0 and r["values_differing_oracle_vs_off"] == 0 and r["hits_differing_oracle"] == 0
+            continue
         assert r["fixture_build"] == "fma"
         assert r["rays_differing_oracle_vs_fma"] == 0, name
+
+
+def _check_k1(k2, t_mins, t_maxs, hits, tag=""):
+    assert K.sha(np.ascontiguousarray(t_mins, np.float32)) == str(k2[f"k1/sha/t_mins{tag}"])
+    assert K.sha(np.ascontiguousarray(t_maxs, np.float32)) == str(k2[f"k1/sha/t_maxs{tag}"])
+    assert np.array_equal(np.packbits(np.asarray(hits, bool).ravel()), k2[f"k1/hits_bits{tag}"])
+
+
+def test_oracle_reproduces_reference_k1(k2):
+    """ray_aabb_intersect through the reference's own kernel (grid.cu:284-313, tests/test_grid.py:7-35 generator)"""
+    import oracle
+
+    o, d, boxes = k2["k1/rays_o"], k2["k1/rays_d"], k2["k1/aabbs"]
+    _check_k1(k2, *oracle.ray_aabb_intersect(o, d, boxes))
+    _check_k1(k2, *oracle.ray_aabb_intersect(o, d, boxes, 0.1, 0.7, -1.0), tag="_nf")
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_k1(k2):
+    from gpu_utils import n, t
+    from nerfacc_amd.grid import ray_aabb_intersect
+
+    o, d, boxes = t(k2["k1/rays_o"]), t(k2["k1/rays_d"]), t(k2["k1/aabbs"])
+    _check_k1(k2, *[n(x) for x in ray_aabb_intersect(o, d, boxes)])
+    _check_k1(k2, *[n(x) for x in ray_aabb_intersect(o, d, boxes, 0.1, 0.7, -1.0)], tag="_nf")
 
 
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/nerfacc") and os.path.isdir(os.path.join(ROOT, "oracle", "_ref"))
