@@ -197,3 +197,32 @@ def test_exchange_adam_fused_path_matches_torch_adam_on_device():
             ((ps[0] * 0.7 - 0.1).square().sum() * (it + 1) * 1024.0).backward()
             o.step()
     assert torch.allclose(a[0], b[0], atol=1e-6, rtol=1e-5)
+
+
+def test_in_kernel_near_far_planes_equal_the_torch_composition():
+    """OccGridEstimator.sampling hands near_plane / far_plane / t_min / t_max / the stratified jitter to the kernel; the planes it
+    forms must be the floats occ_grid.py:154-163 forms with torch ops (full_like, clamp, rand * step added in place)"""
+    from nerfacc_amd import cuda as C
+
+    o, d, aabb, occ = lego_like(21, 5000, res=64)
+    O, D, B, A = t(o), t(d), t(occ), t(aabb)
+    R = O.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    t_min = torch.rand(R, device=DEV, generator=g) * 4.0
+    t_max = t_min + torch.rand(R, device=DEV, generator=g) * 3.0
+    jit = torch.rand(R, device=DEV, generator=g)
+    step, near_plane, far_plane = 7e-3, 0.35, 5.5
+    near = torch.clamp(torch.full_like(O[..., 0], near_plane), min=t_min)
+    far = torch.clamp(torch.full_like(O[..., 0], far_plane), max=t_max)
+    near += jit * step
+    want = C.sample_occgrid(O, D, B, A, near.contiguous(), far.contiguous(), step, 0.0)
+    got = C.sample_occgrid(O, D, B, A, None, None, step, 0.0, near_plane=near_plane, far_plane=far_plane,
+                           t_min=t_min, t_max=t_max, jitter=jit, jitter_scale=step)
+    assert want[0].numel() > 1000
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # scalars only (the training call: near 0, far 1e10, stratified)
+    want = C.sample_occgrid(O, D, B, A, (jit * step).contiguous(), torch.full((R,), 1e10, device=DEV), step, 0.0)
+    got = C.sample_occgrid(O, D, B, A, None, None, step, 0.0, near_plane=0.0, far_plane=1e10, jitter=jit, jitter_scale=step)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
