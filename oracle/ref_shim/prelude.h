@@ -64,6 +64,36 @@ template <class K, class S0, class S1> static inline RefLauncher<K> ref_launch(K
 }
 #define REF_LAUNCH(kernel, ...) ref_launch(kernel, __VA_ARGS__)
 
+// --- argument checks: the reference's CHECK_INPUT (include/utils_cuda.cuh:12-17) insists on CUDA tensors.  The header is
+// pulled in HERE (its `#pragma once` then keeps later includes out) so that CHECK_CUDA can be re-defined for host
+// tensors; contiguity is still checked by the reference's own macro.
+#include "include/utils_cuda.cuh"
+#undef CHECK_CUDA
+#define CHECK_CUDA(x)
+
+// --- random numbers of pdf.cu (only reached with stratified = true, which the fixtures never use): enough of
+// at::PhiloxCudaState / CUDAGeneratorImpl / cuRAND for the file to compile; the generator look-up
+// `at::get_generator_or_default<at::CUDAGeneratorImpl>(` is rewritten to `ref_generator(` by the recipe's sed
+#include <mutex>
+#include <tuple>
+namespace at {
+struct PhiloxCudaState { uint64_t seed = 0, offset = 0; };
+struct RefGenerator {
+    std::mutex mutex_;
+    PhiloxCudaState philox_cuda_state(uint64_t) { return PhiloxCudaState{}; }
+};
+namespace cuda { namespace detail { static inline int getDefaultCUDAGenerator() { return 0; } }
+namespace philox { static inline std::tuple<uint64_t, uint64_t> unpack(PhiloxCudaState s) { return {s.seed, s.offset}; } } }
+}  // namespace at
+template <class A, class B> static inline at::RefGenerator *ref_generator(A, B) { static at::RefGenerator g; return &g; }
+struct curandStatePhilox4_32_10_t {};
+static inline void curand_init(uint64_t, uint64_t, uint64_t, curandStatePhilox4_32_10_t *) {}
+static inline float curand_uniform(curandStatePhilox4_32_10_t *) { return 0.5f; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }   // CUDA's integer overloads used by pdf.cu
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
+static inline long max(long a, long b) { return a > b ? a : b; }
+
 // --- the two pieces of at::cuda the host wrappers touch ---------------------------------------------
 namespace at { namespace cuda {
 struct CUDAStream {};

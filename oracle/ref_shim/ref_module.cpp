@@ -19,6 +19,11 @@ std::vector<torch::Tensor> ray_aabb_intersect(const torch::Tensor rays_o, const 
                                               const torch::Tensor aabbs, const float near_plane,
                                               const float far_plane, const float miss_value);
 
+// pdf.cu:294-425 (Tensor-count and int-count overloads) and :428-456
+std::vector<RaySegmentsSpec> importance_sampling(RaySegmentsSpec ray_segments, torch::Tensor cdfs, torch::Tensor n_intervels_per_ray, bool stratified);
+std::vector<RaySegmentsSpec> importance_sampling(RaySegmentsSpec ray_segments, torch::Tensor cdfs, int64_t n_intervels_per_ray, bool stratified);
+std::vector<torch::Tensor> searchsorted(RaySegmentsSpec query, RaySegmentsSpec key);
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     // same attribute names as the reference's own binding (nerfacc.cpp:126-137), so that the reference's
     // PYTHON layer (nerfacc/grid.py, data_specs.py, estimators/occ_grid.py) runs unmodified on top of it.
@@ -34,4 +39,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("traverse_grids", &traverse_grids);
     m.def("ray_aabb_intersect", &ray_aabb_intersect);
     m.def("is_cub_available", []() { return false; });
+    // the two overloads as the reference binds them (nerfacc.cpp:152-159)
+    m.def("importance_sampling", py::overload_cast<RaySegmentsSpec, torch::Tensor, torch::Tensor, bool>(&importance_sampling));
+    m.def("importance_sampling", py::overload_cast<RaySegmentsSpec, torch::Tensor, int64_t, bool>(&importance_sampling));
+    m.def("searchsorted", &searchsorted);
 }
