@@ -265,6 +265,35 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
     finally:
         oracle.set_threads(1)
 
+    # ---- the reference's OWN traversal (grid.cu compiled for the host, oracle/_ref; single thread, its serial kernel loop) on the
+    # same n1 rays, when that build travelled with the tree: what "the reference on this CPU" means for the part of the path
+    # that exists only as CUDA upstream
+    ref_leg = None
+    try:
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        if os.path.isdir(ref_dir) and any(f.startswith("nerfacc_ref_fma") for f in os.listdir(ref_dir)):
+            sys.path.insert(0, ref_dir)
+            import importlib
+
+            ref = importlib.import_module("nerfacc_ref_fma")
+            tt_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            ro, rd, rb, ra = tt_(o1), tt_(d1), tt_(binaries), tt_(aabbs)
+            torch.set_num_threads(1)
+            xs = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                tmin, tmax, hits = ref.ray_aabb_intersect(ro, rd, ra, -float("inf"), float("inf"), float("inf"))
+                ts_, ti_ = torch.sort(torch.cat([tmin, tmax], -1), -1)
+                iv_, sm_, _ = ref.traverse_grids(ro, rd, torch.ones(n1, dtype=torch.bool), rb, ra, ts_, ti_, hits, torch.zeros(n1),
+                                                 torch.full((n1,), 1e10), RENDER_STEP, 0.0, True, True, True, -1, False)
+                xs.append(time.perf_counter() - t0)
+            torch.set_num_threads(cores)
+            ref_leg = {"rays_per_sec": n1 / float(np.median(xs)), "candidate_samples_per_sec": int(sm_.vals.shape[0]) / float(np.median(xs)),
+                       "sample": f"{n1} rays: the reference's ray_aabb_intersect + traverse_grids (count pass, cumsum, fill pass) exactly as grid.cu "
+                                 "runs them, one host thread; traversal only"}
+    except Exception as e:      # noqa: BLE001  (an optional leg)
+        ref_leg = {"error": repr(e)[:160]}
+
     # ---- configs[0]: pure-PyTorch render_weight_from_density on CPU, C1 shapes
     rng = np.random.default_rng(42)
     R = 4096
@@ -339,6 +368,7 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
                     f"{p_sig.numel()} padded elements for {N} samples); flat = cumsum minus per-ray offset on the packed layout",
         },
         "host_cores_available": cores,
+        "reference_host_build": ref_leg,
     }
 
 
