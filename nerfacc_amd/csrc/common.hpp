@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
 
 #include "../../include/nerfacc_hip.h"
 
@@ -194,62 +195,363 @@ __device__ __forceinline__ int dist_to_tail(unsigned long long tails, int lane, 
 
 
 // ----------------------------------------------------------------------------------------
-// Snapped tiling of a key-grouped array (DESIGN.md "segment-snapped wave tiles").
+// Ray-owning wave tiles of a key-grouped array (DESIGN.md "aligned wave tiles").
 //
-// The flat sample array is cut into nominal tiles of `tile` elements, one wave each.  Each
-// wave then moves both of its boundaries forward to the next segment head (first element of
-// a ray), so every ray lies wholly inside one wave's range: no carry ever crosses waves, no
-// inter-workgroup communication, no atomics, bit-reproducible.  A wave whose nominal tile
-// holds no head owns nothing (the ray that covers it belongs to an earlier wave).
+// The flat sample array is cut into nominal tiles of `tile` elements, one wave each.  A wave OWNS the rays
+// whose first element (forward walks) / last element (backward walks) lies in its nominal tile, so every ray is
+// wholly inside one wave's range: no carry ever crosses waves, no inter-workgroup communication, no atomics,
+// bit-reproducible.  A wave whose nominal tile holds no such element owns nothing (the ray that covers it belongs
+// to another wave).
+//
+// The wave walks chunks of 64 x E elements aligned to the NOMINAL grid (base = multiple of 64 E), lane l holding
+// the E consecutive elements base + l E ...: every load and store is an aligned 4 E-byte (keys: 8 E-byte) vector
+// per lane and a whole number of 128-byte lines per wave.  (Chunks aligned to the start of the owned range made
+// every access straddle lines and needed one memory instruction per element and array: weight_fwd 4.7 vs 5.5 TB/s
+// on 63- vs 64-sample rays, profiles/r02_streaming.md; and the range had to be searched for first — two dependent
+// memory round trips per wave before the first useful load.)  Ownership is decided from the chunk's own keys:
+// elements of the first / last chunk that belong to a neighbouring wave's ray are masked off.  PF further chunks
+// are requested before the current one is used (payloads are raw loaded values: anything computed in `load` would
+// wait for the data there); with `spec` — launches too small to fill the chip — the chunk past the nominal tile
+// is requested ahead as well.
+//
+// Per-ray results of forward walks: the last element of a ray is known from the heads of its own chunk, except
+// for the chunk's very last element, whose successor lives in the next chunk.  The walker reports `tail` for
+// everything it knows and calls `flush(key)` at the start of the next chunk when that element turns out to have
+// ended its ray (the kernel's carries then hold the ray's totals).
 // ----------------------------------------------------------------------------------------
+struct NoPayload {};
 
-// first position p in [from, limit) with keys[p] != keys[p-1] (position 0 counts as a head);
-// returns `limit` if there is none.  Wave-uniform result; all 64 lanes must call.
-__device__ __forceinline__ int64_t find_head(const int64_t *__restrict__ keys, int64_t from, int64_t limit) {
-    if (from <= 0) return 0 < limit ? 0 : limit;
-    const int lane = lane_id();
-    for (int64_t base = from; base < limit; base += 64) {
-        const int64_t i = base + lane;
-        bool h = false;
-        if (i < limit) h = keys[i] != keys[i - 1];
-        const unsigned long long b = __ballot(h);
-        if (b) return base + (__ffsll((long long)b) - 1);
-    }
-    return limit;
-}
-
-struct TileRange {
-    int64_t begin, end;
+template <int E, class P>
+struct RayChunk {
+    int64_t key[E];
+    P p;
 };
 
-// range owned by wave `w` for nominal tile size `tile` over n elements
-__device__ __forceinline__ TileRange snapped_tile(const int64_t *__restrict__ keys, int64_t n, int64_t w, int64_t tile) {
-    TileRange r;
-    const int64_t nb = w * tile;
-    int64_t ne = nb + tile;
-    if (ne > n) ne = n;
-    if (nb >= n) { r.begin = r.end = n; return r; }
-    r.begin = find_head(keys, nb, ne);
-    if (r.begin >= ne) { r.begin = r.end = n; return r; }   // no head in the nominal tile
-    r.end = (ne >= n) ? n : find_head(keys, ne, n);
-    return r;
+// aligned E-wide loads / stores (i0 is a multiple of E by construction; elements at or beyond n are filled / skipped)
+template <int E, class T>
+__device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int64_t n, T fill, T (&out)[E]) {
+    typedef T vec_t __attribute__((ext_vector_type(E)));
+    if (i0 + E <= n) {
+        const vec_t v = *reinterpret_cast<const vec_t *>(p + i0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = (i0 + e < n) ? p[i0 + e] : fill;
+    }
+}
+// S interleaved channels per element (rgb: S = 3): out[e][c]
+template <int E, int S>
+__device__ __forceinline__ void ld_vec_strided(const float *__restrict__ p, int64_t i0, int64_t n, float fill, float (&out)[E][S]) {
+    if (E > 1 && i0 + E <= n) {
+        typedef float vec_t __attribute__((ext_vector_type(E)));
+        float flat[E * S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const vec_t v = *reinterpret_cast<const vec_t *>(p + i0 * S + j * E);
+#pragma unroll
+            for (int e = 0; e < E; ++e) flat[j * E + e] = v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int c = 0; c < S; ++c) out[e][c] = flat[e * S + c];
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int c = 0; c < S; ++c) out[e][c] = (i0 + e < n) ? p[(i0 + e) * S + c] : fill;
+    }
+}
+template <int E, class T>
+__device__ __forceinline__ void st_vec(T *__restrict__ p, int64_t i0, const bool (&act)[E], const T (&v)[E]) {
+    typedef T vec_t __attribute__((ext_vector_type(E)));
+    bool all = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) all = all && act[e];
+    if (E > 1 && all) {
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = v[e];
+        *reinterpret_cast<vec_t *>(p + i0) = o;
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (act[e]) p[i0 + e] = v[e];
+    }
 }
 
-// nominal tile size: multiples of 64, small enough to give every SIMD of the chip a few waves
-// on mid-size inputs.  Capped at 576 (nine chunks, not a power of two): with big tiles every
-// resident wave streams its own region `tile` elements apart, and at 2048 x 4 B = 8 KiB spacing
-// the concurrent 256-byte requests alias onto a subset of the HBM channels (measured at
-// N = 2^24: weight_bwd 3.77 -> 4.80 TB/s, keyed scan 4.03 -> 4.77 TB/s, profiles/r01_tile_sweep.md).
-inline int64_t pick_tile(int64_t n) {
-    if (const char *e = getenv("NFA_TILE")) {           // tuning knob (multiple of 64)
-        const int64_t v = atoll(e);
-        if (v >= 64 && v % 64 == 0) return v;
+// Segment flags of one chunk, lane view.  Forward: head[e] (elements outside the owned range count as heads);
+// the lane-level scan runs over lanes that contain a head.
+template <int E>
+struct SegFwd {
+    bool head[E], open;
+    int dist;
+};
+template <int E>
+struct SegBwd {
+    bool tail[E], open;
+    int dist;
+};
+
+// Segmented scans of a chunk: E elements per lane serially, the lane totals through the 64-lane DPP scan, one
+// carry register across chunks.
+template <class Op, int E>
+__device__ __forceinline__ void seg_scan_fwd(const float (&v)[E], const SegFwd<E> &s, float &carry, float (&incl)[E], float (&excl)[E]) {
+    const int lane = lane_id();
+    float x[E];
+    x[0] = v[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) x[e] = s.head[e] ? v[e] : Op::apply(x[e - 1], v[e]);
+    float tot = wave_seg_scan_fwd<Op>(x[E - 1], s.dist);
+    if (s.open) tot = Op::apply(carry, tot);
+    float pre = lane_prev_f(tot, Op::identity());
+    if (lane == 0) pre = carry;
+    carry = readlane_f<63>(tot);
+    bool cont = true;                                   // no head so far in this lane: the segment came in from the left
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        cont = cont && !s.head[e];
+        incl[e] = cont ? Op::apply(pre, x[e]) : x[e];
+        excl[e] = s.head[e] ? Op::identity() : (e == 0 ? pre : incl[e > 0 ? e - 1 : 0]);
     }
-    const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
-    int64_t t = ceil_div(ceil_div(n, target_waves), 64) * 64;
-    if (t < 256) t = 256;
-    if (t > 576) t = 576;
-    return t;
 }
+template <class Op, int E>
+__device__ __forceinline__ void seg_scan_bwd(const float (&v)[E], const SegBwd<E> &s, float &carry, float (&incl)[E], float (&excl)[E]) {
+    const int lane = lane_id();
+    float x[E];
+    x[E - 1] = v[E - 1];
+#pragma unroll
+    for (int e = E - 2; e >= 0; --e) x[e] = s.tail[e] ? v[e] : Op::apply(v[e], x[e + 1]);
+    float tot = wave_seg_scan_bwd<Op>(x[0], s.dist);
+    if (s.open) tot = Op::apply(tot, carry);
+    float post = lane_next_f(tot, Op::identity());
+    if (lane == 63) post = carry;
+    carry = readlane_f<0>(tot);
+    bool cont = true;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        cont = cont && !s.tail[e];
+        incl[e] = cont ? Op::apply(x[e], post) : x[e];
+        excl[e] = s.tail[e] ? Op::identity() : (e == E - 1 ? post : incl[e < E - 1 ? e + 1 : E - 1]);
+    }
+}
+
+template <int E, class P, class Load>
+__device__ __forceinline__ RayChunk<E, P> fetch_chunk(const int64_t *__restrict__ keys, int64_t n, int64_t base, int lane, Load &load) {
+    RayChunk<E, P> c;
+    const int64_t i0 = base + (int64_t)lane * E;
+    ld_vec<E, int64_t>(keys, i0, n, (int64_t)0, c.key);
+    c.p = load(i0);
+    return c;
+}
+
+// position (lane * E + e) of the first / last set flag of a chunk; f[e] per lane.  Wave-uniform; -1 if none.
+template <int E>
+__device__ __forceinline__ int first_flag(const bool (&f)[E]) {
+    int fe = E;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) if (f[e]) fe = e;
+    const unsigned long long b = __ballot(fe < E);
+    if (!b) return -1;
+    const int l = __ffsll((long long)b) - 1;
+    return l * E + __builtin_amdgcn_readlane(fe, l);
+}
+template <int E>
+__device__ __forceinline__ int last_flag(const bool (&f)[E]) {
+    int fe = -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (f[e]) fe = e;
+    const unsigned long long b = __ballot(fe >= 0);
+    if (!b) return -1;
+    const int l = 63 - __clzll((long long)b);
+    return l * E + __builtin_amdgcn_readlane(fe, l);
+}
+
+// body(i0, act[E], key[E], SegFwd<E>, tail[E], payload) for every chunk of the rays whose head lies in nominal tile w,
+// ascending; flush(key) when the element that closed the previous chunk ended ray `key`.
+template <int E, int PF, class P, class Load, class Body, class Flush>
+__device__ __forceinline__ void walk_rays_fwd(const int64_t *__restrict__ keys, int64_t n, int64_t w, int64_t tile, int spec,
+                                              Load load, Body body, Flush flush)
+{
+    constexpr int64_t CH = 64 * E;
+    const int lane = lane_id();
+    const int64_t nb = w * tile;
+    if (nb >= n) return;
+    const int64_t ne = nb + tile < n ? nb + tile : n;
+    int64_t lim = ne + (spec ? CH : 0);                     // chunks below `lim` are requested ahead
+    if (lim > n) lim = n;
+    RayChunk<E, P> q[PF + 1];
+    q[0] = fetch_chunk<E, P>(keys, n, nb, lane, load);
+#pragma unroll
+    for (int d = 1; d < PF; ++d)
+        if (nb + CH * d < lim) q[d] = fetch_chunk<E, P>(keys, n, nb + CH * d, lane, load);
+    int64_t edge = nb > 0 ? keys[nb - 1] : 0;               // the key before the current chunk
+    bool started = false, pending = false;                  // pending: the previous chunk's last element was walked, its tail unknown
+    for (int64_t base = nb;; base += CH) {
+        if (PF > 0 && base + CH * PF < lim) q[PF] = fetch_chunk<E, P>(keys, n, base + CH * PF, lane, load);
+        const int64_t i0 = base + (int64_t)lane * E;
+        int64_t pk = lane_prev_i64(q[0].key[E - 1]);
+        if (lane == 0) pk = edge;
+        bool hf[E];
+        hf[0] = i0 < n && (i0 == 0 || q[0].key[0] != pk);
+#pragma unroll
+        for (int e = 1; e < E; ++e) hf[e] = i0 + e < n && q[0].key[e] != q[0].key[e - 1];
+        int lo = 0, hi = CH;
+        bool done = base + CH >= n, skip = false;
+        if (base < ne) {
+            if (!started) {
+                const int f = first_flag<E>(hf);
+                if (f >= 0) { lo = f; started = true; }
+                else if (base + CH >= ne) return;                   // no head in the nominal tile: nothing owned
+                else skip = true;
+            }
+        } else {                                                    // past the tile: the straddling ray ends at the next head
+            const int f = first_flag<E>(hf);
+            if (f >= 0) { hi = f; done = true; }
+        }
+        if (!skip) {
+            if (pending && (__ballot(hf[0]) & 1ull)) flush(edge);
+            bool act[E], tail[E];
+            SegFwd<E> s;
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pos = lane * E + e;
+                act[e] = i0 + e < n && pos >= lo && pos < hi;
+                s.head[e] = !act[e] || hf[e];
+                any = any || s.head[e];
+            }
+            s.dist = dist_to_head(__ballot(any), lane, s.open);
+            // tail[e]: the next element is a head, lies past the array or past the range
+            int nh0 = s.head[0] ? 1 : 0;
+            nh0 = __builtin_amdgcn_update_dpp(1, nh0, kDppWaveShl1, 0xf, 0xf, false);   // lane 63: unknown here, see `pending`
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool next_head = e + 1 < E ? s.head[e + 1 < E ? e + 1 : 0] : (lane == 63 ? base + CH >= n : nh0 != 0);
+                tail[e] = act[e] && next_head;
+            }
+            body(i0, act, q[0].key, s, tail, q[0].p);
+            pending = true;                                         // (if the walk goes on, the chunk's last element was active)
+        }
+        edge = readlane_i64<63>(q[0].key[E - 1]);
+        if (done) break;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) q[d] = q[d + 1];
+        if (PF == 0 || base + CH >= lim) q[0] = fetch_chunk<E, P>(keys, n, base + CH, lane, load);
+    }
+}
+
+// body(i0, act[E], key[E], SegBwd<E>, payload) for every chunk of the rays whose tail lies in nominal tile w, descending
+template <int E, int PF, class P, class Load, class Body>
+__device__ __forceinline__ void walk_rays_bwd(const int64_t *__restrict__ keys, int64_t n, int64_t w, int64_t tile, int spec,
+                                              Load load, Body body)
+{
+    constexpr int64_t CH = 64 * E;
+    const int lane = lane_id();
+    const int64_t nb = w * tile;
+    if (nb >= n) return;
+    const int64_t ne = nb + tile < n ? nb + tile : n;
+    int64_t lim = nb - (spec ? CH : 0);                     // chunks at or above `lim` are requested ahead
+    if (lim < 0) lim = 0;
+    const int64_t top = ((ne - 1) / CH) * CH;
+    RayChunk<E, P> q[PF + 1];
+    q[0] = fetch_chunk<E, P>(keys, n, top, lane, load);
+#pragma unroll
+    for (int d = 1; d < PF; ++d)
+        if (top - CH * d >= lim) q[d] = fetch_chunk<E, P>(keys, n, top - CH * d, lane, load);
+    int64_t edge = top + CH < n ? keys[top + CH] : 0;       // the key after the current chunk
+    bool started = false;
+    for (int64_t base = top;; base -= CH) {
+        if (PF > 0 && base - CH * PF >= lim) q[PF] = fetch_chunk<E, P>(keys, n, base - CH * PF, lane, load);
+        const int64_t i0 = base + (int64_t)lane * E;
+        int64_t nk = lane_next_i64(q[0].key[0]);
+        if (lane == 63) nk = edge;
+        bool tf[E];
+#pragma unroll
+        for (int e = 0; e + 1 < E; ++e) tf[e] = i0 + e < n && (i0 + e + 1 >= n || q[0].key[e] != q[0].key[e + 1]);
+        tf[E - 1] = i0 + E - 1 < n && (i0 + E >= n || q[0].key[E - 1] != nk);
+        int lo = 0, hi = CH;
+        bool done = base == 0, skip = false;
+        if (base >= nb) {
+            if (!started) {
+                const int f = last_flag<E>(tf);
+                if (f >= 0) { hi = f + 1; started = true; }
+                else if (base == nb) return;                        // no tail in the nominal tile: nothing owned
+                else skip = true;
+            }
+        } else {                                                    // below the tile: the straddling ray begins after the last tail
+            const int f = last_flag<E>(tf);
+            if (f >= 0) { lo = f + 1; done = true; }
+        }
+        if (!skip) {
+            bool act[E];
+            SegBwd<E> s;
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pos = lane * E + e;
+                act[e] = i0 + e < n && pos >= lo && pos < hi;
+                s.tail[e] = !act[e] || tf[e];
+                any = any || s.tail[e];
+            }
+            s.dist = dist_to_tail(__ballot(any), lane, s.open);
+            body(i0, act, q[0].key, s, q[0].p);
+        }
+        edge = readlane_i64<0>(q[0].key[0]);
+        if (done) break;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) q[d] = q[d + 1];
+        if (PF == 0 || base - CH < lim) q[0] = fetch_chunk<E, P>(keys, n, base - CH, lane, load);
+    }
+}
+
+// Launch plan of the tiled kernels: elements per lane, nominal tile, whether to request the chunk past the tile early.
+// Tiles are 9 chunks (not a power of two: with big power-of-two tiles every resident wave streams its own region
+// `tile` elements apart and the concurrent requests alias onto a subset of the HBM channels — measured at N = 2^24:
+// weight_bwd 3.77 -> 4.80 TB/s, profiles/r01_tile_sweep.md), shrunk on inputs that cannot give every SIMD a few waves.
+struct TilePlan {
+    int e;
+    int64_t tile;
+    int spec;
+};
+// every pointer of a vectorised walk must be 16-byte aligned (tensors from the caching allocator are; views with an
+// odd storage offset are not): otherwise one element per lane
+inline bool aligned16(std::initializer_list<const void *> ptrs) {
+    for (const void *q : ptrs)
+        if ((reinterpret_cast<uintptr_t>(q) & 15u) != 0) return false;
+    return true;
+}
+inline TilePlan pick_plan(int64_t n, bool vec_ok = true) {
+    TilePlan p;
+    p.e = n >= ((int64_t)1 << 22) ? 4 : 1;
+    if (const char *s = getenv("NFA_E")) {               // tuning knobs
+        const int v = atoi(s);
+        if (v == 1 || v == 2 || v == 4) p.e = v;
+    }
+    if (!vec_ok) p.e = 1;
+    const int64_t ch = 64 * p.e;
+    const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
+    int64_t t = ceil_div(ceil_div(n, target_waves), ch) * ch;
+    if (t < ch) t = ch;                                  // (the one-element-per-lane plan has the smallest tile: workspaces are sized by it)
+    if (t > 9 * ch) t = 9 * ch;
+    if (const char *s = getenv("NFA_TILE")) {
+        const int64_t v = atoll(s);
+        if (v >= ch && v % ch == 0) t = v;
+    }
+    p.tile = t;
+    p.spec = t < 9 * ch;
+    return p;
+}
+inline unsigned tile_blocks(int64_t n, int64_t tile) { return (unsigned)ceil_div(ceil_div(n, tile), kWavesPerBlock); }
+
+// hipLaunchKernelGGL of KERNEL<E> for the plan's E
+#define NFA_LAUNCH_TILED(KERNEL, plan, n, stream, ...)                                                                     \
+    do {                                                                                                                   \
+        const dim3 g_(tile_blocks(n, (plan).tile)), b_(kBlock);                                                            \
+        if ((plan).e == 4) hipLaunchKernelGGL((KERNEL<4>), g_, b_, 0, stream, __VA_ARGS__);                                 \
+        else if ((plan).e == 2) hipLaunchKernelGGL((KERNEL<2>), g_, b_, 0, stream, __VA_ARGS__);                            \
+        else hipLaunchKernelGGL((KERNEL<1>), g_, b_, 0, stream, __VA_ARGS__);                                               \
+    } while (0)
 
 }  // namespace nfa

@@ -5,7 +5,7 @@
 // atomics, clamp/div, background blend — and their autograd twins) plus three host-syncing
 // boolean-mask compactions in OccGridEstimator.sampling (occ_grid.py:194-220).  Here each
 // logical op is ONE streaming kernel over the flat sample array, built on the
-// segment-snapped wave tiles of common.hpp:
+// ray-owning, line-aligned wave tiles of common.hpp:
 //   nfa_render_weight_from_density_{fwd,bwd}   volrend.py:219-278, 326-376
 //   nfa_visibility_compact                     volrend.py:435-494 + occ_grid.py:216-220
 //   nfa_accumulate_along_rays{,_bwd}           volrend.py:497-587
@@ -20,185 +20,150 @@ namespace {
 
 constexpr float kEpsF32 = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
 
-// Forward-direction segment flags of one 64-element chunk.
-struct SegFwd {
-    bool head, open;
-    int dist;
-    unsigned long long heads;
-};
-__device__ __forceinline__ SegFwd seg_fwd(int64_t key, bool active, bool first_chunk, int64_t edge_key, int lane) {
-    SegFwd s;
-    const int64_t pk = lane_prev_i64(key);
-    s.head = !active || key != pk;
-    if (lane == 0) s.head = first_chunk || key != edge_key;
-    s.heads = __ballot(s.head);
-    s.dist = dist_to_head(s.heads, lane, s.open);
-    return s;
-}
-// tail flag for a forward walk: the sample is the last of its ray.  Every lane loads the key after
-// its own together with its other inputs (same cache lines, one memory round trip) — peeking
-// keys[i + 1] from lane 63 only, after the scan flags, made each chunk wait for memory twice.
-__device__ __forceinline__ int64_t load_next_key(const int64_t *__restrict__ keys, int64_t i, int64_t end, int64_t key) {
-    return (i + 1 < end) ? keys[i + 1] : ~key;
-}
-// Reverse-direction flags.
-struct SegBwd {
-    bool tail, open;
-    int dist;
-};
-__device__ __forceinline__ SegBwd seg_bwd(int64_t key, bool active, int64_t i, int64_t end, int64_t edge_key, int lane) {
-    SegBwd s;
-    const int64_t nk = lane_next_i64(key);
-    s.tail = !active || (i + 1 >= end) || key != nk;
-    if (lane == 63 && active && i + 1 < end) s.tail = key != edge_key;
-    const unsigned long long tails = __ballot(s.tail);
-    s.dist = dist_to_tail(tails, lane, s.open);
-    return s;
-}
-
-__device__ __forceinline__ float seg_incl_fwd(float v, const SegFwd &s, float &carry) {
-    float incl = wave_seg_scan_fwd<OpSum>(v, s.dist);
-    if (s.open) incl += carry;
-    carry = readlane_f<63>(incl);
-    return incl;
-}
-__device__ __forceinline__ float seg_excl_fwd(float v, const SegFwd &s, float &carry, int lane) {
-    float incl = wave_seg_scan_fwd<OpSum>(v, s.dist);
-    if (s.open) incl += carry;
-    float excl = lane_prev_f(incl, 0.0f);
-    if (s.head) excl = 0.0f;
-    else if (lane == 0) excl = carry;
-    carry = readlane_f<63>(incl);
-    return excl;
-}
-__device__ __forceinline__ float seg_excl_bwd(float v, const SegBwd &s, float &carry, int lane) {
-    float incl = wave_seg_scan_bwd<OpSum>(v, s.dist);
-    if (s.open) incl += carry;
-    float excl = lane_next_f(incl, 0.0f);
-    if (s.tail) excl = 0.0f;
-    else if (lane == 63) excl = carry;
-    carry = readlane_f<0>(incl);
-    return excl;
-}
-
-#define NFA_WAVE_TILE_PROLOGUE(keys, n, tile)                                        \
-    const int64_t w_ = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);    \
-    const TileRange tr = snapped_tile(keys, n, w_, tile);                             \
-    if (tr.begin >= tr.end) return;                                                   \
-    const int lane = lane_id();                                                       \
-    const int64_t n_chunks = (tr.end - tr.begin + 63) >> 6;
+__device__ __forceinline__ int64_t wave_index() { return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
 
 // ----------------------------------------------------------------------------------------
 // weights / transmittance / alpha from density
 // ----------------------------------------------------------------------------------------
+template <int E>
+struct WeightFwdIn { float t0[E], t1[E], sg[E], pf[E]; };
+template <int E>
 __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const float *__restrict__ sigmas, const float *__restrict__ prefix, int64_t n, int64_t tile,
+    const float *__restrict__ sigmas, const float *__restrict__ prefix, int64_t n, int64_t tile, int spec,
     float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ alphas)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
     float carry = 0.0f;
-    int64_t edge_key = 0;
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t i = tr.begin + c * 64 + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0;
-        float sd = 0.0f;
-        if (active) { key = keys[i]; sd = sigmas[i] * (te[i] - ts[i]); }
-        const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
-        const float acc = seg_excl_fwd(sd, s, carry, lane);
-        edge_key = readlane_i64<63>(key);
-        if (active) {
-            const float a = 1.0f - expf(-sd);
-            float T = expf(-acc);
-            if (prefix) T = T * prefix[i];
-            if (alphas) st_stream(alphas + i, a);
-            if (trans) st_stream(trans + i, T);
-            if (weights) st_stream(weights + i, T * a);
-        }
-    }
+    walk_rays_fwd<E, 1, WeightFwdIn<E>>(keys, n, wave_index(), tile, spec,
+        [&](int64_t i0) {
+            WeightFwdIn<E> p;
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1);
+            ld_vec<E>(sigmas, i0, n, 0.0f, p.sg);
+            if (prefix) ld_vec<E>(prefix, i0, n, 1.0f, p.pf);
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const WeightFwdIn<E> &p) {
+            float sd[E], incl[E], acc[E], a[E], T[E], wgt[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) sd[e] = act[e] ? p.sg[e] * (p.t1[e] - p.t0[e]) : 0.0f;
+            seg_scan_fwd<OpSum, E>(sd, s, carry, incl, acc);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                a[e] = 1.0f - expf(-sd[e]);
+                T[e] = expf(-acc[e]);
+                if (prefix) T[e] = T[e] * p.pf[e];
+                wgt[e] = T[e] * a[e];
+            }
+            if (alphas) st_vec<E>(alphas, i0, act, a);
+            if (trans) st_vec<E>(trans, i0, act, T);
+            if (weights) st_vec<E>(weights, i0, act, wgt);
+        },
+        [](int64_t) {});
 }
 
 // d/dsigma of sum(g_w w + g_T T + g_a a):
 //   g_sd_i = (g_w_i T_i + g_a_i)(1 - a_i) - sum_{j>i, same ray} (g_w_j w_j + g_T_j T_j)
+template <int E>
+struct WeightBwdIn { float T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E]; };
+template <int E>
 __global__ __launch_bounds__(kBlock) void weight_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ trans, const float *__restrict__ alphas,
     const float *__restrict__ g_w, const float *__restrict__ g_T, const float *__restrict__ g_a,
-    int64_t n, int64_t tile, float *__restrict__ g_sigmas)
+    int64_t n, int64_t tile, int spec, float *__restrict__ g_sigmas)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
     float carry = 0.0f;
-    int64_t edge_key = 0;
-    for (int64_t c = n_chunks - 1; c >= 0; --c) {
-        const int64_t i = tr.begin + c * 64 + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0;
-        float T = 0.f, a = 0.f, gw = 0.f, gT = 0.f, ga = 0.f;
-        if (active) {
-            key = keys[i];
-            T = trans[i];
-            a = alphas[i];
-            if (g_w) gw = g_w[i];
-            if (g_T) gT = g_T[i];
-            if (g_a) ga = g_a[i];
-        }
-        const SegBwd s = seg_bwd(key, active, i, tr.end, edge_key, lane);
-        const float q = gw * (T * a) + gT * T;
-        const float suffix = seg_excl_bwd(q, s, carry, lane);
-        edge_key = readlane_i64<0>(key);
-        if (active) g_sigmas[i] = ((gw * T + ga) * (1.0f - a) - suffix) * (te[i] - ts[i]);
-    }
+    walk_rays_bwd<E, 1, WeightBwdIn<E>>(keys, n, wave_index(), tile, spec,
+        [&](int64_t i0) {
+            WeightBwdIn<E> p;
+            ld_vec<E>(trans, i0, n, 0.0f, p.T);
+            ld_vec<E>(alphas, i0, n, 0.0f, p.a);
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
+            if (g_w) ld_vec<E>(g_w, i0, n, 0.0f, p.gw);
+            if (g_T) ld_vec<E>(g_T, i0, n, 0.0f, p.gT);
+            if (g_a) ld_vec<E>(g_a, i0, n, 0.0f, p.ga);
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegBwd<E> &s, const WeightBwdIn<E> &p) {
+            float q[E], incl[E], suffix[E], gs[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) q[e] = act[e] ? p.gw[e] * (p.T[e] * p.a[e]) + p.gT[e] * p.T[e] : 0.0f;
+            seg_scan_bwd<OpSum, E>(q, s, carry, incl, suffix);
+#pragma unroll
+            for (int e = 0; e < E; ++e) gs[e] = ((p.gw[e] * p.T[e] + p.ga[e]) * (1.0f - p.a[e]) - suffix[e]) * (p.t1[e] - p.t0[e]);
+            st_vec<E>(g_sigmas, i0, act, gs);
+        });
 }
 
 // ----------------------------------------------------------------------------------------
 // visibility filter + compaction (three kernels, no host round trip in between)
 // ----------------------------------------------------------------------------------------
-// 1) keep mask and per-wave-tile kept counts
+// 1) keep mask, per-wave-tile kept counts and the range each wave owned (for the compaction's walk)
+template <int E>
+struct VisIn { float d[E], t0[E], t1[E]; };
+template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, float eps, float alpha_thre,
-    uint8_t *__restrict__ mask, int64_t *__restrict__ tile_cnts)
+    const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, int spec, float eps, float alpha_thre,
+    uint8_t *__restrict__ mask, int64_t *__restrict__ tile_cnts, int64_t *__restrict__ tile_rng)
 {
-    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t w = wave_index();
     if (w * tile >= n) return;
-    const TileRange tr = snapped_tile(keys, n, w, tile);
     const int lane = lane_id();
-    int64_t kept = 0;
-    if (tr.begin < tr.end) {
-        const int64_t n_chunks = (tr.end - tr.begin + 63) >> 6;
-        float carry = from_alpha ? 1.0f : 0.0f;
-        int64_t edge_key = 0;
-        for (int64_t c = 0; c < n_chunks; ++c) {
-            const int64_t i = tr.begin + c * 64 + lane;
-            const bool active = i < tr.end;
-            int64_t key = 0;
-            float x = 0.0f, a = 0.0f;
-            if (active) {
-                key = keys[i];
-                if (from_alpha) { a = dens[i]; x = 1.0f - a; }
-                else { x = dens[i] * (te[i] - ts[i]); a = 1.0f - expf(-x); }
-            }
-            const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
-            float T;
+    int64_t kept = 0, rb = 0, re = 0;
+    bool first = true;
+    float carry = from_alpha ? 1.0f : 0.0f;
+    walk_rays_fwd<E, 1, VisIn<E>>(keys, n, w, tile, spec,
+        [&](int64_t i0) {
+            VisIn<E> p;
+            ld_vec<E>(dens, i0, n, 0.0f, p.d);
+            if (!from_alpha) { ld_vec<E>(ts, i0, n, 0.0f, p.t0); ld_vec<E>(te, i0, n, 0.0f, p.t1); }
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
+            float x[E], a[E], incl[E], ex[E];
+            uint8_t keep[E];
             if (from_alpha) {   // exclusive product of (1 - alpha), volrend.py:207-209
-                float incl = wave_seg_scan_fwd<OpProd>(active ? x : 1.0f, s.dist);
-                if (s.open) incl = carry * incl;
-                T = lane_prev_f(incl, 0.0f);
-                if (s.head) T = 1.0f;
-                else if (lane == 0) T = carry;
-                carry = readlane_f<63>(incl);
+#pragma unroll
+                for (int e = 0; e < E; ++e) { a[e] = p.d[e]; x[e] = act[e] ? 1.0f - a[e] : 1.0f; }
+                seg_scan_fwd<OpProd, E>(x, s, carry, incl, ex);
             } else {
-                T = expf(-seg_excl_fwd(x, s, carry, lane));
+#pragma unroll
+                for (int e = 0; e < E; ++e) { x[e] = act[e] ? p.d[e] * (p.t1[e] - p.t0[e]) : 0.0f; a[e] = 1.0f - expf(-x[e]); }
+                seg_scan_fwd<OpSum, E>(x, s, carry, incl, ex);
+#pragma unroll
+                for (int e = 0; e < E; ++e) ex[e] = expf(-ex[e]);
             }
-            edge_key = readlane_i64<63>(key);
-            bool keep = active && (T >= eps);
-            if (alpha_thre > 0.0f) keep = keep && (a >= alpha_thre);
-            if (active) mask[i] = keep ? 1 : 0;
-            kept += __popcll(__ballot(keep));
-        }
-    }
-    if (lane == 0) tile_cnts[w] = kept;
+            bool any_act = false, lane_first = false;
+            int fe = 0, le = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                bool k = act[e] && (ex[e] >= eps);
+                if (alpha_thre > 0.0f) k = k && (a[e] >= alpha_thre);
+                keep[e] = k ? 1 : 0;
+                kept += __popcll(__ballot(k));
+                if (act[e]) { if (!any_act) fe = e; le = e; any_act = true; }
+            }
+            st_vec<E>(mask, i0, act, keep);
+            (void)lane_first;
+            const unsigned long long am = __ballot(any_act);
+            if (am) {
+                const int64_t base = i0 - (int64_t)lane * E;
+                if (first) {
+                    const int l = __ffsll((long long)am) - 1;
+                    rb = base + l * E + __builtin_amdgcn_readlane(fe, l);
+                    first = false;
+                }
+                const int l = 63 - __clzll((long long)am);
+                re = base + l * E + __builtin_amdgcn_readlane(le, l) + 1;
+            }
+        },
+        [](int64_t) {});
+    if (lane == 0) { tile_cnts[w] = kept; tile_rng[2 * w] = rb; tile_rng[2 * w + 1] = re; }
 }
 
 // 2) (only beyond kVisFusedTiles tiles) one wave per group of 64 tiles: exclusive prefix of the
@@ -234,17 +199,25 @@ constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
-    int mode, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t n, int64_t tile,
+    const int64_t *__restrict__ tile_rng, int mode, int64_t n_tiles, int64_t *__restrict__ n_out,
     int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
-    const int64_t w_ = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t w_ = wave_index();
     if (w_ >= n_tiles) return;
     const int lane = lane_id();
-    const TileRange tr = snapped_tile(keys, n, w_, tile);
+    const int64_t rb = tile_rng[2 * w_], re = tile_rng[2 * w_ + 1];
     int64_t dst;
     if (mode == 1) {
         int64_t p = 0;
-        for (int64_t j = lane; j < w_; j += 64) p += tile_offs[j];
+        int64_t j = lane;
+        for (; j + 7 * 64 < w_; j += 8 * 64) {             // eight loads in flight: up to 64 rounds of one L2 latency each otherwise
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tile_offs[j + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p += v[u];
+        }
+        for (; j < w_; j += 64) p += tile_offs[j];
         dst = wave_sum_i64(p);
         if (w_ == n_tiles - 1 && lane == 0) *n_out = dst + tile_offs[w_];
     } else if (mode == 2) {
@@ -256,12 +229,10 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     } else {
         dst = tile_offs[w_];
     }
-    if (!o_keys) return;
-    if (tr.begin >= tr.end) return;
-    const int64_t n_chunks = (tr.end - tr.begin + 63) >> 6;
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t i = tr.begin + c * 64 + lane;
-        const bool keep = (i < tr.end) && mask[i];
+    if (!o_keys || rb >= re) return;
+    for (int64_t base = (rb >> 6) << 6; base < re; base += 64) {      // the mask kernel's chunks
+        const int64_t i = base + lane;
+        const bool keep = i >= rb && i < re && mask[i];
         const unsigned long long b = __ballot(keep);
         if (keep) {
             const int64_t k = dst + __popcll(b & lanes_lt(lane));
@@ -276,55 +247,50 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
 // ----------------------------------------------------------------------------------------
 // accumulate_along_rays: out[r, c0 + c] += sum_i w_i v[i, c0 + c]   (DC channels per launch)
 // ----------------------------------------------------------------------------------------
-template <int DC>
+template <int E, int DC>
+struct AccumIn { float w[E], v[E][DC]; };
+template <int E, int DC>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ weights, const float *__restrict__ values,
-    int64_t n, int64_t tile, int D, int c0, int64_t n_rays, float *__restrict__ out)
+    int64_t n, int64_t tile, int spec, int D, int c0, int64_t n_rays, float *__restrict__ out)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
+    const int lane = lane_id();
     float carry[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) carry[c] = 0.0f;
-    int64_t edge_key = 0;
-    // U chunks per trip, all their loads issued before the first scan: this kernel moves only
-    // 12 + 4 DC bytes per sample, and with one chunk in flight per wave the bytes in flight per CU
-    // (not the HBM) bounded it (Little's law)
-    constexpr int U = 3;
-    for (int64_t ch0 = 0; ch0 < n_chunks; ch0 += U) {
-        int64_t key[U], nkey[U];
-        float w[U], v[U][DC];
+    // two further chunks requested ahead: this kernel moves only 12 + 4 DC bytes per sample, and with one chunk in
+    // flight per wave the bytes in flight per CU (not the HBM) bounded it (Little's law)
+    walk_rays_fwd<E, (E == 1 ? 2 : 1), AccumIn<E, DC>>(keys, n, wave_index(), tile, spec,
+        [&](int64_t i0) {
+            AccumIn<E, DC> p;
+            ld_vec<E>(weights, i0, n, 0.0f, p.w);
+            if (values && D == DC) ld_vec_strided<E, DC>(values, i0, n, 1.0f, p.v);
+            else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = tr.begin + (ch0 + u) * 64 + lane;
-            key[u] = 0; nkey[u] = -1; w[u] = 0.0f;
+                for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int c = 0; c < DC; ++c) v[u][c] = 1.0f;
-            if (i < tr.end) {
-                key[u] = keys[i];
-                nkey[u] = load_next_key(keys, i, tr.end, key[u]);
-                w[u] = weights[i];
-                if (values) {
-#pragma unroll
-                    for (int c = 0; c < DC; ++c) v[u][c] = values[i * D + c0 + c];
-                }
+                    for (int c = 0; c < DC; ++c) p.v[e][c] = (values && i0 + e < n) ? values[(i0 + e) * D + c0 + c] : 1.0f;
             }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t ch = ch0 + u;
-            if (ch >= n_chunks) break;
-            const int64_t i = tr.begin + ch * 64 + lane;
-            const bool active = i < tr.end;
-            const SegFwd s = seg_fwd(key[u], active, ch == 0, edge_key, lane);
-            const bool tail = active && nkey[u] != key[u];
-            edge_key = readlane_i64<63>(key[u]);
+            return p;
+        },
+        [&](int64_t, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&tail)[E], const AccumIn<E, DC> &p) {
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-                const float tot = seg_incl_fwd(w[u] * v[u][c], s, carry[c]);
-                if (active && tail && key[u] >= 0 && key[u] < n_rays) unsafeAtomicAdd(out + key[u] * D + c0 + c, tot);
+                float x[E], incl[E], excl[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = act[e] ? p.w[e] * p.v[e][c] : 0.0f;
+                seg_scan_fwd<OpSum, E>(x, s, carry[c], incl, excl);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (tail[e] && key[e] >= 0 && key[e] < n_rays) unsafeAtomicAdd(out + key[e] * D + c0 + c, incl[e]);
             }
-        }
-    }
+        },
+        [&](int64_t key) {
+            if (lane == 0 && key >= 0 && key < n_rays) {
+#pragma unroll
+                for (int c = 0; c < DC; ++c) unsafeAtomicAdd(out + key * D + c0 + c, carry[c]);
+            }
+        });
 }
 
 __global__ __launch_bounds__(kBlock) void accumulate_bwd_kernel(
@@ -361,109 +327,142 @@ __global__ __launch_bounds__(kBlock) void fill_rays_kernel(int64_t n_rays, const
     }
 }
 
+template <int E>
+struct RenderFwdIn { float t0[E], t1[E], sg[E], rgb[E][3]; };
+template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const float *__restrict__ sigmas, const float *__restrict__ rgbs, int64_t n, int64_t tile, int64_t n_rays,
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, int64_t n, int64_t tile, int spec, int64_t n_rays,
     const float *__restrict__ bkgd, int expected_depths,
     float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ alphas,
     float *__restrict__ colors, float *__restrict__ opac, float *__restrict__ depth)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
+    const int lane = lane_id();
     float c_sd = 0.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, c_w = 0.f, c_m = 0.f;
-    int64_t edge_key = 0;
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t i = tr.begin + c * 64 + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0, nkey = -1;
-        float t0 = 0.f, t1 = 0.f, sd = 0.f, r = 0.f, g = 0.f, b = 0.f;
-        if (active) {
-            key = keys[i];
-            nkey = load_next_key(keys, i, tr.end, key);
-            t0 = ts[i]; t1 = te[i];
-            sd = sigmas[i] * (t1 - t0);
-            r = rgbs[3 * i]; g = rgbs[3 * i + 1]; b = rgbs[3 * i + 2];
-        }
-        const SegFwd s = seg_fwd(key, active, c == 0, edge_key, lane);
-        const bool tail = active && nkey != key;
-        edge_key = readlane_i64<63>(key);
-        const float acc = seg_excl_fwd(sd, s, c_sd, lane);
-        float w = 0.0f;
-        if (active) {
-            const float a = 1.0f - expf(-sd);
-            const float T = expf(-acc);
-            w = T * a;
-            st_stream(alphas + i, a);
-            st_stream(trans + i, T);
-            st_stream(weights + i, w);
-        }
-        const float sr = seg_incl_fwd(w * r, s, c_r);
-        const float sg = seg_incl_fwd(w * g, s, c_g);
-        const float sb = seg_incl_fwd(w * b, s, c_b);
-        const float sw = seg_incl_fwd(w, s, c_w);
-        const float sm = seg_incl_fwd(w * ((t0 + t1) / 2.0f), s, c_m);
-        if (active && tail && key >= 0 && key < n_rays) {
-            const float rem = 1.0f - sw;
-            colors[3 * key] = bkgd ? sr + bk0 * rem : sr;
-            colors[3 * key + 1] = bkgd ? sg + bk1 * rem : sg;
-            colors[3 * key + 2] = bkgd ? sb + bk2 * rem : sb;
-            opac[key] = sw;
-            depth[key] = expected_depths ? sm / fmaxf(sw, kEpsF32) : sm;
-        }
-    }
+    auto ray_out = [&](int64_t key, float sr, float sg, float sb, float sw, float sm) {
+        if (key < 0 || key >= n_rays) return;
+        const float rem = 1.0f - sw;
+        colors[3 * key] = bkgd ? sr + bk0 * rem : sr;
+        colors[3 * key + 1] = bkgd ? sg + bk1 * rem : sg;
+        colors[3 * key + 2] = bkgd ? sb + bk2 * rem : sb;
+        opac[key] = sw;
+        depth[key] = expected_depths ? sm / fmaxf(sw, kEpsF32) : sm;
+    };
+    walk_rays_fwd<E, 1, RenderFwdIn<E>>(keys, n, wave_index(), tile, spec,
+        [&](int64_t i0) {
+            RenderFwdIn<E> p;
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1);
+            ld_vec<E>(sigmas, i0, n, 0.0f, p.sg);
+            ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb);
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&tail)[E], const RenderFwdIn<E> &p) {
+            float sd[E], incl[E], acc[E], a[E], T[E], w[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) sd[e] = act[e] ? p.sg[e] * (p.t1[e] - p.t0[e]) : 0.0f;
+            seg_scan_fwd<OpSum, E>(sd, s, c_sd, incl, acc);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                a[e] = 1.0f - expf(-sd[e]);
+                T[e] = expf(-acc[e]);
+                w[e] = act[e] ? T[e] * a[e] : 0.0f;
+            }
+            st_vec<E>(alphas, i0, act, a);
+            st_vec<E>(trans, i0, act, T);
+            st_vec<E>(weights, i0, act, w);
+            float x[E], sr[E], sg[E], sb[E], sw[E], sm[E], ex[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = w[e] * p.rgb[e][0];
+            seg_scan_fwd<OpSum, E>(x, s, c_r, sr, ex);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = w[e] * p.rgb[e][1];
+            seg_scan_fwd<OpSum, E>(x, s, c_g, sg, ex);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = w[e] * p.rgb[e][2];
+            seg_scan_fwd<OpSum, E>(x, s, c_b, sb, ex);
+            seg_scan_fwd<OpSum, E>(w, s, c_w, sw, ex);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = w[e] * ((p.t0[e] + p.t1[e]) / 2.0f);
+            seg_scan_fwd<OpSum, E>(x, s, c_m, sm, ex);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (tail[e]) ray_out(key[e], sr[e], sg[e], sb[e], sw[e], sm[e]);
+        },
+        [&](int64_t key) { if (lane == 0) ray_out(key, c_r, c_g, c_b, c_w, c_m); });
 }
 
+template <int E>
+struct RenderBwdIn { float w[E], T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E], rgb[E][3]; };
+template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ rgbs, const float *__restrict__ weights, const float *__restrict__ trans,
     const float *__restrict__ alphas, const float *__restrict__ opac, const float *__restrict__ depth,
-    int64_t n, int64_t tile, int64_t n_rays, const float *__restrict__ bkgd, int expected_depths,
+    int64_t n, int64_t tile, int spec, int64_t n_rays, const float *__restrict__ bkgd, int expected_depths,
     const float *__restrict__ g_colors, const float *__restrict__ g_opac, const float *__restrict__ g_depth,
     const float *__restrict__ g_w_ext, const float *__restrict__ g_T_ext, const float *__restrict__ g_a_ext,
     float *__restrict__ g_sigmas, float *__restrict__ g_rgbs)
 {
-    NFA_WAVE_TILE_PROLOGUE(keys, n, tile)
     float carry = 0.0f;
-    int64_t edge_key = 0;
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
-    for (int64_t c = n_chunks - 1; c >= 0; --c) {
-        const int64_t i = tr.begin + c * 64 + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0;
-        float w = 0.f, T = 0.f, a = 0.f, gw = 0.f, gT = 0.f, ga = 0.f, dt = 0.f;
-        if (active) {
-            key = keys[i];
-            w = weights[i]; T = trans[i]; a = alphas[i];
-            const float t0 = ts[i], t1 = te[i];
-            dt = t1 - t0;
-            if (g_w_ext) gw = g_w_ext[i];
-            if (g_T_ext) gT = g_T_ext[i];
-            if (g_a_ext) ga = g_a_ext[i];
-            if (key >= 0 && key < n_rays) {
-                float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
-                if (g_colors) { gc0 = g_colors[3 * key]; gc1 = g_colors[3 * key + 1]; gc2 = g_colors[3 * key + 2]; }
-                float go = g_opac ? g_opac[key] : 0.0f;
-                float gacc = 0.0f;                      // dL/d(sum w m)
-                if (g_depth) {
-                    const float gd = g_depth[key];
-                    if (expected_depths) {
-                        const float O = opac[key];
-                        gacc = gd / fmaxf(O, kEpsF32);
-                        if (O > kEpsF32) go -= gd * depth[key] / O;
-                    } else gacc = gd;
+    walk_rays_bwd<E, 1, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
+        [&](int64_t i0) {
+            RenderBwdIn<E> p;
+            ld_vec<E>(weights, i0, n, 0.0f, p.w);
+            ld_vec<E>(trans, i0, n, 0.0f, p.T);
+            ld_vec<E>(alphas, i0, n, 0.0f, p.a);
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1);
+            ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb);
+#pragma unroll
+            for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
+            if (g_w_ext) ld_vec<E>(g_w_ext, i0, n, 0.0f, p.gw);
+            if (g_T_ext) ld_vec<E>(g_T_ext, i0, n, 0.0f, p.gT);
+            if (g_a_ext) ld_vec<E>(g_a_ext, i0, n, 0.0f, p.ga);
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegBwd<E> &s, const RenderBwdIn<E> &p) {
+            float gw[E], q[E], incl[E], suffix[E], gs[E], grgb[E][3];
+            bool wr[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                gw[e] = p.gw[e];
+                wr[e] = act[e] && key[e] >= 0 && key[e] < n_rays;
+                grgb[e][0] = grgb[e][1] = grgb[e][2] = 0.0f;
+                if (wr[e]) {
+                    const int64_t k = key[e];
+                    float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+                    if (g_colors) { gc0 = g_colors[3 * k]; gc1 = g_colors[3 * k + 1]; gc2 = g_colors[3 * k + 2]; }
+                    float go = g_opac ? g_opac[k] : 0.0f;
+                    float gacc = 0.0f;                      // dL/d(sum w m)
+                    if (g_depth) {
+                        const float gd = g_depth[k];
+                        if (expected_depths) {
+                            const float O = opac[k];
+                            gacc = gd / fmaxf(O, kEpsF32);
+                            if (O > kEpsF32) go -= gd * depth[k] / O;
+                        } else gacc = gd;
+                    }
+                    if (bkgd) go -= gc0 * bk0 + gc1 * bk1 + gc2 * bk2;
+                    gw[e] += gc0 * p.rgb[e][0] + gc1 * p.rgb[e][1] + gc2 * p.rgb[e][2] + go + gacc * ((p.t0[e] + p.t1[e]) / 2.0f);
+                    grgb[e][0] = p.w[e] * gc0; grgb[e][1] = p.w[e] * gc1; grgb[e][2] = p.w[e] * gc2;
                 }
-                if (bkgd) go -= gc0 * bk0 + gc1 * bk1 + gc2 * bk2;
-                gw += gc0 * rgbs[3 * i] + gc1 * rgbs[3 * i + 1] + gc2 * rgbs[3 * i + 2] + go + gacc * ((t0 + t1) / 2.0f);
-                if (g_rgbs) { g_rgbs[3 * i] = w * gc0; g_rgbs[3 * i + 1] = w * gc1; g_rgbs[3 * i + 2] = w * gc2; }
+                q[e] = act[e] ? gw[e] * p.w[e] + p.gT[e] * p.T[e] : 0.0f;
             }
-        }
-        const SegBwd s = seg_bwd(key, active, i, tr.end, edge_key, lane);
-        const float suffix = seg_excl_bwd(gw * w + gT * T, s, carry, lane);
-        edge_key = readlane_i64<0>(key);
-        if (active && g_sigmas) g_sigmas[i] = ((gw * T + ga) * (1.0f - a) - suffix) * dt;
-    }
+            if (g_rgbs) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (wr[e]) { g_rgbs[3 * (i0 + e)] = grgb[e][0]; g_rgbs[3 * (i0 + e) + 1] = grgb[e][1]; g_rgbs[3 * (i0 + e) + 2] = grgb[e][2]; }
+            }
+            seg_scan_bwd<OpSum, E>(q, s, carry, incl, suffix);
+#pragma unroll
+            for (int e = 0; e < E; ++e) gs[e] = ((gw[e] * p.T[e] + p.ga[e]) * (1.0f - p.a[e]) - suffix[e]) * (p.t1[e] - p.t0[e]);
+            if (g_sigmas) st_vec<E>(g_sigmas, i0, act, gs);
+        });
 }
 
 // ----------------------------------------------------------------------------------------
@@ -601,7 +600,6 @@ __global__ __launch_bounds__(kBlock) void sample_positions_kernel(
     }
 }
 
-inline unsigned tile_blocks(int64_t n, int64_t tile) { return (unsigned)ceil_div(ceil_div(n, tile), kWavesPerBlock); }
 
 }  // namespace
 }  // namespace nfa
@@ -616,9 +614,9 @@ NFA_EXPORT int nfa_render_weight_from_density_fwd(const int64_t *ray_indices, co
     NFA_REQUIRE(n >= 0, "render_weight_from_density_fwd: n < 0");
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && sigmas, "render_weight_from_density_fwd: NULL input");
-    const int64_t tile = pick_tile(n);
-    hipLaunchKernelGGL(weight_fwd_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, (hipStream_t)stream,
-                       ray_indices, t_starts, t_ends, sigmas, prefix_trans, n, tile, weights, trans, alphas);
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, sigmas, prefix_trans, weights, trans, alphas}));
+    NFA_LAUNCH_TILED(weight_fwd_kernel, pl, n, (hipStream_t)stream,
+                     ray_indices, t_starts, t_ends, sigmas, prefix_trans, n, pl.tile, pl.spec, weights, trans, alphas);
     return check_launch("weight_fwd_kernel");
 }
 
@@ -632,16 +630,17 @@ NFA_EXPORT int nfa_render_weight_from_density_bwd(const int64_t *ray_indices, co
     NFA_REQUIRE(n >= 0, "render_weight_from_density_bwd: n < 0");
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && trans && alphas && g_sigmas, "render_weight_from_density_bwd: NULL pointer");
-    const int64_t tile = pick_tile(n);
-    hipLaunchKernelGGL(weight_bwd_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, (hipStream_t)stream,
-                       ray_indices, t_starts, t_ends, trans, alphas, g_weights, g_trans, g_alphas, n, tile, g_sigmas);
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
+    NFA_LAUNCH_TILED(weight_bwd_kernel, pl, n, (hipStream_t)stream,
+                     ray_indices, t_starts, t_ends, trans, alphas, g_weights, g_trans, g_alphas, n, pl.tile, pl.spec, g_sigmas);
     return check_launch("weight_bwd_kernel");
 }
 
-// workspace layout: [ mask: n bytes, padded to 16 ][ tile_cnts: T int64 ][ tile_offs: T int64 ]
-static inline int64_t vis_tiles(int64_t n) { return ceil_div(n > 0 ? n : 1, pick_tile(n)); }
+// workspace layout: [ mask: n bytes, padded to 16 ][ tile_cnts: T int64 ][ tile_offs: T int64 ][ tile_rng: 2 T int64 ]
+// (the workspace is sized for the smallest tile any plan of this n can pick: one element per lane)
+static inline int64_t vis_tiles(int64_t n) { return ceil_div(n > 0 ? n : 1, pick_plan(n, false).tile); }
 NFA_EXPORT int64_t nfa_visibility_workspace_bytes(int64_t n) {
-    return ceil_div(n > 0 ? n : 1, 16) * 16 + 2 * (int64_t)sizeof(int64_t) * vis_tiles(n);
+    return ceil_div(n > 0 ? n : 1, 16) * 16 + 4 * (int64_t)sizeof(int64_t) * vis_tiles(n);
 }
 
 NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
@@ -655,12 +654,13 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { (void)hipMemsetAsync(n_out, 0, sizeof(int64_t), s); return NFA_OK; }
     NFA_REQUIRE(ray_indices && t_starts && t_ends && dens && workspace, "visibility_compact: NULL pointer");
-    const int64_t tile = pick_tile(n), T = vis_tiles(n);
     uint8_t *mask = out_mask ? out_mask : (uint8_t *)workspace;
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, dens, mask}));
+    const int64_t tile = pl.tile, T = ceil_div(n, tile);
     int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + ceil_div(n, 16) * 16);
-    int64_t *tile_offs = tile_cnts + T;
-    hipLaunchKernelGGL(visibility_mask_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       dens, from_alpha, n, tile, early_stop_eps, alpha_thre, mask, tile_cnts);
+    int64_t *tile_offs = tile_cnts + T, *tile_rng = tile_offs + T;
+    NFA_LAUNCH_TILED(visibility_mask_kernel, pl, n, s, ray_indices, t_starts, t_ends,
+                     dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, mask, tile_cnts, tile_rng);
     if (int rc = check_launch("visibility_mask_kernel")) return rc;
     if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
     const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
@@ -675,7 +675,7 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
         if (!out_ray_indices) return NFA_OK;
     }
     hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, mode, T, n_out, n, tile,
+                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, tile_rng, mode, T, n_out,
                        out_ray_indices, out_t_starts, out_t_ends);
     return check_launch("visibility_compact_kernel");
 }
@@ -688,17 +688,26 @@ NFA_EXPORT int nfa_accumulate_along_rays(const int64_t *ray_indices, const float
     NFA_REQUIRE(values != nullptr || D == 1, "accumulate_along_rays: D must be 1 when values is NULL");
     if (n == 0 || n_rays == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && weights && outputs, "accumulate_along_rays: NULL pointer");
-    const int64_t tile = pick_tile(n);
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, weights, values}));
+    const int64_t tile = pl.tile;
     const dim3 grid(tile_blocks(n, tile)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
+#define NFA_ACC(DC)                                                                                                              \
+    do {                                                                                                                         \
+        if (pl.e == 4) hipLaunchKernelGGL((accumulate_kernel<4, DC>), grid, block, 0, s, ray_indices, weights, values, n, tile, pl.spec, D, c0, n_rays, outputs); \
+        else if (pl.e == 2) hipLaunchKernelGGL((accumulate_kernel<2, DC>), grid, block, 0, s, ray_indices, weights, values, n, tile, pl.spec, D, c0, n_rays, outputs); \
+        else hipLaunchKernelGGL((accumulate_kernel<1, DC>), grid, block, 0, s, ray_indices, weights, values, n, tile, pl.spec, D, c0, n_rays, outputs); \
+        c0 += DC;                                                                                                                \
+    } while (0)
     int c0 = 0;
     while (c0 < D) {
         const int rem = D - c0;
-        if (rem >= 4) { hipLaunchKernelGGL(accumulate_kernel<4>, grid, block, 0, s, ray_indices, weights, values, n, tile, D, c0, n_rays, outputs); c0 += 4; }
-        else if (rem == 3) { hipLaunchKernelGGL(accumulate_kernel<3>, grid, block, 0, s, ray_indices, weights, values, n, tile, D, c0, n_rays, outputs); c0 += 3; }
-        else if (rem == 2) { hipLaunchKernelGGL(accumulate_kernel<2>, grid, block, 0, s, ray_indices, weights, values, n, tile, D, c0, n_rays, outputs); c0 += 2; }
-        else { hipLaunchKernelGGL(accumulate_kernel<1>, grid, block, 0, s, ray_indices, weights, values, n, tile, D, c0, n_rays, outputs); c0 += 1; }
+        if (rem >= 4) NFA_ACC(4);
+        else if (rem == 3) NFA_ACC(3);
+        else if (rem == 2) NFA_ACC(2);
+        else NFA_ACC(1);
     }
+#undef NFA_ACC
     return check_launch("accumulate_kernel");
 }
 
@@ -728,9 +737,9 @@ NFA_EXPORT int nfa_rendering_fwd(const int64_t *ray_indices, const float *t_star
     if (int rc = check_launch("fill_rays_kernel")) return rc;
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && sigmas && rgbs && weights && trans && alphas, "rendering_fwd: NULL pointer");
-    const int64_t tile = pick_tile(n);
-    hipLaunchKernelGGL(rendering_fwd_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       sigmas, rgbs, n, tile, n_rays, bkgd, expected_depths, weights, trans, alphas, colors, opacities, depths);
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, sigmas, rgbs, weights, trans, alphas}));
+    NFA_LAUNCH_TILED(rendering_fwd_kernel, pl, n, s, ray_indices, t_starts, t_ends,
+                     sigmas, rgbs, n, pl.tile, pl.spec, n_rays, bkgd, expected_depths, weights, trans, alphas, colors, opacities, depths);
     return check_launch("rendering_fwd_kernel");
 }
 
@@ -747,10 +756,10 @@ NFA_EXPORT int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_star
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && weights && trans && alphas, "rendering_bwd: NULL pointer");
     NFA_REQUIRE(!(g_depths && expected_depths) || (opacities && depths), "rendering_bwd: opacities/depths needed for g_depths");
-    const int64_t tile = pick_tile(n);
-    hipLaunchKernelGGL(rendering_bwd_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, (hipStream_t)stream,
-                       ray_indices, t_starts, t_ends, rgbs, weights, trans, alphas, opacities, depths, n, tile, n_rays, bkgd,
-                       expected_depths, g_colors, g_opacities, g_depths, g_weights, g_trans, g_alphas, g_sigmas, g_rgbs);
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, weights, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
+    NFA_LAUNCH_TILED(rendering_bwd_kernel, pl, n, (hipStream_t)stream,
+                     ray_indices, t_starts, t_ends, rgbs, weights, trans, alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd,
+                     expected_depths, g_colors, g_opacities, g_depths, g_weights, g_trans, g_alphas, g_sigmas, g_rgbs);
     return check_launch("rendering_bwd_kernel");
 }
 

@@ -4,8 +4,8 @@
 // scan_cub.cu (keyed by ray index, cub::DeviceScan::*ByKey) behind include/nerfacc_hip.h.
 //
 // MI355X mapping
-//   keyed:   segment-snapped wave tiles (common.hpp): each wave owns a range of whole rays,
-//            walks it in 64-element chunks, ballot()s the segment heads, runs a 6-step
+//   keyed:   ray-owning wave tiles (common.hpp): each wave owns a range of whole rays,
+//            walks it in line-aligned 64-element chunks, ballot()s the segment heads, runs a 6-step
 //            segmented shuffle scan and carries one register across chunks.  Single pass,
 //            8+4 bytes read and 4 written per element, no LDS, no atomics, no inter-workgroup
 //            traffic, results independent of scheduling.
@@ -22,67 +22,53 @@ namespace {
 // ----------------------------------------------------------------------------------------
 // Optional fusions for the product backward (scan.cu:199-210): v = in * mul before the scan,
 // result / max(div, 1e-10) after it.
-template <class Op, bool INCL, bool REV>
+template <int E>
+struct ScanIn { float v[E], m[E], d[E]; };
+template <class Op, bool INCL, bool REV, int E>
 __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ in, const float *__restrict__ mul,
-    const float *__restrict__ div, float *__restrict__ out, int64_t n, int64_t tile)
+    const float *__restrict__ div, float *__restrict__ out, int64_t n, int64_t tile, int spec)
 {
     const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const TileRange tr = snapped_tile(keys, n, w, tile);
-    if (tr.begin >= tr.end) return;
-    const int lane = lane_id();
     const float ident = Op::identity();
     float carry = ident;
-    int64_t edge_key = 0;          // key just outside the current chunk on the incoming side
-    const int64_t len = tr.end - tr.begin;
-    const int64_t n_chunks = (len + 63) >> 6;
-
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t pos = tr.begin + (REV ? (n_chunks - 1 - c) : c) * 64;
-        const int64_t i = pos + lane;
-        const bool active = i < tr.end;
-        int64_t key = 0;
-        float v = ident;
-        if (active) {
-            key = keys[i];
-            v = in[i];
-            if (mul) v *= mul[i];
+    auto load = [&](int64_t i0) {
+        ScanIn<E> p;
+        ld_vec<E>(in, i0, n, ident, p.v);
+        if (mul) ld_vec<E>(mul, i0, n, 1.0f, p.m);
+        if (div) ld_vec<E>(div, i0, n, 1.0f, p.d);
+        return p;
+    };
+    auto values = [&](const bool (&act)[E], const ScanIn<E> &p, float (&v)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = act[e] ? (mul ? p.v[e] * p.m[e] : p.v[e]) : ident;
+    };
+    auto store = [&](int64_t i0, const bool (&act)[E], const float (&incl)[E], const float (&excl)[E], const ScanIn<E> &p) {
+        float r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            r[e] = INCL ? incl[e] : excl[e];
+            if (div) r[e] = r[e] / fmaxf(p.d[e], 1e-10f);
         }
-        float incl, excl;
-        if (!REV) {
-            int64_t pk = lane_prev_i64(key);
-            bool head = !active || key != pk;
-            if (lane == 0) head = (c == 0) || key != edge_key;
-            const unsigned long long heads = __ballot(head);
-            bool open;
-            const int dist = dist_to_head(heads, lane, open);
-            incl = wave_seg_scan_fwd<Op>(v, dist);
-            if (open) incl = Op::apply(carry, incl);
-            excl = lane_prev_f(incl, 0.0f);
-            if (head) excl = ident;
-            else if (lane == 0) excl = carry;
-            carry = readlane_f<63>(incl);
-            edge_key = readlane_i64<63>(key);
-        } else {
-            int64_t nk = lane_next_i64(key);
-            bool tail = !active || (i + 1 >= tr.end) || key != nk;
-            if (lane == 63 && active && i + 1 < tr.end) tail = key != edge_key;
-            const unsigned long long tails = __ballot(tail);
-            bool open;
-            const int dist = dist_to_tail(tails, lane, open);
-            incl = wave_seg_scan_bwd<Op>(v, dist);
-            if (open) incl = Op::apply(incl, carry);
-            excl = lane_next_f(incl, 0.0f);
-            if (tail) excl = ident;
-            else if (lane == 63) excl = carry;
-            carry = readlane_f<0>(incl);
-            edge_key = readlane_i64<0>(key);
-        }
-        if (active) {
-            float r = INCL ? incl : excl;
-            if (div) r = r / fmaxf(div[i], 1e-10f);
-            out[i] = r;
-        }
+        st_vec<E>(out, i0, act, r);
+    };
+    if (!REV) {
+        walk_rays_fwd<E, 1, ScanIn<E>>(keys, n, w, tile, spec, load,
+            [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const ScanIn<E> &p) {
+                float v[E], incl[E], excl[E];
+                values(act, p, v);
+                seg_scan_fwd<Op, E>(v, s, carry, incl, excl);
+                store(i0, act, incl, excl, p);
+            },
+            [](int64_t) {});
+    } else {
+        walk_rays_bwd<E, 1, ScanIn<E>>(keys, n, w, tile, spec, load,
+            [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegBwd<E> &s, const ScanIn<E> &p) {
+                float v[E], incl[E], excl[E];
+                values(act, p, v);
+                seg_scan_bwd<Op, E>(v, s, carry, incl, excl);
+                store(i0, act, incl, excl, p);
+            });
     }
 }
 
@@ -168,16 +154,20 @@ __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
     }
 }
 
+template <class Op, bool INCL, bool REV>
+void launch_keyed_dir(const int64_t *keys, const float *in, const float *mul, const float *div, float *out,
+                      int64_t n, const TilePlan &pl, hipStream_t s) {
+    const dim3 g(tile_blocks(n, pl.tile)), b(kBlock);
+    if (pl.e == 4) hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, REV, 4>), g, b, 0, s, keys, in, mul, div, out, n, pl.tile, pl.spec);
+    else if (pl.e == 2) hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, REV, 2>), g, b, 0, s, keys, in, mul, div, out, n, pl.tile, pl.spec);
+    else hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, REV, 1>), g, b, 0, s, keys, in, mul, div, out, n, pl.tile, pl.spec);
+}
 template <class Op, bool INCL>
 void launch_keyed(const int64_t *keys, const float *in, const float *mul, const float *div, float *out,
                   int64_t n, bool reverse, hipStream_t s) {
-    const int64_t tile = pick_tile(n);
-    const int64_t waves = ceil_div(n, tile);
-    const unsigned nb = (unsigned)ceil_div(waves, kWavesPerBlock);
-    if (reverse)
-        hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, true>), dim3(nb), dim3(kBlock), 0, s, keys, in, mul, div, out, n, tile);
-    else
-        hipLaunchKernelGGL((scan_keyed_kernel<Op, INCL, false>), dim3(nb), dim3(kBlock), 0, s, keys, in, mul, div, out, n, tile);
+    const TilePlan pl = pick_plan(n, aligned16({keys, in, mul, div, out}));
+    if (reverse) launch_keyed_dir<Op, INCL, true>(keys, in, mul, div, out, n, pl, s);
+    else launch_keyed_dir<Op, INCL, false>(keys, in, mul, div, out, n, pl, s);
 }
 
 template <class Op, bool INCL>

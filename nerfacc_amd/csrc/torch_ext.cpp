@@ -436,6 +436,15 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
 // traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
 // (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
 // test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
+// k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels take 4 elements per lane then)
+struct Rows {
+    Tensor buf;
+    int64_t pitch, n;
+    Rows(int64_t k, int64_t n_, const at::TensorOptions &o) : pitch((n_ + 3) & ~int64_t(3)), n(n_) { buf = at::empty({k, pitch}, o); }
+    float *p(int64_t r) const { return buf.data_ptr<float>() + r * pitch; }
+    Tensor row(int64_t r) const { return buf[r].narrow(0, 0, n); }
+};
+
 py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tensor &binaries, const Tensor &aabbs,
                          const OptTensor &near_planes, const OptTensor &far_planes, double step_size, double cone_angle,
                          const OptTensor &rays_mask, int64_t traverse_steps_limit, bool with_terminate_planes, double near_plane,
@@ -469,17 +478,17 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     wait_stream(s);
     const int64_t n = h[1], n_overflow = h[2];
     Tensor ray_indices = at::empty({n}, i64);
-    Tensor ts = at::empty({2, n}, f32);
+    Rows ts(2, n, f32);
     a.sm_ray_indices = ptr<int64_t>(ray_indices);
-    a.t_starts = ptr<float>(ts);
-    a.t_ends = ptr<float>(ts) + n;
+    a.t_starts = ts.p(0);
+    a.t_ends = ts.p(1);
     a.terminate_planes = nullptr;                     // written by the count pass only
     if (n > 0) {
         Timed t("traverse_fill", s);
         check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n, n_overflow, s));
     }
-    if (with_terminate_planes) return py::make_tuple(ray_indices, ts[0], ts[1], packed.t(), term);
-    return py::make_tuple(ray_indices, ts[0], ts[1], packed.t());
+    if (with_terminate_planes) return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t(), term);
+    return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t());
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -591,12 +600,11 @@ py::tuple render_weight_from_density_fwd(const Tensor &ray_indices, const Tensor
     check_input(sigmas, "sigmas", at::kFloat);
     if (prefix_trans) check_input(*prefix_trans, "prefix_trans", at::kFloat);
     const int64_t n = sigmas.size(0);
-    Tensor out = at::empty({3, n}, sigmas.options());
+    Rows out(3, n, sigmas.options());
     Guard g(device_of(sigmas));
     check_rc(nfa_render_weight_from_density_fwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas),
-                                                ptr<float>(prefix_trans), n, ptr<float>(out), ptr<float>(out) + n, ptr<float>(out) + 2 * n,
-                                                stream_of(sigmas)));
-    return py::make_tuple(out[0], out[1], out[2]);
+                                                ptr<float>(prefix_trans), n, out.p(0), out.p(1), out.p(2), stream_of(sigmas)));
+    return py::make_tuple(out.row(0), out.row(1), out.row(2));
 }
 
 Tensor render_weight_from_density_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
@@ -639,7 +647,7 @@ py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, 
     check_input(dens, "sigmas/alphas", at::kFloat);
     const int64_t n = dens.size(0);
     Tensor o_idx = at::empty({n}, ray_indices.options());
-    Tensor o_t = at::empty({2, n}, dens.options());
+    Rows o_t(2, n, dens.options());
     Tensor mask;
     if (want_mask) mask = at::empty({n}, opts(dens, at::kBool));
     Tensor ws = at::empty({std::max<int64_t>(nfa_visibility_workspace_bytes(n), 16)}, opts(dens, at::kByte));
@@ -649,13 +657,13 @@ py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, 
     {
         Timed t("visibility", s);
         check_rc(nfa_visibility_compact(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha, n,
-                                        (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), ptr<float>(o_t), ptr<float>(o_t) + n,
+                                        (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
                                         ptr<uint8_t>(mask), h, ws.data_ptr(), s));
     }
     wait_stream(s);
     const int64_t k = n > 0 ? h[0] : 0;
     py::object m = want_mask ? py::cast(mask) : py::none();
-    return py::make_tuple(o_idx.narrow(0, 0, k), o_t[0].narrow(0, 0, k), o_t[1].narrow(0, 0, k), m);
+    return py::make_tuple(o_idx.narrow(0, 0, k), o_t.row(0).narrow(0, 0, k), o_t.row(1).narrow(0, 0, k), m);
 }
 
 Tensor accumulate_along_rays(const Tensor &ray_indices, const Tensor &weights, const OptTensor &values, int64_t n_rays, const OptTensor &outputs) {
@@ -694,7 +702,7 @@ py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const
     check_input(rgbs, "rgbs", at::kFloat);
     if (bkgd) { check_input(*bkgd, "render_bkgd", at::kFloat); TORCH_CHECK(bkgd->numel() == 3, "render_bkgd must hold 3 floats"); }
     const int64_t n = sigmas.size(0);
-    Tensor per = at::empty({3, n}, sigmas.options());
+    Rows per(3, n, sigmas.options());
     Tensor colors = at::empty({n_rays, 3}, sigmas.options());
     Tensor od = at::empty({2, n_rays, 1}, sigmas.options());
     Guard g(device_of(sigmas));
@@ -702,10 +710,10 @@ py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const
     {
         Timed t("rendering_fwd", s);
         check_rc(nfa_rendering_fwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas), ptr<float>(rgbs), n,
-                                   n_rays, ptr<float>(bkgd), expected_depths, ptr<float>(per), ptr<float>(per) + n, ptr<float>(per) + 2 * n,
+                                   n_rays, ptr<float>(bkgd), expected_depths, per.p(0), per.p(1), per.p(2),
                                    ptr<float>(colors), ptr<float>(od), ptr<float>(od) + n_rays, s));
     }
-    return py::make_tuple(colors, od[0], od[1], per[0], per[1], per[2]);
+    return py::make_tuple(colors, od[0], od[1], per.row(0), per.row(1), per.row(2));
 }
 
 py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,

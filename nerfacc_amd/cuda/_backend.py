@@ -409,6 +409,13 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     return a
 
 
+def _rows(k: int, n: int, device) -> torch.Tensor:
+    """k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels then take
+    4 elements per lane); rows are x[i] (1-D, contiguous)."""
+    pitch = (n + 3) & ~3
+    return torch.empty((k, pitch), dtype=torch.float32, device=device)[:, :n]
+
+
 class _CtypesC:
     """ctypes face of the C ABI with the names of the reference's compiled module (the fallback backend:
     `NERFACC_AMD_BACKEND=ctypes`, or when the torch extension nerfacc_amd/_hip*.so is not built)."""
@@ -704,7 +711,7 @@ class _CtypesC:
             _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
             _, n, n_overflow, _ = _read_ints(totals, dev)
             ray_indices = torch.empty(n, **i64)
-            ts = torch.empty((2, n), dtype=torch.float32, device=dev)
+            ts = _rows(2, n, dev)
             a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
             a.terminate_planes = None                    # written by the count pass only
             if n > 0:
@@ -739,7 +746,7 @@ class _CtypesC:
         if prefix_trans is not None:
             _check_input(prefix_trans, "prefix_trans", torch.float32)
         n = sigmas.shape[0]
-        out = torch.empty((3, n), dtype=torch.float32, device=sigmas.device)
+        out = _rows(3, n, sigmas.device)
         with _Guard(sigmas):
             _check(load_library().nfa_render_weight_from_density_fwd(
                 _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(sigmas), _ptr(prefix_trans), n,
@@ -789,7 +796,7 @@ class _CtypesC:
         n = dens.shape[0]
         dev = dens.device
         o_idx = torch.empty(n, dtype=torch.int64, device=dev)
-        o_t = torch.empty((2, n), dtype=torch.float32, device=dev)
+        o_t = _rows(2, n, dev)
         mask = torch.empty(n, dtype=torch.bool, device=dev) if want_mask else None
         n_out = _host_ints(dev)
         ws = torch.empty(max(L.nfa_visibility_workspace_bytes(n), 16), dtype=torch.uint8, device=dev)
@@ -917,7 +924,7 @@ class _CtypesC:
             _check_input(bkgd, "render_bkgd", torch.float32)
         n = sigmas.shape[0]
         dev = sigmas.device
-        per_sample = torch.empty((3, n), dtype=torch.float32, device=dev)
+        per_sample = _rows(3, n, dev)
         colors = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
         od = torch.empty((2, n_rays, 1), dtype=torch.float32, device=dev)
         with _Guard(sigmas):

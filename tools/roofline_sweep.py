@@ -18,6 +18,9 @@ logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 g = torch.Generator(device=dev).manual_seed(42)
 R = (1 << logn) // 96
 cnts = torch.randint(0, 193, (R,), device=dev, generator=g)
+if os.environ.get("NFA_SWEEP_CNT"):                    # constant ray length (alignment experiments)
+    R = (1 << logn) // int(os.environ["NFA_SWEEP_CNT"])
+    cnts = torch.full((R,), int(os.environ["NFA_SWEEP_CNT"]), device=dev)
 ri = torch.repeat_interleave(torch.arange(R, device=dev), cnts)
 N = ri.shape[0]
 pk = torch.stack([torch.cumsum(cnts, 0) - cnts, cnts], -1)
