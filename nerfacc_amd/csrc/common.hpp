@@ -219,6 +219,9 @@ __device__ __forceinline__ int dist_to_tail(unsigned long long tails, int lane, 
 // everything it knows and calls `flush(key)` at the start of the next chunk when that element turns out to have
 // ended its ray (the kernel's carries then hold the ray's totals).
 // ----------------------------------------------------------------------------------------
+#ifndef NFA_PF
+#define NFA_PF 1      // chunks requested ahead by the tiled walkers (tuning knob)
+#endif
 struct NoPayload {};
 
 template <int E, class P>

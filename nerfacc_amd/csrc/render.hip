@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
     float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ alphas)
 {
     float carry = 0.0f;
-    walk_rays_fwd<E, 1, WeightFwdIn<E>>(keys, n, wave_index(), tile, spec,
+    walk_rays_fwd<E, NFA_PF, WeightFwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             WeightFwdIn<E> p;
             ld_vec<E>(ts, i0, n, 0.0f, p.t0);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void weight_bwd_kernel(
     int64_t n, int64_t tile, int spec, float *__restrict__ g_sigmas)
 {
     float carry = 0.0f;
-    walk_rays_bwd<E, 1, WeightBwdIn<E>>(keys, n, wave_index(), tile, spec,
+    walk_rays_bwd<E, NFA_PF, WeightBwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             WeightBwdIn<E> p;
             ld_vec<E>(trans, i0, n, 0.0f, p.T);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     int64_t kept = 0, rb = 0, re = 0;
     bool first = true;
     float carry = from_alpha ? 1.0f : 0.0f;
-    walk_rays_fwd<E, 1, VisIn<E>>(keys, n, w, tile, spec,
+    walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, spec,
         [&](int64_t i0) {
             VisIn<E> p;
             ld_vec<E>(dens, i0, n, 0.0f, p.d);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
         opac[key] = sw;
         depth[key] = expected_depths ? sm / fmaxf(sw, kEpsF32) : sm;
     };
-    walk_rays_fwd<E, 1, RenderFwdIn<E>>(keys, n, wave_index(), tile, spec,
+    walk_rays_fwd<E, NFA_PF, RenderFwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             RenderFwdIn<E> p;
             ld_vec<E>(ts, i0, n, 0.0f, p.t0);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     float carry = 0.0f;
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
-    walk_rays_bwd<E, 1, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
+    walk_rays_bwd<E, NFA_PF, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             RenderBwdIn<E> p;
             ld_vec<E>(weights, i0, n, 0.0f, p.w);

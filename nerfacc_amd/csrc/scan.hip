@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
         st_vec<E>(out, i0, act, r);
     };
     if (!REV) {
-        walk_rays_fwd<E, 1, ScanIn<E>>(keys, n, w, tile, spec, load,
+        walk_rays_fwd<E, NFA_PF, ScanIn<E>>(keys, n, w, tile, spec, load,
             [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const ScanIn<E> &p) {
                 float v[E], incl[E], excl[E];
                 values(act, p, v);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
             },
             [](int64_t) {});
     } else {
-        walk_rays_bwd<E, 1, ScanIn<E>>(keys, n, w, tile, spec, load,
+        walk_rays_bwd<E, NFA_PF, ScanIn<E>>(keys, n, w, tile, spec, load,
             [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegBwd<E> &s, const ScanIn<E> &p) {
                 float v[E], incl[E], excl[E];
                 values(act, p, v);

@@ -1,0 +1,63 @@
+"""The tiled streaming kernels (common.hpp: walk_rays_fwd / walk_rays_bwd) under every launch plan: 1 / 2 / 4 elements
+per lane, one-chunk and multi-chunk tiles, unaligned views (fall back to one element per lane).  The default plans only
+reach E = 4 at N >= 2^22; the NFA_E / NFA_TILE knobs (read per call) force the others onto the small oracle-checked cases."""
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_scan
+import test_gpu_volrend
+from gpu_utils import DEV, n, ragged, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("e,tile", [(1, 64), (1, 192), (2, 128), (2, 384), (4, 256), (4, 768)])
+def test_every_plan_vs_oracle(monkeypatch, e, tile):
+    monkeypatch.setenv("NFA_E", str(e))
+    monkeypatch.setenv("NFA_TILE", str(tile))
+    for args in ((7, 5, 1), (500, 90, 2), (3000, 700, 3), (3, 5000, 4), (20000, 12, 5)):
+        test_gpu_volrend.test_ragged_vs_oracle_fwd_bwd(*args)
+    for args in ((9, 3, 1), (700, 150, 2), (5, 3000, 3), (20000, 9, 4)):
+        test_gpu_scan.test_ragged_vs_oracle(*args)
+    for r in (50, 5000):
+        test_gpu_volrend.test_visibility_compact_all_prefix_modes(r)
+    test_gpu_volrend.test_accumulate_unsorted_ray_indices_like_index_add()
+    test_gpu_volrend.test_accumulate_backward_and_inplace()
+
+
+@pytest.mark.parametrize("e", [2, 4])
+def test_large_n_properties_vectorised(monkeypatch, e):
+    monkeypatch.setenv("NFA_E", str(e))
+    test_gpu_volrend.test_large_n_properties()
+
+
+def test_unaligned_views_equal_aligned(monkeypatch):
+    """views whose storage offset is not a multiple of 16 bytes take the one-element plan: same results"""
+    from nerfacc_amd import cuda as C
+
+    monkeypatch.setenv("NFA_E", "4")
+    rng = np.random.default_rng(0)
+    ri_, _ = ragged(rng, 4000, 60)
+    N = ri_.shape[0]
+    base = {k: torch.rand(N + 1, device=DEV) for k in ("ts", "dt", "sig")}
+    ts, dt, sig = (base[k][1:] for k in ("ts", "dt", "sig"))           # 4-byte offset
+    assert ts.data_ptr() % 16 != 0
+    ri = t(ri_)
+    te = ts + dt * 0.01
+    te_al, ts_al, sig_al = te.clone(), ts.clone(), (sig * 30).clone()
+    sig_un = torch.empty(N + 1, device=DEV)[1:]
+    sig_un.copy_(sig_al)
+    te_un = torch.empty(N + 1, device=DEV)[1:]
+    te_un.copy_(te_al)
+    a = C.render_weight_from_density_fwd(ri, ts_al, te_al, sig_al, None)
+    b = C.render_weight_from_density_fwd(ri, ts, te_un, sig_un, None)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-6)
+    rgb = torch.rand(N, 3, device=DEV)
+    ra = C.rendering_fwd(ri, ts_al, te_al, sig_al, rgb, 4000, None, True)
+    rb = C.rendering_fwd(ri, ts, te_un, sig_un, rgb, 4000, None, True)
+    for x, y in zip(ra, rb):
+        assert torch.allclose(x, y, atol=1e-5)
+    assert torch.allclose(C.exclusive_sum_cub(ri, sig_al, False), C.exclusive_sum_cub(ri, sig_un, False), atol=1e-3, rtol=1e-5)
+    assert np.isfinite(n(rb[0])).all()
