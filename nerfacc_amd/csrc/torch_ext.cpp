@@ -44,6 +44,16 @@ inline void check_input(const Tensor &t, const char *name, std::optional<at::Sca
     if (dtype) TORCH_CHECK(t.scalar_type() == *dtype, name, " must have dtype ", *dtype, ", got ", t.scalar_type());
 }
 
+// 1-D (or [n, inner]) tensor of the given dtype with exactly n leading elements, on the reference tensor's device
+inline void check_len(const Tensor &t, const char *name, at::ScalarType dtype, int64_t n, const Tensor &like, int64_t inner = 1) {
+    check_input(t, name, dtype);
+    TORCH_CHECK(t.numel() == n * inner, name, " must have ", n * inner, " elements, got ", t.numel());
+    TORCH_CHECK(t.device() == like.device(), name, " is on ", t.device(), ", expected ", like.device());
+}
+inline void check_len(const OptTensor &t, const char *name, at::ScalarType dtype, int64_t n, const Tensor &like, int64_t inner = 1) {
+    if (t) check_len(*t, name, dtype, n, like, inner);
+}
+
 template <class T> inline T *ptr(const Tensor &t) { return t.defined() ? reinterpret_cast<T *>(t.data_ptr()) : nullptr; }
 template <class T> inline T *ptr(const OptTensor &t) { return (t && t->defined()) ? reinterpret_cast<T *>(t->data_ptr()) : nullptr; }
 
@@ -161,6 +171,7 @@ constexpr size_t kBrickSlots = 4;
 std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) {
     check_input(binaries, "binaries", at::kBool);
     TORCH_CHECK(binaries.dim() == 4, "binaries must have shape [n_grids, resx, resy, resz]");
+    Guard g(device_of(binaries));                       // events and the copy below belong to the tensor's device
     std::lock_guard<std::mutex> l(g_brick_mu);
     hipStream_t s = stream_of(binaries);
     c10::TensorImpl *impl = binaries.unsafeGetTensorImpl();
@@ -174,10 +185,7 @@ std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) 
         const int G = (int)binaries.size(0), rx = (int)binaries.size(1), ry = (int)binaries.size(2), rz = (int)binaries.size(3);
         const int64_t words = nfa_packed_grid_words(G, rx, ry, rz);
         Tensor bricks = at::empty({words}, opts(binaries, at::kLong));
-        {
-            Guard g(device_of(binaries));
-            check_rc(nfa_pack_binaries(ptr<uint8_t>(binaries), G, rx, ry, rz, ptr<uint64_t>(bricks), s));
-        }
+        check_rc(nfa_pack_binaries(ptr<uint8_t>(binaries), G, rx, ry, rz, ptr<uint64_t>(bricks), s));
         hipEvent_t ev;
         hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         hipEventRecord(ev, s);
@@ -206,7 +214,9 @@ std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) 
         int64_t hdr[9];
         TORCH_CHECK(hipMemcpyAsync(hdr, ptr<int64_t>(c.bricks) + nb, sizeof(hdr), hipMemcpyDeviceToHost, s) == hipSuccess,
                     "nerfacc_amd: readback of the packed-grid header failed");
-        wait_stream(s);
+        // (the GIL stays held: releasing it while holding g_brick_mu would let another Python thread block on the mutex
+        // with the GIL, and this thread could then never take the GIL back.  Once per grid state, ~20 us.)
+        TORCH_CHECK(hipStreamSynchronize(s) == hipSuccess, "nerfacc_amd: hipStreamSynchronize failed");
         c.nonempty = hdr[0];
         for (int g = 0; g < 8; ++g) c.level_counts[g] = hdr[1 + g];
     }
@@ -309,6 +319,8 @@ nfa_traverse_args traverse_args(const Tensor &rays_o, const Tensor &rays_d, cons
     per_ray(t_max, "t_max");
     per_ray(jitter, "jitter");
     TORCH_CHECK(rays_o.dim() == 2 && rays_o.size(1) == 3 && rays_d.sizes() == rays_o.sizes(), "rays_o / rays_d must have shape [n_rays, 3]");
+    TORCH_CHECK(rays_d.device() == rays_o.device() && binaries.device() == rays_o.device() && aabbs.device() == rays_o.device(),
+                "rays_o, rays_d, binaries and aabbs must live on the same device");
     TORCH_CHECK(aabbs.dim() == 2 && aabbs.size(0) == G && aabbs.size(1) == 6, "aabbs must have shape [n_grids, 6]");
     nfa_traverse_args a{};
     a.near_plane = (float)near_plane;
@@ -433,9 +445,6 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
     return {intervals, samples, terminate};
 }
 
-// traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
-// (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
-// test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
 // k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels take 4 elements per lane then)
 struct Rows {
     Tensor buf;
@@ -445,6 +454,9 @@ struct Rows {
     Tensor row(int64_t r) const { return buf[r].narrow(0, 0, n); }
 };
 
+// traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
+// (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
+// test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
 py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tensor &binaries, const Tensor &aabbs,
                          const OptTensor &near_planes, const OptTensor &far_planes, double step_size, double cone_angle,
                          const OptTensor &rays_mask, int64_t traverse_steps_limit, bool with_terminate_planes, double near_plane,
@@ -512,6 +524,7 @@ Tensor scan_keyed(const Tensor &indices, const Tensor &inputs, int op, bool incl
     check_input(indices, "indices", at::kLong);
     check_input(inputs, "inputs", at::kFloat);
     TORCH_CHECK(indices.dim() == 1 && inputs.dim() == 1 && indices.size(0) == inputs.size(0), "indices and inputs must be 1-D with the same length");
+    TORCH_CHECK(indices.device() == inputs.device(), "indices and inputs must live on the same device");
     Tensor out = at::empty_like(inputs);
     Guard g(device_of(inputs));
     check_rc(nfa_scan_keyed(ptr<int64_t>(indices), ptr<float>(inputs), ptr<float>(out), inputs.size(0), op, inclusive, reverse, stream_of(inputs)));
@@ -520,12 +533,15 @@ Tensor scan_keyed(const Tensor &indices, const Tensor &inputs, int op, bool incl
 
 Tensor prod_bwd(const OptTensor &indices, const OptTensor &chunk_starts, const OptTensor &chunk_cnts, const Tensor &inputs,
                 const Tensor &outputs, const Tensor &grad_outputs, bool inclusive) {
-    if (indices) check_input(*indices, "indices", at::kLong);
+    check_input(inputs, "inputs", at::kFloat);
+    const int64_t n = inputs.numel();
+    check_len(indices, "indices", at::kLong, n, inputs);
     if (chunk_starts) check_input(*chunk_starts, "chunk_starts", at::kLong);
     if (chunk_cnts) check_input(*chunk_cnts, "chunk_cnts", at::kLong);
-    check_input(inputs, "inputs", at::kFloat);
-    check_input(outputs, "outputs", at::kFloat);
-    check_input(grad_outputs, "grad_outputs", at::kFloat);
+    TORCH_CHECK(chunk_starts.has_value() == chunk_cnts.has_value() && (!chunk_starts || chunk_starts->numel() == chunk_cnts->numel()),
+                "chunk_starts and chunk_cnts must be given together with the same length");
+    check_len(outputs, "outputs", at::kFloat, n, inputs);
+    check_len(grad_outputs, "grad_outputs", at::kFloat, n, inputs);
     Tensor gin = at::empty_like(grad_outputs);
     Guard g(device_of(inputs));
     check_rc(nfa_prod_backward(ptr<int64_t>(indices), ptr<int64_t>(chunk_starts), ptr<int64_t>(chunk_cnts), chunk_cnts ? chunk_cnts->size(0) : 0,
@@ -577,6 +593,7 @@ std::vector<Tensor> searchsorted(const RaySegmentsSpec &query, const RaySegments
 // ---------------------------------------------------------------------------------------------------
 Tensor pack_info(const Tensor &ray_indices, int64_t n_rays) {
     check_input(ray_indices, "ray_indices", at::kLong);
+    TORCH_CHECK(n_rays >= 0, "n_rays must be >= 0");
     Tensor out = at::empty({n_rays, 2}, ray_indices.options());
     Guard g(device_of(ray_indices));
     check_rc(nfa_pack_info(ptr<int64_t>(ray_indices), ray_indices.size(0), n_rays, ptr<int64_t>(out), stream_of(ray_indices)));
@@ -586,6 +603,7 @@ Tensor pack_info(const Tensor &ray_indices, int64_t n_rays) {
 Tensor unpack_info(const Tensor &chunk_starts, const Tensor &chunk_cnts, int64_t n) {
     check_input(chunk_starts, "chunk_starts", at::kLong);
     check_input(chunk_cnts, "chunk_cnts", at::kLong);
+    TORCH_CHECK(chunk_starts.numel() == chunk_cnts.numel() && n >= 0, "chunk_starts and chunk_cnts differ in length (or n < 0)");
     Tensor out = at::empty({n}, chunk_starts.options());
     Guard g(device_of(chunk_starts));
     check_rc(nfa_unpack_info(ptr<int64_t>(chunk_starts), ptr<int64_t>(chunk_cnts), chunk_cnts.size(0), ptr<int64_t>(out), n, stream_of(chunk_starts)));
@@ -594,12 +612,12 @@ Tensor unpack_info(const Tensor &chunk_starts, const Tensor &chunk_cnts, int64_t
 
 py::tuple render_weight_from_density_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
                                          const OptTensor &prefix_trans) {
-    check_input(ray_indices, "ray_indices", at::kLong);
-    check_input(t_starts, "t_starts", at::kFloat);
-    check_input(t_ends, "t_ends", at::kFloat);
     check_input(sigmas, "sigmas", at::kFloat);
-    if (prefix_trans) check_input(*prefix_trans, "prefix_trans", at::kFloat);
-    const int64_t n = sigmas.size(0);
+    const int64_t n = sigmas.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
+    check_len(t_starts, "t_starts", at::kFloat, n, sigmas);
+    check_len(t_ends, "t_ends", at::kFloat, n, sigmas);
+    check_len(prefix_trans, "prefix_trans", at::kFloat, n, sigmas);
     Rows out(3, n, sigmas.options());
     Guard g(device_of(sigmas));
     check_rc(nfa_render_weight_from_density_fwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas),
@@ -609,8 +627,14 @@ py::tuple render_weight_from_density_fwd(const Tensor &ray_indices, const Tensor
 
 Tensor render_weight_from_density_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
                                       const Tensor &trans, const Tensor &alphas, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a) {
-    for (auto *t : {&g_w, &g_T, &g_a})
-        if (*t) check_input(**t, "grad", at::kFloat);
+    check_input(sigmas, "sigmas", at::kFloat);
+    const int64_t n = sigmas.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
+    check_len(t_starts, "t_starts", at::kFloat, n, sigmas);
+    check_len(t_ends, "t_ends", at::kFloat, n, sigmas);
+    check_len(trans, "trans", at::kFloat, n, sigmas);
+    check_len(alphas, "alphas", at::kFloat, n, sigmas);
+    for (auto *t : {&g_w, &g_T, &g_a}) check_len(*t, "grad", at::kFloat, n, sigmas);
     Tensor gs = at::empty_like(sigmas);
     Guard g(device_of(sigmas));
     check_rc(nfa_render_weight_from_density_bwd(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(sigmas),
@@ -641,11 +665,11 @@ py::object sample_positions(const Tensor &rays_o, const Tensor &rays_d, const Te
 // (ray_indices', t_starts', t_ends', mask or None); ONE host sync (the count)
 py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &dens, bool from_alpha,
                              double early_stop_eps, double alpha_thre, bool want_mask) {
-    check_input(ray_indices, "ray_indices", at::kLong);
-    check_input(t_starts, "t_starts", at::kFloat);
-    check_input(t_ends, "t_ends", at::kFloat);
     check_input(dens, "sigmas/alphas", at::kFloat);
-    const int64_t n = dens.size(0);
+    const int64_t n = dens.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, dens);
+    check_len(t_starts, "t_starts", at::kFloat, n, dens);
+    check_len(t_ends, "t_ends", at::kFloat, n, dens);
     Tensor o_idx = at::empty({n}, ray_indices.options());
     Rows o_t(2, n, dens.options());
     Tensor mask;
@@ -667,13 +691,24 @@ py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, 
 }
 
 Tensor accumulate_along_rays(const Tensor &ray_indices, const Tensor &weights, const OptTensor &values, int64_t n_rays, const OptTensor &outputs) {
-    check_input(ray_indices, "ray_indices", at::kLong);
     check_input(weights, "weights", at::kFloat);
+    const int64_t n = weights.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, weights);
     int64_t D = 1;
-    if (values) { check_input(*values, "values", at::kFloat); D = values->size(-1); }
+    if (values) {
+        TORCH_CHECK(values->dim() >= 1, "values must be [n_samples, D]");
+        D = values->size(-1);
+        check_len(*values, "values", at::kFloat, n, weights, D);
+    }
     Tensor out;
-    if (outputs) { check_input(*outputs, "outputs", at::kFloat); out = *outputs; }
-    else out = at::zeros({n_rays, D}, weights.options());
+    if (outputs) {
+        check_input(*outputs, "outputs", at::kFloat);
+        TORCH_CHECK(outputs->dim() == 2 && outputs->size(1) == D && outputs->device() == weights.device(), "outputs must be [n_rays, ", D, "] on the inputs' device");
+        out = *outputs;
+    } else {
+        TORCH_CHECK(n_rays >= 0, "n_rays must be >= 0");
+        out = at::zeros({n_rays, D}, weights.options());
+    }
     Guard g(device_of(weights));
     check_rc(nfa_accumulate_along_rays(ptr<int64_t>(ray_indices), ptr<float>(weights), ptr<float>(values), weights.size(0), (int32_t)D,
                                        out.size(0), ptr<float>(out), stream_of(weights)));
@@ -683,7 +718,13 @@ Tensor accumulate_along_rays(const Tensor &ray_indices, const Tensor &weights, c
 py::tuple accumulate_along_rays_bwd(const Tensor &ray_indices, const Tensor &weights, const OptTensor &values, const Tensor &g_out, bool need_w,
                                     bool need_v) {
     check_input(g_out, "g_outputs", at::kFloat);
-    const int64_t D = g_out.size(-1);
+    check_input(weights, "weights", at::kFloat);
+    TORCH_CHECK(g_out.dim() == 2, "g_outputs must be [n_rays, D]");
+    const int64_t D = g_out.size(-1), n = weights.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, weights);
+    check_len(values, "values", at::kFloat, n, weights, D);
+    TORCH_CHECK(values.has_value() || D == 1, "g_outputs must be [n_rays, 1] when values is None");
+    TORCH_CHECK(g_out.device() == weights.device(), "g_outputs must live on the inputs' device");
     Tensor g_w, g_v;
     if (need_w) g_w = at::empty_like(weights);
     if (need_v && values) g_v = at::empty_like(*values);
@@ -695,13 +736,14 @@ py::tuple accumulate_along_rays_bwd(const Tensor &ray_indices, const Tensor &wei
 
 py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
                         int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
-    check_input(ray_indices, "ray_indices", at::kLong);
-    check_input(t_starts, "t_starts", at::kFloat);
-    check_input(t_ends, "t_ends", at::kFloat);
     check_input(sigmas, "sigmas", at::kFloat);
-    check_input(rgbs, "rgbs", at::kFloat);
-    if (bkgd) { check_input(*bkgd, "render_bkgd", at::kFloat); TORCH_CHECK(bkgd->numel() == 3, "render_bkgd must hold 3 floats"); }
-    const int64_t n = sigmas.size(0);
+    const int64_t n = sigmas.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
+    check_len(t_starts, "t_starts", at::kFloat, n, sigmas);
+    check_len(t_ends, "t_ends", at::kFloat, n, sigmas);
+    check_len(rgbs, "rgbs", at::kFloat, n, sigmas, 3);
+    check_len(bkgd, "render_bkgd", at::kFloat, 1, sigmas, 3);
+    TORCH_CHECK(n_rays >= 0, "n_rays must be >= 0");
     Rows per(3, n, sigmas.options());
     Tensor colors = at::empty({n_rays, 3}, sigmas.options());
     Tensor od = at::empty({2, n_rays, 1}, sigmas.options());
@@ -720,8 +762,22 @@ py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const
                         const Tensor &weights, const Tensor &trans, const Tensor &alphas, const Tensor &opacities, const Tensor &depths,
                         int64_t n_rays, const OptTensor &bkgd, bool expected_depths, const OptTensor &g_colors, const OptTensor &g_opac,
                         const OptTensor &g_depth, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a, bool need_sigma, bool need_rgb) {
-    for (auto *t : {&g_colors, &g_opac, &g_depth, &g_w, &g_T, &g_a})
-        if (*t) check_input(**t, "grad", at::kFloat);
+    check_input(sigmas, "sigmas", at::kFloat);
+    const int64_t n = sigmas.numel();
+    check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
+    check_len(t_starts, "t_starts", at::kFloat, n, sigmas);
+    check_len(t_ends, "t_ends", at::kFloat, n, sigmas);
+    check_len(rgbs, "rgbs", at::kFloat, n, sigmas, 3);
+    check_len(weights, "weights", at::kFloat, n, sigmas);
+    check_len(trans, "trans", at::kFloat, n, sigmas);
+    check_len(alphas, "alphas", at::kFloat, n, sigmas);
+    check_len(opacities, "opacities", at::kFloat, n_rays, sigmas);
+    check_len(depths, "depths", at::kFloat, n_rays, sigmas);
+    check_len(bkgd, "render_bkgd", at::kFloat, 1, sigmas, 3);
+    check_len(g_colors, "g_colors", at::kFloat, n_rays, sigmas, 3);
+    check_len(g_opac, "g_opacities", at::kFloat, n_rays, sigmas);
+    check_len(g_depth, "g_depths", at::kFloat, n_rays, sigmas);
+    for (auto *t : {&g_w, &g_T, &g_a}) check_len(*t, "grad", at::kFloat, n, sigmas);
     Tensor g_sig, g_rgb;
     if (need_sigma) g_sig = at::empty_like(sigmas);
     if (need_rgb) g_rgb = at::empty_like(rgbs);

@@ -3,7 +3,7 @@
 Three input modes per function, as in the reference:
   * batched N-D tensor: plain torch.cumsum / cumprod along the last dim (differentiable);
   * flattened + `packed_info` [n_rays, 2]: chunked HIP scan (scan.hip, rows per quarter-wave);
-  * flattened + `indices` (ray index per element): keyed HIP scan (segment-snapped wave tiles).
+  * flattened + `indices` (ray index per element): keyed HIP scan (ray-owning wave tiles).
 Backward passes are the reversed scans the reference uses (scan.py:302-310, 400-404) and the
 fused product backward of scan.cu:199-210.
 """

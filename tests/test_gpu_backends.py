@@ -116,3 +116,31 @@ def test_kernel_timer_through_the_extension(faces):
         _backend.set_kernel_timer(None)
     assert summ["traverse_count"][0] == 3 and 0.0 < summ["traverse_count"][1] < 5.0
     assert summ["traverse_fill"][0] == 3
+
+
+def test_extension_rejects_mismatched_arguments(faces):
+    """lengths, dtypes and devices are checked on the host before any kernel sees a pointer (the reference's CHECK_INPUT
+    checks device + contiguity only, utils_cuda.cuh:12-17; a short tensor there is an out-of-bounds read)"""
+    ext, _ = faces
+    n = 1000
+    ri = torch.zeros(n, dtype=torch.int64, device=DEV)
+    f = torch.rand(n, device=DEV)
+    rgb = torch.rand(n, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="t_ends"):
+        ext.render_weight_from_density_fwd(ri, f, f[:-1].contiguous(), f, None)
+    with pytest.raises(RuntimeError, match="ray_indices"):
+        ext.render_weight_from_density_fwd(ri.int(), f, f, f, None)
+    with pytest.raises(RuntimeError, match="rgbs"):
+        ext.rendering_fwd(ri, f, f, f, rgb[:-1].contiguous(), 1, None, True)
+    with pytest.raises(RuntimeError, match="render_bkgd"):
+        ext.rendering_fwd(ri, f, f, f, rgb, 1, torch.ones(4, device=DEV), True)
+    with pytest.raises(RuntimeError, match="values"):
+        ext.accumulate_along_rays(ri, f, rgb[:-1].contiguous(), 1)
+    with pytest.raises(RuntimeError, match="outputs"):
+        ext.accumulate_along_rays(ri, f, rgb, 1, torch.zeros(1, 2, device=DEV))
+    with pytest.raises(RuntimeError, match="CUDA/HIP"):
+        ext.render_weight_from_density_fwd(ri.cpu(), f, f, f, None)
+    with pytest.raises(RuntimeError, match="t_starts"):
+        ext.visibility_compact(ri, f[:-1].contiguous(), f, f, False, 1e-4, 0.0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.exclusive_sum_cub(ri, torch.rand(n, 2, device=DEV)[:, 0], False)
