@@ -90,6 +90,11 @@ int nfa_grid_mark_invisible(float *occs, const int64_t *cell_ids, int64_t n, int
 int64_t nfa_grid_threshold_workspace_bytes(void);
 int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_thre, void *workspace,
                        uint8_t *binaries, float *threshold_out, void *stream);
+/* nfa_grid_threshold followed by nfa_pack_binaries, fused (the comparison pass writes the bool grid AND the bricks:
+ * four launches instead of five, and the bool grid is not read back).  occs: float[n_grids * rx * ry * rz];
+ * binaries: the same number of bytes; bricks: nfa_packed_grid_words(...) words; workspace as nfa_grid_threshold. */
+int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz, float occ_thre,
+                              void *workspace, uint8_t *binaries, float *threshold_out, uint64_t *bricks, void *stream);
 
 /* Arguments of traverse_grids (nerfacc.cpp:71-98, grid.cu:320-474).  The reference does
  * count -> cumsum + .item() -> allocate -> fill inside one C++ call; a C ABI cannot allocate

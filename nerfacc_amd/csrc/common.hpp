@@ -557,4 +557,26 @@ inline unsigned tile_blocks(int64_t n, int64_t tile) { return (unsigned)ceil_div
         else hipLaunchKernelGGL((KERNEL<1>), g_, b_, 0, stream, __VA_ARGS__);                                               \
     } while (0)
 
+
+// ----------------------------------------------------------------------------------------
+// occupancy threshold shared by occgrid.hip (nfa_grid_threshold) and grid.hip (nfa_grid_threshold_packed)
+// ----------------------------------------------------------------------------------------
+constexpr int kReduceBlocks = 128;
+// {sum, count} partial pairs of the visible cells -> min(mean, occ_thre) (NaN mean: nothing passes); fixed-order tree,
+// called by the first wave of a workgroup (all 64 lanes)
+__device__ __forceinline__ float threshold_from_partials(const double *__restrict__ partials, int n_partials, float occ_thre) {
+    const int l = lane_id();
+    double a = 0.0, b = 0.0;
+    if (l < n_partials) { a = partials[2 * l]; b = partials[2 * l + 1]; }
+    if (l + 64 < n_partials) { a += partials[2 * (l + 64)]; b += partials[2 * (l + 64) + 1]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    a = __shfl(a, 0, 64);
+    b = __shfl(b, 0, 64);
+    const float mean = b > 0.0 ? (float)(a / b) : __builtin_nanf("");
+    return (mean != mean) ? mean : fminf(mean, occ_thre);
+}
+// launches grid_mean_partials_kernel (occgrid.hip); returns the number of partial pairs written to `partials`
+int launch_grid_mean_partials(const float *occs, int64_t n_cells, double *partials, hipStream_t s);
+
 }  // namespace nfa

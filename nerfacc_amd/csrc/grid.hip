@@ -192,10 +192,28 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
 
 // one lane per brick: gather its 4x4x4 voxels (16 loads of 4 contiguous bytes along z); the
 // wave's ballot of "non-empty" is the coarse bitmap (two u32 words per wave).
+// FROM_OCCS: the voxels come from the float occupancies (`occs > min(mean, occ_thre)`, occ_grid.py:392-404) and the
+// bool grid is an OUTPUT — threshold and bit-pack in one pass (nfa_grid_threshold_packed).
+template <bool FROM_OCCS>
 __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
     const uint8_t *__restrict__ binaries, int n_grids, int rx, int ry, int rz,
-    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse, int64_t *__restrict__ level_counts)
+    int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse, int64_t *__restrict__ level_counts,
+    const float *__restrict__ occs, const double *__restrict__ partials, int n_partials, float occ_thre,
+    uint8_t *__restrict__ binaries_out, float *__restrict__ thre_out)
 {
+    float thre = 0.0f;
+    if (FROM_OCCS) {
+        __shared__ float s_thre;
+        if (threadIdx.x < 64) {
+            const float th = threshold_from_partials(partials, n_partials, occ_thre);
+            if (threadIdx.x == 0) {
+                s_thre = th;
+                if (blockIdx.x == 0 && thre_out) *thre_out = th;
+            }
+        }
+        __syncthreads();
+        thre = s_thre;
+    }
     const int64_t per_grid = (int64_t)nbx * nby * nbz;
     const int64_t total = per_grid * n_grids;
     const int64_t rounded = (total + 63) / 64 * 64;
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
             const int bx = (int)(rem / ((int64_t)nby * nbz));
             rem -= (int64_t)bx * nby * nbz;
             const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
-            const uint8_t *grid = binaries + g * (int64_t)rx * ry * rz;
+            const int64_t grid_off = g * (int64_t)rx * ry * rz;
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const int x = bx * 4 + dx;
@@ -216,10 +234,15 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
                 for (int dy = 0; dy < 4; ++dy) {
                     const int y = by * 4 + dy;
                     if (x >= rx || y >= ry) continue;
-                    const uint8_t *row = grid + ((int64_t)x * ry + y) * rz + bz * 4;
+                    const int64_t row = grid_off + ((int64_t)x * ry + y) * rz + bz * 4;
 #pragma unroll
-                    for (int dz = 0; dz < 4; ++dz)
-                        if (bz * 4 + dz < rz && row[dz]) bits |= 1ull << (dx * 16 + dy * 4 + dz);
+                    for (int dz = 0; dz < 4; ++dz) {
+                        if (bz * 4 + dz >= rz) continue;
+                        bool on;
+                        if (FROM_OCCS) { on = occs[row + dz] > thre; binaries_out[row + dz] = on ? 1 : 0; }
+                        else on = binaries[row + dz] != 0;
+                        if (on) bits |= 1ull << (dx * 16 + dy * 4 + dz);
+                    }
                 }
             }
             bricks[b] = bits;
@@ -1559,6 +1582,16 @@ NFA_EXPORT int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry
     return packed_layout(n_grids, rx, ry, rz).total_words;
 }
 
+static int rank_and_compact(uint64_t *bricks, const PackedLayout &L, hipStream_t s) {
+    uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
+    uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
+    hipLaunchKernelGGL(rank_bricks_kernel, dim3(1), dim3(1024), 0, s, coarse, L.n_words, prefix, (int64_t *)(bricks + L.off_header));
+    if (int rc = check_launch("rank_bricks_kernel")) return rc;
+    hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+                       bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
+    return check_launch("compact_bricks_kernel");
+}
+
 NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
                                  uint64_t *bricks, void *stream)
 {
@@ -1568,17 +1601,35 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
     NFA_REQUIRE(L.n_bricks < (1ll << 24), "pack_binaries: grid too large (more than 2^24 bricks)");
     hipStream_t s = (hipStream_t)stream;
     uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
-    uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
     int64_t *header = (int64_t *)(bricks + L.off_header);
     if (hipMemsetAsync(header, 0, 12 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "pack_binaries: memset failed");
-    hipLaunchKernelGGL(pack_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
-                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1);
+    hipLaunchKernelGGL(pack_bricks_kernel<false>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+                       binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
+                       (const float *)nullptr, (const double *)nullptr, 0, 0.0f, (uint8_t *)nullptr, (float *)nullptr);
     if (int rc = check_launch("pack_bricks_kernel")) return rc;
-    hipLaunchKernelGGL(rank_bricks_kernel, dim3(1), dim3(1024), 0, s, coarse, L.n_words, prefix, (int64_t *)(bricks + L.off_header));
-    if (int rc = check_launch("rank_bricks_kernel")) return rc;
-    hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
-                       bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
-    return check_launch("compact_bricks_kernel");
+    return rank_and_compact(bricks, L, s);
+}
+
+// nfa_grid_threshold + nfa_pack_binaries in four launches instead of five: the pass that compares the occupancies
+// with the threshold writes the bool grid AND the bricks (the bool grid is not read back)
+NFA_EXPORT int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz, float occ_thre,
+                                         void *workspace, uint8_t *binaries, float *threshold_out, uint64_t *bricks, void *stream)
+{
+    NFA_REQUIRE(n_grids > 0 && rx > 0 && ry > 0 && rz > 0, "grid_threshold_packed: empty grid");
+    NFA_REQUIRE(occs && workspace && binaries && bricks, "grid_threshold_packed: NULL pointer");
+    const PackedLayout L = packed_layout(n_grids, rx, ry, rz);
+    NFA_REQUIRE(L.n_bricks < (1ll << 24), "grid_threshold_packed: grid too large (more than 2^24 bricks)");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
+    int64_t *header = (int64_t *)(bricks + L.off_header);
+    if (hipMemsetAsync(header, 0, 12 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "grid_threshold_packed: memset failed");
+    const int64_t n_cells = (int64_t)n_grids * rx * ry * rz;
+    const int nb = launch_grid_mean_partials(occs, n_cells, (double *)workspace, s);
+    hipLaunchKernelGGL(pack_bricks_kernel<true>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+                       (const uint8_t *)nullptr, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
+                       occs, (const double *)workspace, nb, occ_thre, binaries, threshold_out);
+    if (int rc = check_launch("pack_bricks_kernel<occs>")) return rc;
+    return rank_and_compact(bricks, L, s);
 }
 
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(
 
 // sum and count of the visible cells (occs >= 0; invisible ones hold -1, :330-332); one
 // {sum, count} pair of doubles per workgroup, combined in a fixed order by the threshold kernel
-constexpr int kReduceBlocks = 128;
 __global__ __launch_bounds__(kBlock) void grid_mean_partials_kernel(const float *__restrict__ occs, int64_t n, double *__restrict__ partials)
 {
     __shared__ double s_sum[kWavesPerBlock], s_cnt[kWavesPerBlock];
@@ -88,16 +87,10 @@ __global__ __launch_bounds__(kBlock) void grid_threshold_kernel(
 {
     __shared__ float s_thre;
     if (threadIdx.x < 64) {                       // first wave: fixed-order tree over the <= 128 partial pairs
-        const int l = threadIdx.x;
-        double a = 0.0, b = 0.0;
-        if (l < n_partials) { a = partials[2 * l]; b = partials[2 * l + 1]; }
-        if (l + 64 < n_partials) { a += partials[2 * (l + 64)]; b += partials[2 * (l + 64) + 1]; }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-        if (l == 0) {
-            const float mean = b > 0.0 ? (float)(a / b) : __builtin_nanf("");
-            s_thre = (mean != mean) ? mean : fminf(mean, occ_thre);
-            if (blockIdx.x == 0 && thre_out) *thre_out = s_thre;
+        const float th = threshold_from_partials(partials, n_partials, occ_thre);
+        if (threadIdx.x == 0) {
+            s_thre = th;
+            if (blockIdx.x == 0 && thre_out) *thre_out = th;
         }
     }
     __syncthreads();
@@ -146,6 +139,15 @@ __global__ __launch_bounds__(kBlock) void grid_mark_invisible_kernel(
 }
 
 }  // namespace
+}  // namespace nfa
+
+namespace nfa {
+int launch_grid_mean_partials(const float *occs, int64_t n_cells, double *partials, hipStream_t s) {
+    int nb = (int)blocks_for(n_cells);
+    if (nb > kReduceBlocks) nb = kReduceBlocks;
+    hipLaunchKernelGGL(grid_mean_partials_kernel, dim3(nb), dim3(kBlock), 0, s, occs, n_cells, partials);
+    return nb;
+}
 }  // namespace nfa
 
 using namespace nfa;
@@ -199,9 +201,7 @@ NFA_EXPORT int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_
     if (n_cells == 0) return NFA_OK;
     NFA_REQUIRE(occs && workspace && binaries, "grid_threshold: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    int nb = (int)blocks_for(n_cells);
-    if (nb > kReduceBlocks) nb = kReduceBlocks;
-    hipLaunchKernelGGL(grid_mean_partials_kernel, dim3(nb), dim3(kBlock), 0, s, occs, n_cells, (double *)workspace);
+    const int nb = launch_grid_mean_partials(occs, n_cells, (double *)workspace, s);
     hipLaunchKernelGGL(grid_threshold_kernel, dim3(blocks_for(n_cells)), dim3(kBlock), 0, s, occs, n_cells,
                        (const double *)workspace, nb, occ_thre, binaries, threshold_out);
     return check_launch("grid_threshold");

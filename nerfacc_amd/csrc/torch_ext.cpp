@@ -167,6 +167,25 @@ std::mutex g_brick_mu;
 std::vector<BrickEntry> g_bricks;     // most recently used first
 constexpr size_t kBrickSlots = 4;
 
+// caller holds g_brick_mu: makes `bricks` (packed on stream s) the front entry for this state of `binaries`
+void insert_brick_entry(const Tensor &binaries, const Tensor &bricks, hipStream_t s) {
+    c10::TensorImpl *impl = binaries.unsafeGetTensorImpl();
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    hipEventRecord(ev, s);
+    // drop slots whose tensor is gone or is this tensor in an older state, then the oldest
+    std::vector<BrickEntry> keep;
+    for (auto &c : g_bricks) {
+        if (c.ref.expired() || c.impl == impl) { hipEventDestroy(c.event); continue; }
+        keep.push_back(std::move(c));
+    }
+    g_bricks = std::move(keep);
+    BrickEntry e{c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr()), impl, binaries._version(), bricks, -1,
+                 {0, 0, 0, 0, 0, 0, 0, 0}, s, ev};
+    g_bricks.insert(g_bricks.begin(), std::move(e));
+    while (g_bricks.size() > kBrickSlots) { hipEventDestroy(g_bricks.back().event); g_bricks.pop_back(); }
+}
+
 // returns (bricks, number of non-empty bricks); reads the count back once per grid state
 std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) {
     check_input(binaries, "binaries", at::kBool);
@@ -186,19 +205,7 @@ std::pair<Tensor, int64_t> brick_entry(const Tensor &binaries, bool need_count) 
         const int64_t words = nfa_packed_grid_words(G, rx, ry, rz);
         Tensor bricks = at::empty({words}, opts(binaries, at::kLong));
         check_rc(nfa_pack_binaries(ptr<uint8_t>(binaries), G, rx, ry, rz, ptr<uint64_t>(bricks), s));
-        hipEvent_t ev;
-        hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        hipEventRecord(ev, s);
-        // drop slots whose tensor is gone or is this tensor in an older state, then the oldest
-        std::vector<BrickEntry> keep;
-        for (auto &c : g_bricks) {
-            if (c.ref.expired() || c.impl == impl) { hipEventDestroy(c.event); continue; }
-            keep.push_back(std::move(c));
-        }
-        g_bricks = std::move(keep);
-        BrickEntry e{c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr()), impl, ver, bricks, -1, {0, 0, 0, 0, 0, 0, 0, 0}, s, ev};
-        g_bricks.insert(g_bricks.begin(), std::move(e));
-        while (g_bricks.size() > kBrickSlots) { hipEventDestroy(g_bricks.back().event); g_bricks.pop_back(); }
+        insert_brick_entry(binaries, bricks, s);
         hit = 0;
     } else if (hit != 0) {
         BrickEntry e = std::move(g_bricks[hit]);
@@ -849,15 +856,29 @@ void grid_mark_invisible(const Tensor &occs_level, const OptTensor &cell_ids, co
                                      (K.numel() == 9 && C != 1) ? 1 : 0, (float)width, (float)height, (float)near_plane, stream_of(occs_level)));
 }
 
-py::tuple grid_threshold(const Tensor &occs, double occ_thre) {
+// shape = None: flat bool grid.  shape = (G, rx, ry, rz): the bool grid in that shape AND its bit-packed form, produced by
+// the same pass and entered into the brick cache — the traversal that follows does not pack again.
+py::tuple grid_threshold(const Tensor &occs, double occ_thre, const std::optional<std::vector<int64_t>> &shape) {
     check_input(occs, "occs", at::kFloat);
     const int64_t n = occs.numel();
     Tensor ws = at::empty({nfa_grid_threshold_workspace_bytes() / 8}, opts(occs, at::kDouble));
-    Tensor binaries = at::empty({n}, opts(occs, at::kBool));
     Tensor thre = at::empty({1}, occs.options());
     Guard g(device_of(occs));
     hipStream_t s = stream_of(occs);
     Timed t("grid_threshold", s);
+    if (shape) {
+        TORCH_CHECK(shape->size() == 4 && (*shape)[0] * (*shape)[1] * (*shape)[2] * (*shape)[3] == n && n > 0,
+                    "grid_threshold: shape must be (n_grids, resx, resy, resz) with as many cells as occs");
+        const int G = (int)(*shape)[0], rx = (int)(*shape)[1], ry = (int)(*shape)[2], rz = (int)(*shape)[3];
+        Tensor binaries = at::empty(*shape, opts(occs, at::kBool));
+        Tensor bricks = at::empty({nfa_packed_grid_words(G, rx, ry, rz)}, opts(occs, at::kLong));
+        check_rc(nfa_grid_threshold_packed(ptr<float>(occs), G, rx, ry, rz, (float)occ_thre, ws.data_ptr(), ptr<uint8_t>(binaries),
+                                           ptr<float>(thre), ptr<uint64_t>(bricks), s));
+        std::lock_guard<std::mutex> l(g_brick_mu);
+        insert_brick_entry(binaries, bricks, s);
+        return py::make_tuple(binaries, thre);
+    }
+    Tensor binaries = at::empty({n}, opts(occs, at::kBool));
     check_rc(nfa_grid_threshold(ptr<float>(occs), n, (float)occ_thre, ws.data_ptr(), ptr<uint8_t>(binaries), ptr<float>(thre), s));
     return py::make_tuple(binaries, thre);
 }
@@ -933,7 +954,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "need_sigma"_a = true, "need_rgb"_a = true);
     m.def("grid_cell_points", &grid_cell_points);
     m.def("grid_ema_update", &grid_ema_update);
-    m.def("grid_threshold", &grid_threshold);
+    m.def("grid_threshold", &grid_threshold, "occs"_a, "occ_thre"_a, "shape"_a = py::none());
     m.def("grid_mark_invisible", &grid_mark_invisible);
     m.def("packed_bricks", &packed_bricks);
     m.def("grid_occupied_counts", &grid_occupied_counts);

@@ -72,6 +72,7 @@ _SIGNATURES = {
                                                c_float, c_float, c_float, _P]),
     "nfa_grid_threshold_workspace_bytes": (c_int64, []),
     "nfa_grid_threshold": (ctypes.c_int, [_P, c_int64, c_float, _P, _P, _P, _P]),
+    "nfa_grid_threshold_packed": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
@@ -330,15 +331,22 @@ def _brick_entry(binaries: torch.Tensor) -> dict:
         bricks = torch.empty(words, dtype=torch.int64, device=binaries.device)
         with _Guard(binaries):
             _check(L.nfa_pack_binaries(_ptr(binaries), G, rx, ry, rz, _ptr(bricks), _stream(binaries)))
-            event = torch.cuda.Event()
-            event.record(stream)
-        # drop slots whose tensor is gone or has changed, then the oldest
-        _brick_cache[:] = [c for c in _brick_cache if c["ref"]() is not None and not (c["ref"]() is binaries)]
-        entry = {"ref": weakref.ref(binaries), "version": binaries._version, "bricks": bricks, "nonempty": -1,
-                 "stream": stream.cuda_stream, "event": event}
-        _brick_cache.insert(0, entry)
-        del _brick_cache[_BRICK_CACHE_SLOTS:]
-        return entry
+            return _insert_brick_entry(binaries, bricks)
+
+
+def _insert_brick_entry(binaries: torch.Tensor, bricks: torch.Tensor) -> dict:
+    """(caller holds _brick_lock and the device guard) make `bricks`, packed on the current stream, the front entry
+    for this state of `binaries`"""
+    stream = torch.cuda.current_stream(binaries.device)
+    event = torch.cuda.Event()
+    event.record(stream)
+    # drop slots whose tensor is gone or has changed, then the oldest
+    _brick_cache[:] = [c for c in _brick_cache if c["ref"]() is not None and not (c["ref"]() is binaries)]
+    entry = {"ref": weakref.ref(binaries), "version": binaries._version, "bricks": bricks, "nonempty": -1,
+             "stream": stream.cuda_stream, "event": event}
+    _brick_cache.insert(0, entry)
+    del _brick_cache[_BRICK_CACHE_SLOTS:]
+    return entry
 
 
 def packed_bricks(binaries: torch.Tensor) -> torch.Tensor:
@@ -901,15 +909,28 @@ class _CtypesC:
         return list(_brick_entry(binaries)["level_counts"])
 
     @staticmethod
-    def grid_threshold(occs, occ_thre: float):
-        """binaries (flat bool) = occs > min(mean(occs[occs >= 0]), occ_thre); also returns the
-        threshold as a 1-element device tensor (no host sync)."""
+    def grid_threshold(occs, occ_thre: float, shape=None):
+        """binaries (bool) = occs > min(mean(occs[occs >= 0]), occ_thre); also returns the threshold as a 1-element
+        device tensor (no host sync).  shape = None: flat grid.  shape = (G, rx, ry, rz): the grid in that shape and,
+        from the same pass, its bit-packed form, entered into the brick cache (the next traversal does not pack again)."""
         _check_input(occs, "occs", torch.float32)
         L = load_library()
         n = occs.numel()
         ws = torch.empty(L.nfa_grid_threshold_workspace_bytes() // 8, dtype=torch.float64, device=occs.device)
-        binaries = torch.empty(n, dtype=torch.bool, device=occs.device)
         thre = torch.empty(1, dtype=torch.float32, device=occs.device)
+        if shape is not None:
+            G, rx, ry, rz = (int(x) for x in shape)
+            if G * rx * ry * rz != n or n == 0:
+                raise RuntimeError("grid_threshold: shape must be (n_grids, resx, resy, resz) with as many cells as occs")
+            binaries = torch.empty((G, rx, ry, rz), dtype=torch.bool, device=occs.device)
+            bricks = torch.empty(L.nfa_packed_grid_words(G, rx, ry, rz), dtype=torch.int64, device=occs.device)
+            with _Guard(occs):
+                _check(_call("grid_threshold", L.nfa_grid_threshold_packed, _ptr(occs), G, rx, ry, rz, float(occ_thre), _ptr(ws),
+                             _ptr(binaries), _ptr(thre), _ptr(bricks), _stream(occs)))
+                with _brick_lock:
+                    _insert_brick_entry(binaries, bricks)
+            return binaries, thre
+        binaries = torch.empty(n, dtype=torch.bool, device=occs.device)
         with _Guard(occs):
             _check(_call("grid_threshold", L.nfa_grid_threshold, _ptr(occs), n, float(occ_thre), _ptr(ws),
                          _ptr(binaries), _ptr(thre), _stream(occs)))

@@ -236,11 +236,9 @@ class OccGridEstimator(AbstractEstimator):
                 occ = occ_eval_fn(world).reshape(-1).float().contiguous()
                 lo = lvl * self.cells_per_lvl
                 _C.grid_ema_update(self.occs[lo:lo + self.cells_per_lvl], indices.contiguous(), occ, ema_decay)
-            binaries, _ = _C.grid_threshold(self.occs, occ_thre)
-            self.binaries = binaries.view(self.binaries.shape)
-            from ..cuda._backend import packed_bricks
-
-            packed_bricks(self.binaries)      # the bit-packed form the traversal kernels read
+            # threshold and bit-pack in one pass: the bool grid comes back in its final shape and its packed form (what the
+            # traversal kernels read) is already in the brick cache under this tensor
+            self.binaries, _ = _C.grid_threshold(self.occs, occ_thre, tuple(self.binaries.shape))
             self._occs_changed()
             return
         # host tensors: the reference's own composition of torch ops (occ_grid.py:377-404)

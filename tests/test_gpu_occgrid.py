@@ -87,6 +87,46 @@ def test_threshold_matches_reference_rule():
     assert not b.any() and torch.isnan(th).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 32), (1, 30, 31, 33), (3, 8, 12, 20)])
+def test_threshold_packed_equals_threshold_then_pack(shape):
+    """grid_threshold(shape=...) — threshold and bit-pack in one pass, cache entry included — gives the bool grid of the
+    two-step form and, word for word, the packed grid nfa_pack_binaries builds from it (bricks, header with the per-level
+    voxel counts, coarse bitmap, rank prefix, compacted bricks)"""
+    from nerfacc_amd import cuda as C
+    from nerfacc_amd.cuda import _backend
+
+    rng = np.random.default_rng(sum(shape))
+    ncell = int(np.prod(shape))
+    occs = (rng.random(ncell, dtype=np.float32) ** 4 * 0.05).astype(np.float32)
+    occs[rng.integers(0, ncell, ncell // 20)] = -1.0
+    o = t(occs)
+    flat, thre_a = C.grid_threshold(o, 0.01)
+    fused, thre_b = C.grid_threshold(o, 0.01, shape)
+    assert fused.shape == tuple(shape) and fused.dtype == torch.bool
+    assert torch.equal(fused.reshape(-1), flat) and torch.equal(thre_a, thre_b)
+    packed_fused = _backend.packed_bricks(fused).clone()            # cache hit: what the fused pass wrote
+    packed_ref = _backend.packed_bricks(flat.view(shape).clone())   # a different tensor: packed from the bool grid
+    assert packed_fused.data_ptr() != packed_ref.data_ptr()
+    # the written parts of the buffer (grid.hip, PackedLayout); padding words are left as allocated
+    G, rx, ry, rz = shape
+    nb = G * ((rx + 3) // 4) * ((ry + 3) // 4) * ((rz + 3) // 4)
+    nw = (nb + 31) // 32
+    off_coarse = nb + 12
+    off_prefix = off_coarse + (nw + 1) // 2
+    off_compact = off_prefix + (nw + 1) // 2
+    nonempty = int(packed_ref[nb])
+    assert nonempty == int((packed_ref[:nb] != 0).sum())
+    for a, b in ((0, nb + 9), (off_compact, off_compact + nonempty)):
+        assert torch.equal(packed_fused[a:b], packed_ref[a:b])
+    f32, r32 = packed_fused.view(torch.int32), packed_ref.view(torch.int32)
+    for off in (off_coarse, off_prefix):
+        assert torch.equal(f32[2 * off:2 * off + nw], r32[2 * off:2 * off + nw])
+    assert C.grid_occupied_counts(fused) == [int(x) for x in fused.reshape(shape[0], -1).sum(1).tolist()]
+    allneg = torch.full((int(np.prod(shape)),), -1.0, device=o.device)
+    b, th = C.grid_threshold(allneg, 0.01, shape)
+    assert not b.any() and torch.isnan(th).all()
+
+
 def test_update_end_to_end_vs_oracle():
     """OccGridEstimator._update on the device == the oracle replay fed with the same draws of the
     device generator (same calls, same order: occ_grid.py:345-404)."""
