@@ -946,6 +946,36 @@ __device__ unsigned long long g_phase_slow[16] = {0};                           
 #define NFA_PHASE_END() do {} while (0)
 #endif
 
+// ---- cross-lane moves inside the P adjacent lanes of a ray (P <= 16: one DPP row).  ds_bpermute shuffles go through
+// the LDS crossbar and a lone wave waits for each batch; these stay in the VALU.
+// value of the lane Q below (same row); only meaningful where part >= Q
+template <int Q>
+__device__ __forceinline__ int group_shr_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kDppRowShr + Q, 0xf, 0xf, false); }
+template <int Q>
+__device__ __forceinline__ int64_t group_shr_i64(int64_t v) { return dpp_i64<kDppRowShr + Q>(v); }
+// inclusive prefix sums over the lanes of a group (part = lane index inside the group)
+template <int P>
+__device__ __forceinline__ int group_incl_sum_i32(int v, int part) {
+    if (P > 1) { const int u = group_shr_i32<1>(v); if (part >= 1) v += u; }
+    if (P > 2) { const int u = group_shr_i32<2>(v); if (part >= 2) v += u; }
+    if (P > 4) { const int u = group_shr_i32<4>(v); if (part >= 4) v += u; }
+    if (P > 8) { const int u = group_shr_i32<8>(v); if (part >= 8) v += u; }
+    return v;
+}
+template <int P>
+__device__ __forceinline__ int64_t group_incl_sum_i64(int64_t v, int part) {
+    if (P > 1) { const int64_t u = group_shr_i64<1>(v); if (part >= 1) v += u; }
+    if (P > 2) { const int64_t u = group_shr_i64<2>(v); if (part >= 2) v += u; }
+    if (P > 4) { const int64_t u = group_shr_i64<4>(v); if (part >= 4) v += u; }
+    if (P > 8) { const int64_t u = group_shr_i64<8>(v); if (part >= 8) v += u; }
+    return v;
+}
+// the group's P bits of a wave-wide ballot
+template <int P>
+__device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int group_base) {
+    return (unsigned)((ballot >> group_base) & ((1ull << P) - 1ull));
+}
+
 template <bool LDS_OCC, int P, int CAP>
 __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
                                                                       int64_t *__restrict__ block_sums, RunStore rs)
@@ -1095,12 +1125,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     // a part with more boundaries than its list holds puts its whole ray (all P lanes) into
     // streaming mode: boundaries are resolved as the walk finds them and only aggregates are kept
     // (S1); the run records are written by walking once more when the ray's prefixes are known (S2)
-    bool streaming = overflow;
-#pragma unroll
-    for (int off = 1; off < P; off <<= 1) {
-        const int other = __shfl_xor((int)streaming, off, 64);
-        streaming = streaming || (other != 0);
-    }
+    const bool streaming = group_bits<P>(__ballot(overflow), group_base) != 0u;
 
     NFA_PHASE_MARK(4);
     // ---- B: absolute lattice position (T_j, K_j = steps from the segment start) of every own
@@ -1150,23 +1175,17 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
 #ifdef NFA_FORCE_SERIAL                          // test builds: every ray through the serial in-kernel walk
     bad = true;
 #endif
-#pragma unroll
-    for (int off = 1; off < P; off <<= 1) {
-        const int other = __shfl_xor((int)bad, off, 64);   // NOT inside a short-circuit: every lane must take part
-        bad = bad || (other != 0);
-    }
+    bad = group_bits<P>(__ballot(bad), group_base) != 0u;
     // boundary before this part's first one: the nearest earlier part that has boundaries
+    const unsigned ev_parts = group_bits<P>(__ballot(n_ev > 0), group_base);     // bit p: part p of this ray has boundaries
     int64_t K_before = 0;
     float T_before = t_seg;
     {
-        bool found = false;
-#pragma unroll
-        for (int q = 1; q < P; ++q) {
-            const int has_q = __shfl_up(n_ev, q, 64);
-            const int64_t Kq = __shfl_up(K_last, q, 64);
-            const float Tq = __shfl_up(T_last, q, 64);
-            if (!found && part >= q && has_q > 0) { found = true; K_before = Kq; T_before = Tq; }
-        }
+        const unsigned earlier = ev_parts & ((1u << part) - 1u);
+        const int src = group_base + (earlier ? 31 - __clz(earlier) : part);
+        const int64_t Kq = __shfl(K_last, src, 64);
+        const float Tq = __shfl(T_last, src, 64);
+        if (earlier) { K_before = Kq; T_before = Tq; }
     }
     // samples of every occupied run that ends in this part; runs with samples are "fresh"
     // (each is preceded by an empty run or starts the ray: boundaries alternate)
@@ -1185,21 +1204,13 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         if (occ_first && K_first > K_before) { n_sm += K_first - K_before; ++n_fresh; }
     }
     // exclusive prefixes of fresh runs and samples over the ray's parts, and ray totals
-    int fresh_before = 0, fresh_total = n_fresh;
-    int64_t sm_before = 0, sm_total = n_sm;
-    int last_part_with_ev = n_ev > 0 ? part : -1;
-#pragma unroll
-    for (int q = 1; q < P; ++q) {
-        const int f = __shfl_up(n_fresh, q, 64);
-        const int64_t m = __shfl_up(n_sm, q, 64);
-        if (part >= q) { fresh_before += f; sm_before += m; }
-    }
-#pragma unroll
-    for (int off = 1; off < P; off <<= 1) {
-        fresh_total += __shfl_xor(fresh_total, off, 64);
-        sm_total += __shfl_xor(sm_total, off, 64);
-        last_part_with_ev = max(last_part_with_ev, __shfl_xor(last_part_with_ev, off, 64));
-    }
+    const int fresh_incl = group_incl_sum_i32<P>(n_fresh, part);
+    const int64_t sm_incl = group_incl_sum_i64<P>(n_sm, part);
+    const int fresh_before = fresh_incl - n_fresh;
+    const int64_t sm_before = sm_incl - n_sm;
+    const int fresh_total = __shfl(fresh_incl, group_base + P - 1, 64);
+    const int64_t sm_total = __shfl(sm_incl, group_base + P - 1, 64);
+    const int last_part_with_ev = ev_parts ? 31 - __clz(ev_parts) : -1;
     const float T_final = __shfl(T_last, group_base + max(last_part_with_ev, 0), 64);
 
     // run records of this part
