@@ -741,8 +741,8 @@ py::tuple accumulate_along_rays_bwd(const Tensor &ray_indices, const Tensor &wei
     return py::make_tuple(g_w.defined() ? py::cast(g_w) : py::none(), g_v.defined() ? py::cast(g_v) : py::none());
 }
 
-py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
-                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
+std::vector<Tensor> rendering_fwd_core(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
+                                       const Tensor &rgbs, int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
     check_input(sigmas, "sigmas", at::kFloat);
     const int64_t n = sigmas.numel();
     check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
@@ -762,13 +762,19 @@ py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const
                                    n_rays, ptr<float>(bkgd), expected_depths, per.p(0), per.p(1), per.p(2),
                                    ptr<float>(colors), ptr<float>(od), ptr<float>(od) + n_rays, s));
     }
-    return py::make_tuple(colors, od[0], od[1], per.row(0), per.row(1), per.row(2));
+    return {colors, od[0], od[1], per.row(0), per.row(1), per.row(2)};
+}
+py::tuple rendering_fwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
+                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
+    const auto o = rendering_fwd_core(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, bkgd, expected_depths);
+    return py::make_tuple(o[0], o[1], o[2], o[3], o[4], o[5]);
 }
 
-py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
-                        const Tensor &weights, const Tensor &trans, const Tensor &alphas, const Tensor &opacities, const Tensor &depths,
-                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths, const OptTensor &g_colors, const OptTensor &g_opac,
-                        const OptTensor &g_depth, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a, bool need_sigma, bool need_rgb) {
+std::pair<Tensor, Tensor> rendering_bwd_core(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas,
+                                             const Tensor &rgbs, const Tensor &weights, const Tensor &trans, const Tensor &alphas,
+                                             const Tensor &opacities, const Tensor &depths, int64_t n_rays, const OptTensor &bkgd,
+                                             bool expected_depths, const OptTensor &g_colors, const OptTensor &g_opac, const OptTensor &g_depth,
+                                             const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a, bool need_sigma, bool need_rgb) {
     check_input(sigmas, "sigmas", at::kFloat);
     const int64_t n = sigmas.numel();
     check_len(ray_indices, "ray_indices", at::kLong, n, sigmas);
@@ -797,7 +803,64 @@ py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const
                                    sigmas.size(0), n_rays, ptr<float>(bkgd), expected_depths, ptr<float>(g_colors), ptr<float>(g_opac),
                                    ptr<float>(g_depth), ptr<float>(g_w), ptr<float>(g_T), ptr<float>(g_a), ptr<float>(g_sig), ptr<float>(g_rgb), s));
     }
-    return py::make_tuple(g_sig.defined() ? py::cast(g_sig) : py::none(), g_rgb.defined() ? py::cast(g_rgb) : py::none());
+    return {g_sig, g_rgb};
+}
+py::tuple rendering_bwd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
+                        const Tensor &weights, const Tensor &trans, const Tensor &alphas, const Tensor &opacities, const Tensor &depths,
+                        int64_t n_rays, const OptTensor &bkgd, bool expected_depths, const OptTensor &g_colors, const OptTensor &g_opac,
+                        const OptTensor &g_depth, const OptTensor &g_w, const OptTensor &g_T, const OptTensor &g_a, bool need_sigma, bool need_rgb) {
+    const auto r = rendering_bwd_core(ray_indices, t_starts, t_ends, sigmas, rgbs, weights, trans, alphas, opacities, depths, n_rays, bkgd,
+                                      expected_depths, g_colors, g_opac, g_depth, g_w, g_T, g_a, need_sigma, need_rgb);
+    return py::make_tuple(r.first.defined() ? py::cast(r.first) : py::none(), r.second.defined() ? py::cast(r.second) : py::none());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rendering with its autograd node in C++ (volrend.py:104-164 after rgb_sigma_fn): what nerfacc.rendering calls on the
+// training path.  The Python twin (nerfacc_amd/volrend.py::_Rendering) costs ~15 us of interpreter per forward and ~30 us
+// per backward on a step whose GPU waits for the host there (tools/step_timeline.py).
+// ---------------------------------------------------------------------------------------------------
+struct RenderingFn : public torch::autograd::Function<RenderingFn> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, Tensor ray_indices, Tensor t_starts, Tensor t_ends,
+                                                  Tensor sigmas, Tensor rgbs, int64_t n_rays, OptTensor bkgd, bool expected_depths) {
+        ctx->set_materialize_grads(false);      // of six outputs a loss usually touches one: no zero fills for the rest
+        ray_indices = ray_indices.contiguous();
+        t_starts = t_starts.contiguous();
+        t_ends = t_ends.contiguous();
+        sigmas = sigmas.contiguous();
+        rgbs = rgbs.contiguous();
+        OptTensor bk;
+        if (bkgd && bkgd->defined()) bk = bkgd->detach().to(at::kFloat).contiguous();
+        std::vector<Tensor> o = rendering_fwd_core(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, bk, expected_depths);
+        ctx->saved_data["n_rays"] = n_rays;
+        ctx->saved_data["expected_depths"] = expected_depths;
+        ctx->saved_data["has_bkgd"] = bk.has_value();
+        std::vector<Tensor> saved = {ray_indices, t_starts, t_ends, sigmas, rgbs, o[3], o[4], o[5], o[1], o[2]};
+        if (bk) saved.push_back(*bk);
+        ctx->save_for_backward(saved);
+        return o;
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list g) {
+        const auto saved = ctx->get_saved_variables();
+        const bool has_bkgd = ctx->saved_data["has_bkgd"].toBool();
+        auto opt = [](const Tensor &t) -> OptTensor { return t.defined() ? OptTensor(t.contiguous()) : std::nullopt; };
+        const bool need_sigma = ctx->needs_input_grad(3), need_rgb = ctx->needs_input_grad(4);
+        Tensor g_sig, g_rgb;
+        if (need_sigma || need_rgb) {            // (no Python object anywhere below: the autograd engine's thread does not hold the GIL)
+            auto r = rendering_bwd_core(saved[0], saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], saved[8], saved[9],
+                                        ctx->saved_data["n_rays"].toInt(), has_bkgd ? OptTensor(saved[10]) : std::nullopt,
+                                        ctx->saved_data["expected_depths"].toBool(), opt(g[0]), opt(g[1]), opt(g[2]), opt(g[3]), opt(g[4]),
+                                        opt(g[5]), need_sigma, need_rgb);
+            g_sig = r.first;
+            g_rgb = r.second;
+        }
+        return {Tensor(), Tensor(), Tensor(), g_sig, g_rgb, Tensor(), Tensor(), Tensor()};
+    }
+};
+
+py::tuple rendering_autograd(const Tensor &ray_indices, const Tensor &t_starts, const Tensor &t_ends, const Tensor &sigmas, const Tensor &rgbs,
+                             int64_t n_rays, const OptTensor &bkgd, bool expected_depths) {
+    auto o = RenderingFn::apply(ray_indices, t_starts, t_ends, sigmas, rgbs, n_rays, bkgd, expected_depths);
+    return py::make_tuple(o[0], o[1], o[2], o[3], o[4], o[5]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -952,6 +1015,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("rendering_bwd", &rendering_bwd, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "sigmas"_a, "rgbs"_a, "weights"_a, "trans"_a, "alphas"_a,
           "opacities"_a, "depths"_a, "n_rays"_a, "bkgd"_a, "expected_depths"_a, "g_colors"_a, "g_opac"_a, "g_depth"_a, "g_w"_a, "g_T"_a, "g_a"_a,
           "need_sigma"_a = true, "need_rgb"_a = true);
+    m.def("rendering", &rendering_autograd, "ray_indices"_a, "t_starts"_a, "t_ends"_a, "sigmas"_a, "rgbs"_a, "n_rays"_a, "render_bkgd"_a,
+          "expected_depths"_a);
     m.def("grid_cell_points", &grid_cell_points);
     m.def("grid_ema_update", &grid_ema_update);
     m.def("grid_threshold", &grid_threshold, "occs"_a, "occ_thre"_a, "shape"_a = py::none());

@@ -154,7 +154,11 @@ def rendering(
             # the kernel blends ONE background colour; anything else the reference's broadcast accepts
             # (per-ray [n_rays, 3], [1], ...) is blended below with the reference's own expression
             fused_bkgd = render_bkgd is not None and render_bkgd.numel() == 3 and not render_bkgd.requires_grad
-            colors, opacities, depths, weights, trans, alphas = _Rendering.apply(
+            from .cuda import _backend
+            # the extension carries this autograd node in C++ (no interpreter in its backward); the ctypes face uses the
+            # Python twin above
+            render = getattr(_backend._C, "rendering", None) or _Rendering.apply
+            colors, opacities, depths, weights, trans, alphas = render(
                 ray_indices.contiguous(), t_starts, t_ends, sigmas, rgbs, int(n_rays),
                 render_bkgd.reshape(3) if fused_bkgd else None, bool(expected_depths))
             extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
