@@ -168,6 +168,13 @@ int nfa_traverse_offsets(const nfa_traverse_args *args, const void *workspace, v
 int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t rewrite_counts,
                       const void *workspace, int64_t n_samples, int64_t n_overflow, void *stream);
 
+/* The emit pass of the two-pass mode launched BEFORE the host has read the totals back (sampling outputs only): the
+ * outputs hold `capacity` samples — the caller's guess — and the kernel takes the true total from the device copy that
+ * nfa_traverse_offsets left in `workspace`; if the total exceeds the capacity the launch does nothing and the caller
+ * calls nfa_traverse_fill with exactly sized outputs after its read-back.  Rays flagged as overflowed by the count
+ * pass are NOT written here: call nfa_traverse_fill(a, 1, 0, workspace, 0, n_overflow, stream) for them. */
+int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const void *workspace, int64_t capacity, void *stream);
+
 /* chunk_starts = cumsum(cnts) - cnts, total -> *total (data_spec.hpp:86-106). total nullable. */
 int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream);
 

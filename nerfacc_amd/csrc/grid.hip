@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     const int64_t *__restrict__ iv_cnts, int64_t *__restrict__ iv_starts,
     const int64_t *__restrict__ sm_cnts, int64_t *__restrict__ sm_starts,
     int64_t n_rays, const int64_t *__restrict__ block_sums, int sums_per_block, int64_t n_sums,
-    int64_t *__restrict__ totals)
+    int64_t *__restrict__ totals, int64_t *__restrict__ totals_dev)
 {
     __shared__ int64_t lds[kWavesPerBlock];
     __shared__ int64_t base[2];
@@ -1335,20 +1335,20 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
         const int64_t c = in ? iv_cnts[r] : 0;
         const int64_t e = block_excl_scan_i64(c, lds, tot);
         if (in) iv_starts[r] = base[0] + e;
-        if (last && threadIdx.x == 0) totals[0] = base[0] + tot;
-    } else if (last && threadIdx.x == 0) totals[0] = 0;
+        if (last && threadIdx.x == 0) { totals[0] = base[0] + tot; totals_dev[0] = base[0] + tot; }
+    } else if (last && threadIdx.x == 0) { totals[0] = 0; totals_dev[0] = 0; }
     {
         const int64_t c = in ? sm_cnts[r] : 0;
         const int64_t e = block_excl_scan_i64(c, lds, tot);
         if (in) sm_starts[r] = base[1] + e;
-        if (last && threadIdx.x == 0) totals[1] = base[1] + tot;
+        if (last && threadIdx.x == 0) { totals[1] = base[1] + tot; totals_dev[1] = base[1] + tot; }
     }
     if (last) {                                   // rays that need the pass-2 re-traversal
         int64_t ov = 0;
         for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
         int64_t tov;
         block_excl_scan_i64(ov, lds, tov);
-        if (threadIdx.x == 0) { totals[2] = tov; totals[3] = 0; }
+        if (threadIdx.x == 0) { totals[2] = tov; totals[3] = 0; totals_dev[2] = tov; totals_dev[3] = 0; }
     }
 }
 
@@ -1382,8 +1382,16 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
 // pass 2, fast form: ONE LANE PER OUTPUT SAMPLE.  sample s -> ray (binary search in the
 // exclusive offsets) -> run (binary search in the runs' first-sample indices) -> lattice point (closed form) -> coalesced
 // stores of ray_indices / t_starts / t_ends (+ interval edges when asked for).
-__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t n_samples)
+// n_dev != NULL: speculative launch (before the host knows the total): the total comes from n_dev[1] and a launch whose
+// outputs (sized `n_samples` = the caller's guess) are too small does nothing — the caller launches again with the right size.
+__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t n_samples,
+                                                               const int64_t *__restrict__ n_dev)
 {
+    if (n_dev) {
+        const int64_t n = n_dev[1];
+        if (n > n_samples) return;
+        n_samples = n;
+    }
     const float step_size = a.step_size, cone = a.cone_angle;
     const int64_t R = a.n_rays;
     __shared__ int64_t s_span[2];
@@ -1541,6 +1549,11 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
 // workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: max_runs*R f32 ][ run first: max_runs*R i32 ][ n_runs: R u16 ]
 // one triple per wave; the finest granularity any count kernel publishes is 4 rays per wave (P = 16)
 inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * (ceil_div(n_rays > 0 ? n_rays : 1, 4) + kWavesPerBlock); }
+// [ block sums | run records | n_runs ] [ totals: 4 int64, the device copy of what nfa_traverse_offsets stores in args.totals ]
+inline int64_t ws_totals_offset(int64_t n_rays) {
+    const int64_t R = n_rays > 0 ? n_rays : 1;
+    return ws_block_sums_bytes(R) + (int64_t)run_capacity(R) * R * 8 + ceil_div(2 * R, 16) * 16;
+}
 RunStore make_runs(void *workspace, int64_t n_rays) {
     RunStore rs;
     uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
@@ -1645,7 +1658,7 @@ NFA_EXPORT int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int
 
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     const int64_t R = n_rays > 0 ? n_rays : 1;
-    return ws_block_sums_bytes(R) + (int64_t)run_capacity(R) * R * 8 + ceil_div(2 * R, 16) * 16;
+    return ws_totals_offset(R) + 4 * (int64_t)sizeof(int64_t);
 }
 
 // lanes per ray of the count pass for this call (1 = lane-per-ray kernels).  `sparse`: the full
@@ -1767,7 +1780,8 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     const int64_t n_sums = ceil_div(a->n_rays, kBlock / P) * kWavesPerBlock;      // one triple per wave of the count launch
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
-                       a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals);
+                       a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals,
+                       (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)));
     return check_launch("traverse_offsets_kernel");
 }
 
@@ -1807,11 +1821,24 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
-        hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples);
+        hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         if (int rc = check_launch("traverse_emit_kernel")) return rc;
     }
     if (n_overflow > 0) return launch_fill(a, 1, 0, rs.n_runs, s);
     return NFA_OK;
+}
+
+NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const void *workspace, int64_t capacity, void *stream)
+{
+    if (int rc = validate_traverse(a)) return rc;
+    if (a->n_rays == 0 || capacity <= 0) return NFA_OK;
+    NFA_REQUIRE(workspace != nullptr, "traverse_emit_speculative: workspace is NULL");
+    NFA_REQUIRE(!a->iv_vals, "traverse_emit_speculative: sampling outputs only");
+    if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
+    const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
+    const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
+    hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    return check_launch("traverse_emit_kernel");
 }
 
 NFA_EXPORT int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream)

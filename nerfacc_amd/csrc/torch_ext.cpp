@@ -494,17 +494,52 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
     }
     check_rc(nfa_traverse_offsets(&a, ws.data_ptr(), s));
-    wait_stream(s);
-    const int64_t n = h[1], n_overflow = h[2];
-    Tensor ray_indices = at::empty({n}, i64);
-    Rows ts(2, n, f32);
-    a.sm_ray_indices = ptr<int64_t>(ray_indices);
-    a.t_starts = ts.p(0);
-    a.t_ends = ts.p(1);
+    // The emit pass is launched BEFORE the read-back, into outputs sized from the previous call on this device (training
+    // steps draw about the same number of samples every time): the GPU goes from the offsets kernel straight into it
+    // instead of idling through the host's wake-up, allocation and launch (16 us, tools/step_timeline.py), and the host —
+    // woken by an event recorded before the emit launch — prepares the caller's next kernels while it runs.  A guess that
+    // is too small costs nothing but the second launch the old order always needed.
+    thread_local std::map<int, int64_t> last_n;
+    thread_local std::map<int, hipEvent_t> events;
+    const int dev = rays_o.device().index();
+    const bool speculate = last_n.count(dev) && last_n[dev] > 0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
+    int64_t cap = speculate ? last_n[dev] + last_n[dev] / 4 + 1024 : 0;
+    Tensor ray_indices;
+    Rows ts(2, cap, f32);
     a.terminate_planes = nullptr;                     // written by the count pass only
-    if (n > 0) {
-        Timed t("traverse_fill", s);
-        check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n, n_overflow, s));
+    if (speculate) {
+        ray_indices = at::empty({cap}, i64);
+        a.sm_ray_indices = ptr<int64_t>(ray_indices);
+        a.t_starts = ts.p(0);
+        a.t_ends = ts.p(1);
+        hipEvent_t &ev = events[dev];
+        if (!ev) TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "nerfacc_amd: hipEventCreate failed");
+        TORCH_CHECK(hipEventRecord(ev, s) == hipSuccess, "nerfacc_amd: hipEventRecord failed");
+        {
+            Timed t("traverse_fill", s);
+            check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
+        }
+        py::gil_scoped_release nogil;
+        TORCH_CHECK(hipEventSynchronize(ev) == hipSuccess, "nerfacc_amd: hipEventSynchronize failed");
+    } else {
+        wait_stream(s);
+    }
+    const int64_t n = h[1], n_overflow = h[2];
+    last_n[dev] = n;
+    if (speculate && n <= cap) {
+        if (n_overflow > 0) check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), 0, n_overflow, s));     // the rays the count pass flagged
+        ray_indices = ray_indices.narrow(0, 0, n);
+        ts.n = n;
+    } else {
+        ray_indices = at::empty({n}, i64);
+        ts = Rows(2, n, f32);
+        a.sm_ray_indices = ptr<int64_t>(ray_indices);
+        a.t_starts = ts.p(0);
+        a.t_ends = ts.p(1);
+        if (n > 0) {
+            Timed t("traverse_fill", s);
+            check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n, n_overflow, s));
+        }
     }
     if (with_terminate_planes) return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t(), term);
     return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t());

@@ -115,7 +115,9 @@ def test_kernel_timer_through_the_extension(faces):
         summ = timer.summary()
         _backend.set_kernel_timer(None)
     assert summ["traverse_count"][0] == 3 and 0.0 < summ["traverse_count"][1] < 5.0
-    assert summ["traverse_fill"][0] == 3
+    # (the emit pass is launched speculatively from the second call on; a guess left over from an earlier test that is too
+    # small for these rays adds one relaunch)
+    assert 3 <= summ["traverse_fill"][0] <= 4
 
 
 def test_extension_rejects_mismatched_arguments(faces):
