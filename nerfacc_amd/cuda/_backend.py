@@ -77,6 +77,7 @@ _SIGNATURES = {
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P, c_int64, c_int64, _P]),
+    "nfa_traverse_emit_speculative": (ctypes.c_int, [_P, _P, c_int64, _P]),    # (used by the extension only)
     "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
     "nfa_pack_info": (ctypes.c_int, [_P, c_int64, c_int64, _P, _P]),
     "nfa_unpack_info": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, _P]),
