@@ -10,8 +10,8 @@
 //            8+4 bytes read and 4 written per element, no LDS, no atomics, no inter-workgroup
 //            traffic, results independent of scheduling.
 //   chunked: a row (ray) per 16-lane quarter wave — arbitrary (start,count) rows, as the
-//            reference allows — four rows per wave, 64 elements per row and trip in flight, 16-wide DPP
-//            scans with a carry.
+//            reference allows — four rows per wave, 64 elements per row and trip as ONE 16-byte access per lane,
+//            four elements per lane serially, the lane totals through a 16-wide DPP scan with a carry.
 #include "common.hpp"
 
 namespace nfa {
@@ -92,6 +92,23 @@ __device__ __forceinline__ float row16_last(float v, int lane) {
     return (lane & 32) ? ((lane & 16) ? d : c) : ((lane & 16) ? b : a);
 }
 
+// four consecutive elements of a row per lane (in walk order: descending addresses when `reverse`).  The row's start is
+// arbitrary, so the 16-byte access is only 4-byte aligned: global memory takes that (unaligned access mode), and it is one
+// memory instruction per 64 elements of a row instead of four.
+struct alignas(4) F4u { float v[4]; };
+__device__ __forceinline__ void ld4_walk(const float *__restrict__ p, int64_t lo, bool full, const bool (&act)[4], const int64_t (&idx)[4],
+                                         bool reverse, float fill, float (&out)[4]) {
+    if (full) {
+        F4u t;
+        __builtin_memcpy(&t, p + lo, sizeof(t));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = reverse ? t.v[3 - e] : t.v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = act[e] ? p[idx[e]] : fill;
+    }
+}
+
 template <class Op, bool INCL>
 __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
     const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts, int64_t n_rows,
@@ -111,34 +128,51 @@ __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
         cmax = max(cmax, __shfl_xor(cmax, 16, 64));
         cmax = max(cmax, __shfl_xor(cmax, 32, 64));
         float carry = Op::identity();
-        constexpr int U = 4;
-        for (int64_t c = 0; c < cmax; c += 16 * U) {
-            float v[U], dv[U];
-            int64_t idx[U];
-            bool act[U];
+        for (int64_t c = 0; c < cmax; c += 64) {
+            const int64_t k0 = c + 4 * sub;                 // this lane's first element of the trip, in walk order
+            bool act[4];
+            int64_t idx[4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t k = c + 16 * u + sub;
-                act[u] = k < cnt;
-                idx[u] = reverse ? (start + cnt - 1 - k) : (start + k);
-                v[u] = Op::identity();
-                dv[u] = 1.0f;
-                if (act[u]) {
-                    v[u] = in[idx[u]];
-                    if (mul) v[u] *= mul[idx[u]];
-                    if (div) dv[u] = div[idx[u]];
-                }
+            for (int e = 0; e < 4; ++e) {
+                act[e] = k0 + e < cnt;
+                idx[e] = reverse ? (start + cnt - 1 - (k0 + e)) : (start + k0 + e);
             }
+            const bool full = act[3];
+            const int64_t lo = reverse ? idx[3] : idx[0];   // lowest address of the four
+            float v[4], dv[4];
+            ld4_walk(in, lo, full, act, idx, reverse != 0, Op::identity(), v);
+            if (mul) {
+                float m[4];
+                ld4_walk(mul, lo, full, act, idx, reverse != 0, 1.0f, m);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float incl = Op::apply(carry, row16_incl_scan<Op>(v[u]));
-                float excl = dpp_f<kDppRowShr + 1>(carry, incl);          // lane 0 of the row has no source: keeps `carry`
-                carry = row16_last(incl, lane);
-                if (act[u]) {
-                    float r = INCL ? incl : excl;
-                    if (div) r = r / fmaxf(dv[u], 1e-10f);
-                    out[idx[u]] = r;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = act[e] ? v[e] * m[e] : Op::identity();
+            }
+            if (div) ld4_walk(div, lo, full, act, idx, reverse != 0, 1.0f, dv);
+            // lane-local scan, then the 16 lane totals of the row on the DPP path
+            float x[4];
+            x[0] = v[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) x[e] = Op::apply(x[e - 1], v[e]);
+            const float incl_lane = Op::apply(carry, row16_incl_scan<Op>(x[3]));
+            const float pre = dpp_f<kDppRowShr + 1>(carry, incl_lane);            // lane 0 of the row has no source: keeps `carry`
+            carry = row16_last(incl_lane, lane);
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float incl = Op::apply(pre, x[e]);
+                const float excl = e == 0 ? pre : Op::apply(pre, x[e > 0 ? e - 1 : 0]);
+                r[e] = INCL ? incl : excl;
+                if (div) r[e] = r[e] / fmaxf(dv[e], 1e-10f);
+            }
+            if (full) {
+                F4u t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.v[e] = reverse ? r[3 - e] : r[e];
+                __builtin_memcpy(out + lo, &t, sizeof(t));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (act[e]) out[idx[e]] = r[e];
             }
         }
         if (normalize) {  // utils_scan.cuh:101-109 / 228-236: divide by the row total

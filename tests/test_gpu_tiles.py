@@ -77,3 +77,63 @@ def test_sampling_with_and_without_the_speculative_emit(monkeypatch, speculative
     # small -> large -> small: the guess is too small for the second case and generous for the third
     for name in ["degenerate", "lego_4k", "lego_70k", "m1_sphere", "near_far", "lego_4k"]:
         T.test_hip_sampling_reproduces_reference_k2(name, k2)
+
+
+def test_packed_scans_over_arbitrary_row_tables():
+    """scan_packed takes ANY (start, count) table, as the reference does: rows with gaps between them, rows in reverse
+    order, a table that covers only part of the input — every row scanned on its own"""
+    from nerfacc_amd import cuda as C
+
+    rng = np.random.default_rng(7)
+    ri_, pk_ = ragged(rng, 3000, 40)
+    N = ri_.shape[0]
+    x_ = (rng.random(N) * 0.4 + 0.8).astype(np.float32)
+    x = t(x_)
+
+    def rows_reference(starts, cnts, inclusive, reverse):
+        out = x_.copy()                                   # elements outside every row are whatever the kernel leaves: compare rows only
+        for s0, c in zip(starts, cnts):
+            seg = x_[s0:s0 + c]
+            if reverse:
+                seg = seg[::-1]
+            inc = np.cumsum(seg.astype(np.float64)).astype(np.float32)
+            r = inc if inclusive else np.concatenate([[0.0], inc[:-1]]).astype(np.float32)
+            out[s0:s0 + c] = r[::-1] if reverse else r
+        return out
+
+    tables = {
+        "gap": (pk_[:, 0] + (np.arange(len(pk_)) >= 1000) * 0, np.where(np.arange(len(pk_)) == 500, np.maximum(pk_[:, 1] - 1, 0), pk_[:, 1])),
+        "reordered": (pk_[::-1, 0].copy(), pk_[::-1, 1].copy()),
+        "short": (pk_[:2000, 0].copy(), pk_[:2000, 1].copy()),
+    }
+    for name, (st_, ct_) in tables.items():
+        for inclusive in (True, False):
+            for reverse in (False, True):
+                got = n(C._lazy("_packed")(t(st_.astype(np.int64)), t(ct_.astype(np.int64)), x, 0, inclusive, reverse, False))
+                ref = rows_reference(st_, ct_, inclusive, reverse)
+                covered = np.zeros(N, bool)
+                for s0, c in zip(st_, ct_):
+                    covered[s0:s0 + c] = True
+                np.testing.assert_allclose(got[covered], ref[covered], rtol=3e-5, atol=1e-4, err_msg=name)
+
+
+def test_packed_scan_at_scale_equals_keyed():
+    """2^21 elements, 60 k rows: the row-per-quarter-wave kernel against the keyed tiled kernel"""
+    from nerfacc_amd import cuda as C
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    R = 60000
+    cnts = torch.randint(0, 90, (R,), device=DEV, generator=g)
+    ri = torch.repeat_interleave(torch.arange(R, device=DEV), cnts)
+    N = ri.shape[0]
+    assert N > 1 << 21
+    starts = torch.cumsum(cnts, 0) - cnts
+    x = torch.rand(N, device=DEV, generator=g)
+    for inclusive in (True, False):
+        for reverse in (False, True):
+            a = C._lazy("_packed")(starts, cnts, x, 0, inclusive, reverse, False)
+            b = C._lazy("_keyed")(ri, x, 0, inclusive, reverse)
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+    p = C._lazy("_packed")(starts, cnts, x * 0.2 + 0.9, 1, True, False, False)
+    q = C._lazy("_keyed")(ri, x * 0.2 + 0.9, 1, True, False)
+    assert torch.allclose(p, q, rtol=1e-4, atol=1e-30)
