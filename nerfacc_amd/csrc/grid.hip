@@ -758,7 +758,7 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
 __device__ __forceinline__ void publish_wave_sums(int64_t n_iv, int64_t n_sm, int64_t n_ovf, int64_t *__restrict__ wave_sums) {
     const int64_t w_iv = wave_sum_i64(n_iv), w_sm = wave_sum_i64(n_sm), w_ov = wave_sum_i64(n_ovf);
     if (lane_id() == 0) {
-        const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         wave_sums[3 * w] = w_iv;
         wave_sums[3 * w + 1] = w_sm;
         wave_sums[3 * w + 2] = w_ov;
@@ -976,18 +976,18 @@ __device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int gr
     return (unsigned)((ballot >> group_base) & ((1ull << P) - 1ull));
 }
 
-template <bool LDS_OCC, int P, int CAP>
-__global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
-                                                                      int64_t *__restrict__ block_sums, RunStore rs)
+template <bool LDS_OCC, int P, int CAP, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
+                                                                   int64_t *__restrict__ block_sums, RunStore rs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NFA_PHASE_BEGIN();
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
     NFA_PHASE_MARK(0);
-    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][kBlock] times, then [CAP][kBlock] indices
+    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][BLK] times, then [CAP][BLK] indices
     const int tid = threadIdx.x, part = tid % P;
     const int64_t R = a.n_rays;
-    const int64_t r = (int64_t)blockIdx.x * (kBlock / P) + tid / P;
+    const int64_t r = (int64_t)blockIdx.x * (BLK / P) + tid / P;
     const bool ray_ok = r < R;
     const int64_t rr = ray_ok ? r : 0;
 
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
                        [&](float t_exit, bool o) {
                            if (n_ev == CAP) { overflow = true; return false; }
-                           ev_lds[n_ev * kBlock + tid] = t_exit;
+                           ev_lds[n_ev * BLK + tid] = t_exit;
                            ev_occ |= (o ? 1u : 0u) << n_ev;
                            ++n_ev;
                            return true;
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     NFA_PHASE_MARK(4);
     // ---- B: absolute lattice position (T_j, K_j = steps from the segment start) of every own
     // boundary; the lists stay in LDS
-    int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
+    int32_t *ev_K = (int32_t *)(ev_lds + CAP * BLK);
     int64_t K_last = 0;
     float T_last = t_seg;
     // streaming aggregates: first boundary kept apart (its samples depend on the previous part)
@@ -1141,12 +1141,12 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
         int64_t K = 0;
         float T = t_seg;
         for (int j = 0; j < n_ev; ++j) {
-            const float bound = ev_lds[j * kBlock + tid];
+            const float bound = ev_lds[j * BLK + tid];
             T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
             stuck_any = stuck_any || stuck;
             K += k_tmp;
-            ev_lds[j * kBlock + tid] = T;
-            ev_K[j * kBlock + tid] = (int32_t)K;
+            ev_lds[j * BLK + tid] = T;
+            ev_K[j * BLK + tid] = (int32_t)K;
         }
         K_last = K;
         T_last = T;
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
     if (!streaming) {
         int64_t K_prev = K_before;
         for (int j = 0; j < n_ev; ++j) {
-            const int64_t K = ev_K[j * kBlock + tid];
+            const int64_t K = ev_K[j * BLK + tid];
             if (((ev_occ >> j) & 1u) && K > K_prev) { n_sm += K - K_prev; ++n_fresh; }
             K_prev = K;
         }
@@ -1220,8 +1220,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_split_kernel(nfa_traver
             float T_prev = T_before;
             int idx = fresh_before;
             for (int j = 0; j < n_ev; ++j) {
-                const int64_t K = ev_K[j * kBlock + tid];
-                const float T = ev_lds[j * kBlock + tid];
+                const int64_t K = ev_K[j * BLK + tid];
+                const float T = ev_lds[j * BLK + tid];
                 if (((ev_occ >> j) & 1u) && K > K_prev) {
                     rs.t0[(int64_t)idx * R + r] = T_prev;
                     rs.first[(int64_t)idx * R + r] = (int32_t)first;
@@ -1548,7 +1548,7 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
 
 // workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: max_runs*R f32 ][ run first: max_runs*R i32 ][ n_runs: R u16 ]
 // one triple per wave; the finest granularity any count kernel publishes is 4 rays per wave (P = 16)
-inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * (ceil_div(n_rays > 0 ? n_rays : 1, 4) + kWavesPerBlock); }
+inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * (ceil_div(n_rays > 0 ? n_rays : 1, 4) + 2 * kWavesPerBlock); }
 // [ block sums | run records | n_runs ] [ totals: 4 int64, the device copy of what nfa_traverse_offsets stores in args.totals ]
 inline int64_t ws_totals_offset(int64_t n_rays) {
     const int64_t R = n_rays > 0 ? n_rays : 1;
@@ -1697,15 +1697,22 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 // sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
 // be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
 // LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
-struct SplitPlan { int P, cap, lds; GridView gv; };
+struct SplitPlan { int P, cap, lds, blk; GridView gv; };
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
     p.P = count_lanes_per_ray(a, true);
     p.cap = 16;      // (8-entry lists at P = 16 overflow into the streaming mode on a trained scene: 80 us instead of 44)
     if (const char *e = getenv("NFA_SPLIT_CAP")) { const int v = atoi(e); if (v == 8 || v == 16) p.cap = v; }   // tuning knob
     p.lds = 0;
+    p.blk = kBlock;
     if (p.P <= 1) return p;
-    p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
+    // 512-thread workgroups for the 16-lane variant from 3 k rays (one workgroup per CU, 32 rays share one staged grid
+    // image: 37.7 vs 39.6 us at 6.5 k rays; below ~3 k rays the 256-thread form spreads over more CUs and wins);
+    // NFA_SPLIT_BLK = 256 | 512 overrides
+    if (p.P == 16 && p.cap == 16 && a->n_rays >= 3072) p.blk = 512;
+    if (const char *e = getenv("NFA_SPLIT_BLK")) { const int v = atoi(e); if (v == 256 || (v == 512 && p.P == 16 && p.cap == 16)) p.blk = v; }
+    p.gv = make_view(a, p.cap * p.blk * 8, &p.lds);
+    if (p.gv.lds_compact_cap == 0 && p.blk != kBlock) { p.blk = kBlock; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
     if (p.gv.lds_compact_cap == 0) {
         p.P = count_lanes_per_ray(a, false);
         p.cap = 32;
@@ -1730,13 +1737,16 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         const int lds = plan.lds;
         const GridView &gv = plan.gv;
         const bool lds_occ = gv.lds_compact_cap > 0;
-        const unsigned nbs = (unsigned)ceil_div(a->n_rays, kBlock / P);
+        const unsigned nbs = (unsigned)ceil_div(a->n_rays, plan.blk / P);
 #define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
     do {                                                                                                                       \
         if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \
         hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
     } while (0)
-        if (lds_occ) {
+        if (lds_occ && plan.blk == 512) {
+            if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
+        } else if (lds_occ) {
             if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
             else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16);
             else if (plan.cap == 16) NFA_LAUNCH_SPLIT(true, 16, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
@@ -1776,9 +1786,10 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     hipStream_t s = (hipStream_t)stream;
     if (a->n_rays == 0) { (void)hipMemsetAsync(a->totals, 0, 4 * sizeof(int64_t), s); return NFA_OK; }
     NFA_REQUIRE(workspace != nullptr, "traverse_offsets: workspace is NULL");
-    const int P = plan_split(a).P;
+    const SplitPlan plan = plan_split(a);
+    const int P = plan.P;
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    const int64_t n_sums = ceil_div(a->n_rays, kBlock / P) * kWavesPerBlock;      // one triple per wave of the count launch
+    const int64_t n_sums = ceil_div(a->n_rays, plan.blk / P) * (plan.blk / kWave);      // one triple per wave of the count launch
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
                        a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals,
                        (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)));
