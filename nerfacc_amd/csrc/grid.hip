@@ -976,7 +976,10 @@ __device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int gr
     return (unsigned)((ballot >> group_base) & ((1ull << P) - 1ull));
 }
 
-template <bool LDS_OCC, int P, int CAP, int BLK = kBlock>
+// XT: the plane-crossing times of the ray's three axes are written out in LDS (lanes 1..3 of the ray walk the x / y / z chains
+// with plain adds — exact by construction — n + 1 values each); the walk's end times and every part's seam restart are then
+// reads and two binary searches instead of closed forms (512-thread form only: the arrays need 1.5 KB per ray).
+template <bool LDS_OCC, int P, int CAP, int BLK = kBlock, bool XT = false>
 __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
                                                                    int64_t *__restrict__ block_sums, RunStore rs)
 {
@@ -1017,7 +1020,48 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     // crossings until each axis reaches its overflow index
     const int nx = s.sx ? (s.ox - s.cx) * s.sx : 1, ny = s.sy ? (s.oy - s.cy) * s.sy : 1, nz = s.sz ? (s.oz - s.cz) * s.sz : 1;
     float Tx, Ty, Tz;      // time of the last crossing of each axis: when the walk ends
-    if (P >= 4) {
+    // XT layout of a ray: x crossings at [0, rx], y at [rx + 1, rx + ry + 1], z behind them (n + 1 values per axis)
+    const int xt_oy = gv.res[0] + 1, xt_oz = gv.res[0] + gv.res[1] + 2;
+    float *xt_ray = nullptr;
+    if (XT) xt_ray = (float *)(smem + occ.bytes) + 2 * CAP * BLK + (tid / P) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
+    if (XT) {
+        const float h = dt * 0.5f;
+        if (live && part == 0) {
+            // the lattice from `near` to the segment start (nfa_lattice_until's verified under-estimate, then single steps)
+            float t = near;
+            if (near + h < seg_lo) {
+                const float est = (seg_lo - h - near) / dt;
+                if (est > 24.0f && est < 1.0e9f) {
+                    const int64_t guess = (int64_t)est;
+                    const float v = nfa_lattice_advance(near, dt, guess - 2 - (guess >> 6), nullptr);
+                    if (v + h < seg_lo) t = v;
+                }
+            }
+            while (t + h < seg_lo) {
+                const float nt = t + dt;
+                if (nt == t) { stuck_any = true; break; }
+                t = nt;
+            }
+            t_seg = t;
+        }
+        if (live && part >= 1 && part <= 3) {
+            float t = part == 1 ? s.tx : (part == 2 ? s.ty : s.tz);
+            const float dd = part == 1 ? s.dx : (part == 2 ? s.dy : s.dz);
+            int n = part == 1 ? nx : (part == 2 ? ny : nz);
+            const int cap_n = part == 1 ? gv.res[0] : (part == 2 ? gv.res[1] : gv.res[2]);
+            n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
+            float *dst = xt_ray + (part == 1 ? 0 : (part == 2 ? xt_oy : xt_oz));
+            for (int i = 0; i <= n; ++i) { dst[i] = t; t = t + dd; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        t_seg = __shfl(t_seg, group_base, 64);
+        const bool ok3 = live && nx > 0 && ny > 0 && nz > 0 && nx <= gv.res[0] && ny <= gv.res[1] && nz <= gv.res[2];
+        Tx = ok3 ? xt_ray[nx - 1] : 0.0f;
+        Ty = ok3 ? xt_ray[xt_oy + ny - 1] : 0.0f;
+        Tz = ok3 ? xt_ray[xt_oz + nz - 1] : 0.0f;
+    } else if (P >= 4) {
         // FOUR closed-form jumps per ray — the lattice from `near` to the segment start and the
         // last crossing of x, y, z — run as ONE call, on lanes 0..3 of the ray's group (a wave pays
         // for a call once, however many of its lanes are in it).  (Folding the segment-start jump
@@ -1072,7 +1116,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     // index bookkeeping the closed forms rely on; anything odd (a final voxel "behind" the first
     // one through float error) is left to the serial walk
     NFA_PHASE_MARK(2);
-    const bool weird = live && (nx <= 0 || ny <= 0 || nz <= 0);
+    const bool weird = live && (nx <= 0 || ny <= 0 || nz <= 0 || (XT && (nx > gv.res[0] || ny > gv.res[1] || nz > gv.res[2])));
     // parts whose range is empty do nothing; a part with j_begin == 0 starts at the segment start
     bool part_live = live && !weird && j_begin < j_end;
     bool have_run = false, run_occ = false;
@@ -1083,9 +1127,39 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     if (part_live && j_begin > 0) {
         const float t0m = m_rank == 2 ? s.tx : (m_rank == 1 ? s.ty : s.tz);
         const float dm = m_rank == 2 ? s.dx : (m_rank == 1 ? s.dy : s.dz);
-        const float T_seam = nfa_lattice_advance(t0m, dm, j_begin - 1, nullptr);    // time of major crossing j_begin
+        const int xt_om = m_rank == 2 ? 0 : (m_rank == 1 ? xt_oy : xt_oz);
+        const float T_seam = XT ? xt_ray[xt_om + j_begin - 1]
+                                : nfa_lattice_advance(t0m, dm, j_begin - 1, nullptr);    // time of major crossing j_begin
         if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;
-        else {
+        else if (XT) {
+            // crossings of the two minor axes that precede the seam: lower bounds in their arrays (both searches in one
+            // loop of 8 rounds: <= 129 entries), the pending crossing is the entry found
+            const bool xm = m_rank == 2, zm = m_rank == 0;
+            const float *A1 = xt_ray + (xm ? xt_oy : 0), *A2 = xt_ray + (zm ? xt_oy : xt_oz);
+            const int r1 = xm ? 1 : 2, r2 = zm ? 1 : 0;
+            const int n1 = xm ? ny : nx, n2 = zm ? ny : nz;
+            int lo1 = 0, hi1 = n1, lo2 = 0, hi2 = n2;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                const float v1 = A1[m1], v2 = A2[m2];
+                if (lo1 < hi1) { if (crossing_precedes(v1, r1, T_seam, m_rank)) lo1 = m1 + 1; else hi1 = m1; }
+                if (lo2 < hi2) { if (crossing_precedes(v2, r2, T_seam, m_rank)) lo2 = m2 + 1; else hi2 = m2; }
+            }
+            const int c1 = lo1, c2 = lo2;
+            const float pend1 = A1[c1], pend2 = A2[c2];
+            if (!xm) { s.cx += c1 * s.sx; s.tx = pend1; }
+            if (xm) { s.cy += c1 * s.sy; s.ty = pend1; }
+            if (zm) { s.cy += c2 * s.sy; s.ty = pend2; }
+            if (!zm) { s.cz += c2 * s.sz; s.tz = pend2; }
+            int px = s.cx, py = s.cy, pz = s.cz;
+            if (m_rank == 2) { px += (j_begin - 1) * s.sx; s.cx += j_begin * s.sx; s.tx = T_seam + s.dx; }
+            else if (m_rank == 1) { py += (j_begin - 1) * s.sy; s.cy += j_begin * s.sy; s.ty = T_seam + s.dy; }
+            else { pz += (j_begin - 1) * s.sz; s.cz += j_begin * s.sz; s.tz = T_seam + s.dz; }
+            have_run = true;
+            run_occ = occupied(gv, occ, cache, 0, px, py, pz);
+            run_exit = fminf(T_seam, seg_hi);
+        } else {
             // the two minor axes, picked with selects so that every lane of the wave runs the SAME two
             // closed-form counts whatever its ray's major axis is (three `if (m_rank != k)` blocks made
             // a wave with mixed major axes execute all three): minor 1 is x (y for an x-major ray),
@@ -1509,7 +1583,7 @@ int validate_traverse(const nfa_traverse_args *a) {
 constexpr int kLdsBudget = 96 * 1024;
 constexpr int kEvBytes = kEvCap * kBlock * 4 * 2;   // boundary times + lattice indices
 
-GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
+GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int budget = kLdsBudget) {
     GridView gv;
     const PackedLayout L = packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]);
     gv.bricks = a->bricks;
@@ -1525,14 +1599,14 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes) {
     gv.n_words = (int)L.n_words;
     const int64_t w4 = ((int64_t)L.n_words + 3) & ~3ll;
     const int64_t words_bytes = 2 * w4 * 4;
-    const int64_t room = (int64_t)kLdsBudget - ev_bytes - 16 - words_bytes;
+    const int64_t room = (int64_t)budget - ev_bytes - 16 - words_bytes;
     // full LDS image only when the caller told us how many bricks are non-empty and they all fit
     const int64_t need = a->n_nonempty_bricks >= 0 ? (a->n_nonempty_bricks > 0 ? a->n_nonempty_bricks : 1) : -1;
     if (need > 0 && room >= need * 8) {
         gv.lds_words = (int)L.n_words;
         gv.lds_compact_cap = (int)need;
         *lds_bytes = (int)(((words_bytes + need * 8 + 15) & ~15ll) + ev_bytes);
-    } else if (w4 * 4 <= 16 * 1024 && (int64_t)kLdsBudget - ev_bytes - 16 >= w4 * 4) {
+    } else if (w4 * 4 <= 16 * 1024 && (int64_t)budget - ev_bytes - 16 >= w4 * 4) {
         // bricks from L2; a small bitmap of non-empty bricks (<= 16 KiB: up to 128 K bricks) is
         // still staged and answers the empty bricks
         gv.lds_words = (int)L.n_words;
@@ -1697,7 +1771,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 // sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
 // be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
 // LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
-struct SplitPlan { int P, cap, lds, blk; GridView gv; };
+struct SplitPlan { int P, cap, lds, blk, xt; GridView gv; };
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
     p.P = count_lanes_per_ray(a, true);
@@ -1705,13 +1779,20 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     if (const char *e = getenv("NFA_SPLIT_CAP")) { const int v = atoi(e); if (v == 8 || v == 16) p.cap = v; }   // tuning knob
     p.lds = 0;
     p.blk = kBlock;
+    p.xt = 0;
     if (p.P <= 1) return p;
     // 512-thread workgroups for the 16-lane variant from 3 k rays (one workgroup per CU, 32 rays share one staged grid
     // image: 37.7 vs 39.6 us at 6.5 k rays; below ~3 k rays the 256-thread form spreads over more CUs and wins);
     // NFA_SPLIT_BLK = 256 | 512 overrides
     if (p.P == 16 && p.cap == 16 && a->n_rays >= 3072) p.blk = 512;
     if (const char *e = getenv("NFA_SPLIT_BLK")) { const int v = atoi(e); if (v == 256 || (v == 512 && p.P == 16 && p.cap == 16)) p.blk = v; }
-    p.gv = make_view(a, p.cap * p.blk * 8, &p.lds);
+    // crossing-time arrays (512-thread form only; NFA_SPLIT_XT = 0 switches them off)
+    p.xt = p.blk == 512 && !(getenv("NFA_SPLIT_XT") && atoi(getenv("NFA_SPLIT_XT")) == 0);
+    const int xt_bytes = p.xt ? (p.blk / p.P) * (a->res[0] + a->res[1] + a->res[2] + 3) * 4 : 0;
+    // (the 512-thread form is alone on its CU: it may take the whole 160 KB)
+    const int budget = p.blk == 512 ? 156 * 1024 : kLdsBudget;
+    p.gv = make_view(a, p.cap * p.blk * 8 + xt_bytes, &p.lds, budget);
+    if (p.gv.lds_compact_cap == 0 && p.xt) { p.xt = 0; p.gv = make_view(a, p.cap * p.blk * 8, &p.lds, budget); }
     if (p.gv.lds_compact_cap == 0 && p.blk != kBlock) { p.blk = kBlock; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
     if (p.gv.lds_compact_cap == 0) {
         p.P = count_lanes_per_ray(a, false);
@@ -1743,7 +1824,10 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \
         hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
     } while (0)
-        if (lds_occ && plan.blk == 512) {
+        if (lds_occ && plan.blk == 512 && plan.xt) {
+            if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true>, lds)) return rc;
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
+        } else if (lds_occ && plan.blk == 512) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ) {

@@ -137,3 +137,30 @@ def test_packed_scan_at_scale_equals_keyed():
     p = C._lazy("_packed")(starts, cnts, x * 0.2 + 0.9, 1, True, False, False)
     q = C._lazy("_keyed")(ri, x * 0.2 + 0.9, 1, True, False)
     assert torch.allclose(p, q, rtol=1e-4, atol=1e-30)
+
+
+@pytest.mark.parametrize("env", [{"NFA_SPLIT_BLK": "512"}, {"NFA_SPLIT_BLK": "512", "NFA_SPLIT_XT": "0"}, {"NFA_SPLIT_BLK": "256"}])
+def test_count_pass_workgroup_forms(monkeypatch, env):
+    """the 16-lanes-per-ray count pass runs in 256-thread workgroups (closed-form seam restart), in 512-thread ones, and in
+    512-thread ones with the plane-crossing times written out in LDS (default from 3 k rays): every form on the adversarial
+    fuzz cases, the degenerate grids, the overflow paths and the reference fixture"""
+    import os
+
+    import test_gpu_fuzz as F
+    import test_gpu_grid as G
+    import test_k2_reference as T
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("NFA_SPLIT_P", "16")
+    for seed in range(6):
+        F.test_fuzz_single_level(seed, 700)
+    F.test_fuzz_degenerate_grids()
+    F.test_many_transitions_overflow_paths()
+    G.test_traverse_lego_like_128_bit_exact_and_invariants()
+    G.test_traverse_near_far_single_cell()
+    k2 = dict(np.load(os.path.join(T.GOLD, "k2_reference.npz")))
+    for name in ["m1_sphere", "lego_4k", "near_far", "degenerate"]:
+        T.test_hip_sampling_reproduces_reference_k2(name, k2)
+    for name in ["ref_test_grid", "m1_noise", "lego_4k", "non_cubic", "steps_limit"]:
+        T.test_hip_reproduces_reference_k2(name, k2)
