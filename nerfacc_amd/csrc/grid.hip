@@ -1025,33 +1025,48 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     float *xt_ray = nullptr;
     if (XT) xt_ray = (float *)(smem + occ.bytes) + 2 * CAP * BLK + (tid / P) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
     if (XT) {
+        static_assert(!XT || P == 16, "the crossing-time arrays are filled by lanes 1..15 of a ray's group");
+        // ONE closed-form call per ray group: lane 0 jumps the lattice from `near` to the segment start, lanes 1..15 jump to
+        // the first entry of their fifth of the x / y / z chain (5 lanes per axis); then short plain-add loops: lane 0's last
+        // few lattice steps, the others' <= 26 chain entries (exact by construction).
         const float h = dt * 0.5f;
+        float adv_t = near, adv_d = dt;
+        int64_t adv_j = 0;
+        bool jump = false;
+        int i_lo = 0, i_hi = 0;
+        float *dst = xt_ray;
+        if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
+            const float est = (seg_lo - h - near) / dt;
+            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - 2 - (guess >> 6); jump = true; }
+        }
+        if (live && part >= 1) {
+            const int ax = (part - 1) / 5, k = (part - 1) % 5;
+            adv_t = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
+            adv_d = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
+            int n = ax == 0 ? nx : (ax == 1 ? ny : nz);
+            const int cap_n = gv.res[ax];
+            n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
+            const int L = (n + 1 + 4) / 5;
+            i_lo = k * L;
+            i_hi = (k + 1) * L < n + 1 ? (k + 1) * L : n + 1;
+            adv_j = i_lo;
+            jump = i_lo > 0 && i_lo < i_hi;
+            dst = xt_ray + (ax == 0 ? 0 : (ax == 1 ? xt_oy : xt_oz));
+        }
+        float adv_v = adv_t;
+        if (jump) adv_v = nfa_lattice_advance(adv_t, adv_d, adv_j, nullptr);
         if (live && part == 0) {
-            // the lattice from `near` to the segment start (nfa_lattice_until's verified under-estimate, then single steps)
             float t = near;
-            if (near + h < seg_lo) {
-                const float est = (seg_lo - h - near) / dt;
-                if (est > 24.0f && est < 1.0e9f) {
-                    const int64_t guess = (int64_t)est;
-                    const float v = nfa_lattice_advance(near, dt, guess - 2 - (guess >> 6), nullptr);
-                    if (v + h < seg_lo) t = v;
-                }
-            }
+            if (jump && adv_v + h < seg_lo) t = adv_v;
             while (t + h < seg_lo) {
                 const float nt = t + dt;
                 if (nt == t) { stuck_any = true; break; }
                 t = nt;
             }
             t_seg = t;
-        }
-        if (live && part >= 1 && part <= 3) {
-            float t = part == 1 ? s.tx : (part == 2 ? s.ty : s.tz);
-            const float dd = part == 1 ? s.dx : (part == 2 ? s.dy : s.dz);
-            int n = part == 1 ? nx : (part == 2 ? ny : nz);
-            const int cap_n = part == 1 ? gv.res[0] : (part == 2 ? gv.res[1] : gv.res[2]);
-            n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
-            float *dst = xt_ray + (part == 1 ? 0 : (part == 2 ? xt_oy : xt_oz));
-            for (int i = 0; i <= n; ++i) { dst[i] = t; t = t + dd; }
+        } else if (live) {
+            float t = adv_v;
+            for (int i = i_lo; i < i_hi; ++i) { dst[i] = t; t = t + adv_d; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
