@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
         float *dst = xt_ray;
         if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
             const float est = (seg_lo - h - near) / dt;
-            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - 2 - (guess >> 6); jump = true; }
+            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - nfa_jump_margin(guess); jump = true; }
         }
         if (live && part >= 1) {
             const int ax = (part - 1) / 5, k = (part - 1) % 5;
@@ -1053,8 +1053,10 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
             jump = i_lo > 0 && i_lo < i_hi;
             dst = xt_ray + (ax == 0 ? 0 : (ax == 1 ? xt_oy : xt_oz));
         }
+        NFA_PHASE_MARK(9);
         float adv_v = adv_t;
         if (jump) adv_v = nfa_lattice_advance(adv_t, adv_d, adv_j, nullptr);
+        NFA_PHASE_MARK(10);
         if (live && part == 0) {
             float t = near;
             if (jump && adv_v + h < seg_lo) t = adv_v;
@@ -1068,6 +1070,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
             float t = adv_v;
             for (int i = i_lo; i < i_hi; ++i) { dst[i] = t; t = t + adv_d; }
         }
+        NFA_PHASE_MARK(11);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
         bool jump = false;
         if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
             const float est = (seg_lo - h - near) / dt;
-            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - 2 - (guess >> 6); jump = true; }
+            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - nfa_jump_margin(guess); jump = true; }
         }
         if (part >= 1 && part <= 3) {
             adv_t = part == 1 ? s.tx : (part == 2 ? s.ty : s.tz);

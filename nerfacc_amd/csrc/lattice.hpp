@@ -44,7 +44,12 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
     // adds are cheaper there than the per-binade bookkeeping below.
     if (d_ok) {
         const float small = d * 32.0f;
-        while (j > 0 && t < small && t > -small) { t = t + d; --j; }
+        if (t > -small) {                               // (t only grows: checked once; a 32-bit counter keeps the loop at four instructions)
+            const int lim = j < 64 ? (int)j : 64;
+            int cnt = 0;
+            while (cnt < lim && t < small) { t = t + d; ++cnt; }
+            j -= cnt;
+        }
     }
     // One trip = either n >= 1 steps inside the current binade (integer multiply-add) or one real
     // fp32 add (binade crossings, ties on an odd mantissa, anything irregular).  Both candidates
@@ -95,6 +100,15 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
     return t;
 }
 
+// How far below a real-number estimate of the step count a jump has to aim so that it (almost) never overshoots: inside a
+// binade every step makes the same rounding error (<= half an ulp), so k steps drift by at most k/2 ulps = (k 2^-12)^2 steps.
+// Only speed depends on it: a jump is used only if the value it lands on is verified to be short of the target.
+NFA_HD int64_t nfa_jump_margin(int64_t guess)
+{
+    const int64_t m = (guess >> 12) + 1;
+    return 2 + m * m;
+}
+
 // The loop  `while (t + d/2 < target) { nt = t + d; if (nt == t) {stuck} t = nt; ++k; }`
 // (grid.cu:157-161, 199-203, 208-216 with constant dt): returns the final t, the number of
 // steps in *steps, and whether the walk got stuck before reaching the target.
@@ -143,7 +157,7 @@ NFA_HD float nfa_lattice_until(float t, float d, float target, int64_t *steps, b
         const float est = (target - h - t) / d;
         if (est > 24.0f && est < 1.0e9f) {
             const int64_t guess = (int64_t)est;
-            const int64_t j = guess - 2 - (guess >> 6);
+            const int64_t j = guess - nfa_jump_margin(guess);
             int64_t took = 0;
             const float tj = nfa_lattice_advance(t, d, j, &took);
             if (tj + h < target) { t = tj; k = took; }

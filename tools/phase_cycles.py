@@ -82,7 +82,11 @@ names = ["stage occupancy into LDS (+barrier)", "ray loads, slab test, lattice t
          "end-of-walk times (3 closed forms), major axis", "seam restart (closed-form DDA state at the part start)",
          "A: voxel walk of the part", "B: lattice position of own boundaries", "stitch across the P lanes + run records",
          "per-ray outputs (+ serial fallback)", "block sums"]
-tot = sum(buf[i] for i in range(9))
+tot = sum(buf[i] for i in range(12))
 print(f"rays {n}  P={os.environ.get('NFA_SPLIT_P', 'auto')}  waves/launch {waves / iters:.0f}  cycles/wave {tot / max(waves, 1):.0f}")
 for i, nm in enumerate(names):
     print(f"  {buf[i] / max(waves, 1):9.0f} cyc  {100.0 * buf[i] / max(tot, 1):5.1f} %  {nm}")
+for i, nm in ((9, "  (crossing-time form) before the closed-form call"), (10, "  (crossing-time form) the closed-form call"),
+              (11, "  (crossing-time form) last lattice steps / chain segments")):
+    if buf[i]:
+        print(f"  {buf[i] / max(waves, 1):9.0f} cyc  {100.0 * buf[i] / max(tot, 1):5.1f} %  {nm}")
