@@ -923,7 +923,7 @@ __device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC>
 constexpr int kPhaseSlots = 16384;
 __device__ unsigned long long g_phase_cycles[kPhaseSlots][16];
 __device__ unsigned long long g_phase_max_wave = 0, g_phase_hist[16] = {0};     // slowest wave; histogram of wave totals in 16 k-cycle bins
-__device__ unsigned long long g_phase_slow[16] = {0};                           // phase sums over the waves slower than 88 k cycles ([15] = how many)
+__device__ unsigned long long g_phase_slow[16] = {0};                           // phase sums over the waves slower than 60 k cycles ([15] = how many)
 #define NFA_PHASE_BEGIN() unsigned long long ph_[16] = {0}; unsigned long long phase_t_ = __builtin_readcyclecounter(); const unsigned long long phase_t0_ = phase_t_
 #define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
 #define NFA_PHASE_END()                                                                        \
@@ -933,7 +933,7 @@ __device__ unsigned long long g_phase_slow[16] = {0};                           
             const unsigned long long tot_ = __builtin_readcyclecounter() - phase_t0_;          \
             atomicMax(&g_phase_max_wave, tot_);                                                \
             atomicAdd(&g_phase_hist[tot_ >> 14 > 15 ? 15 : tot_ >> 14], 1ull);                 \
-            if (tot_ > 88000ull) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_phase_slow[i_], ph_[i_]); atomicAdd(&g_phase_slow[15], 1ull); } \
+            if (tot_ > 60000ull) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_phase_slow[i_], ph_[i_]); atomicAdd(&g_phase_slow[15], 1ull); } \
         }                                                                                     \
         if (lane_id() == 0 && slot_ < kPhaseSlots) {                                          \
             ph_[14] = phase_t0_; ph_[15] = 1;                                                  \
@@ -1268,6 +1268,10 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     bad = true;
 #endif
     bad = group_bits<P>(__ballot(bad), group_base) != 0u;
+#ifdef NFA_PHASE_CYCLES
+    ph_[12] = __popcll(__ballot(bad && ray_ok && part == 0));          // rays of this wave that take the serial walk
+    ph_[13] = __popcll(__ballot(streaming && ray_ok && part == 0));    // rays in streaming mode
+#endif
     // boundary before this part's first one: the nearest earlier part that has boundaries
     const unsigned ev_parts = group_bits<P>(__ballot(n_ev > 0), group_base);     // bit p: part p of this ray has boundaries
     int64_t K_before = 0;
@@ -1981,8 +1985,9 @@ extern "C" __attribute__((visibility("default"))) int nfa_debug_phase_cycles(uns
             fprintf(stderr, "\n");
             unsigned long long slow[16];
             if (hipMemcpyFromSymbol(slow, HIP_SYMBOL(nfa::g_phase_slow), sizeof(slow)) == hipSuccess && slow[15]) {
-                fprintf(stderr, "[phase] %llu waves slower than 88 k cycles, average per phase:", slow[15]);
-                for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", slow[i] / slow[15]);
+                fprintf(stderr, "[phase] %llu waves slower than 60 k cycles, average per phase:", slow[15]);
+                for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", slow[i] / slow[15]);
+                fprintf(stderr, " | serial rays %llu, streaming rays %llu in those waves", slow[12], slow[13]);
                 fprintf(stderr, "\n");
             }
         }
