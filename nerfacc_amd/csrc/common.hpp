@@ -384,7 +384,7 @@ __device__ __forceinline__ void walk_rays_fwd(const int64_t *__restrict__ keys, 
     const int64_t ne = nb + tile < n ? nb + tile : n;
     int64_t lim = ne + (spec ? CH : 0);                     // chunks below `lim` are requested ahead
     if (lim > n) lim = n;
-    RayChunk<E, P> q[PF + 1];
+    RayChunk<E, P> q[PF + 1] = {};            // (slots past the last requested chunk are copied around by the shifts below, never used)
     q[0] = fetch_chunk<E, P>(keys, n, nb, lane, load);
 #pragma unroll
     for (int d = 1; d < PF; ++d)
@@ -458,7 +458,7 @@ __device__ __forceinline__ void walk_rays_bwd(const int64_t *__restrict__ keys, 
     int64_t lim = nb - (spec ? CH : 0);                     // chunks at or above `lim` are requested ahead
     if (lim < 0) lim = 0;
     const int64_t top = ((ne - 1) / CH) * CH;
-    RayChunk<E, P> q[PF + 1];
+    RayChunk<E, P> q[PF + 1] = {};            // (slots past the last requested chunk are copied around by the shifts below, never used)
     q[0] = fetch_chunk<E, P>(keys, n, top, lane, load);
 #pragma unroll
     for (int d = 1; d < PF; ++d)
