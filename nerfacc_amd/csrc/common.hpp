@@ -527,7 +527,9 @@ inline bool aligned16(std::initializer_list<const void *> ptrs) {
 }
 inline TilePlan pick_plan(int64_t n, bool vec_ok = true) {
     TilePlan p;
-    p.e = n >= ((int64_t)1 << 22) ? 4 : 1;
+    // (2 samples per lane from 4 M samples: measured equal to 4 per lane within noise for every kernel except rendering_bwd,
+    // which needs 170 VGPRs at 4 and runs 13-15 % faster at 2: profiles/r02_streaming.md)
+    p.e = n >= ((int64_t)1 << 22) ? 2 : 1;
     if (const char *s = getenv("NFA_E")) {               // tuning knobs
         const int v = atoi(s);
         if (v == 1 || v == 2 || v == 4) p.e = v;
