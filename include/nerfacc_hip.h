@@ -157,6 +157,9 @@ int nfa_traverse_count(const nfa_traverse_args *args, void *workspace, void *str
  * the counts, totals = {n_edges, n_samples, rays whose runs did not fit (re-traversed by pass 2), 0}.
  * Same args and workspace as the nfa_traverse_count call it follows. */
 int nfa_traverse_offsets(const nfa_traverse_args *args, const void *workspace, void *stream);
+/* The same; totals[3] receives `stamp` (the plain call stores 0 there), last and behind a system-scope fence: a host that
+ * polls that word in coherent pinned memory may read the totals as soon as it sees the stamp. */
+int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const void *workspace, int64_t stamp, void *stream);
 /* pass 2 (grid.cu:445 / the single over-allocated pass :375): write edges / samples at
  * iv_starts / sm_starts.
  * workspace != NULL: the workspace nfa_traverse_count filled for the SAME args, with
@@ -252,6 +255,14 @@ int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, co
                            int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends,
                            uint8_t *out_mask /* [n] nullable */, int64_t *n_out, void *workspace,
                            void *stream);
+/* The same with a completion stamp for callers that poll instead of synchronising the stream: n_out is [2] in coherent pinned
+ * host memory and the kernel stores `stamp` (non-zero) into n_out[1] right after the count, behind a system-scope fence — the
+ * host may read n_out[0] as soon as it sees the stamp, while the compaction itself is still running (inputs of fewer than
+ * 2^24 tiles; beyond that the stamp never comes: fall back to a stream synchronisation after a bounded wait). */
+int nfa_visibility_compact_stamped(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                   const float *sigmas, int32_t from_alpha, int64_t n, float early_stop_eps, float alpha_thre,
+                                   int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, uint8_t *out_mask,
+                                   int64_t *n_out, int64_t stamp, void *workspace, void *stream);
 
 /* accumulate_along_rays / accumulate_along_rays_ (volrend.py:497-587):
  * outputs[r, :] += sum_{i in r} w_i * values[i, :]  (values NULL: D = 1, values = 1). */

@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     const int64_t *__restrict__ iv_cnts, int64_t *__restrict__ iv_starts,
     const int64_t *__restrict__ sm_cnts, int64_t *__restrict__ sm_starts,
     int64_t n_rays, const int64_t *__restrict__ block_sums, int sums_per_block, int64_t n_sums,
-    int64_t *__restrict__ totals, int64_t *__restrict__ totals_dev)
+    int64_t *__restrict__ totals, int64_t *__restrict__ totals_dev, int64_t stamp)
 {
     __shared__ int64_t lds[kWavesPerBlock];
     __shared__ int64_t base[2];
@@ -1444,7 +1444,13 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
         for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
         int64_t tov;
         block_excl_scan_i64(ov, lds, tov);
-        if (threadIdx.x == 0) { totals[2] = tov; totals[3] = 0; totals_dev[2] = tov; totals_dev[3] = 0; }
+        if (threadIdx.x == 0) {
+            totals[2] = tov; totals_dev[2] = tov; totals_dev[3] = 0;
+            // totals[3]: the caller's completion stamp, stored LAST and behind a system-scope fence — a host that polls this word
+            // in (coherent) pinned memory may read the three totals as soon as it sees the stamp (nfa_traverse_offsets_stamped)
+            __threadfence_system();
+            totals[3] = stamp;
+        }
     }
 }
 
@@ -1887,6 +1893,11 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
 
 NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *workspace, void *stream)
 {
+    return nfa_traverse_offsets_stamped(a, workspace, 0, stream);
+}
+
+NFA_EXPORT int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const void *workspace, int64_t stamp, void *stream)
+{
     if (int rc = validate_traverse(a)) return rc;
     NFA_REQUIRE(a->totals != nullptr, "traverse_offsets: totals is NULL");
     hipStream_t s = (hipStream_t)stream;
@@ -1898,7 +1909,7 @@ NFA_EXPORT int nfa_traverse_offsets(const nfa_traverse_args *a, const void *work
     const int64_t n_sums = ceil_div(a->n_rays, plan.blk / P) * (plan.blk / kWave);      // one triple per wave of the count launch
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
                        a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals,
-                       (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)));
+                       (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)), stamp);
     return check_launch("traverse_offsets_kernel");
 }
 

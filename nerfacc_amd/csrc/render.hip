@@ -199,7 +199,7 @@ constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
-    const int64_t *__restrict__ tile_rng, int mode, int64_t n_tiles, int64_t *__restrict__ n_out,
+    const int64_t *__restrict__ tile_rng, int mode, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t stamp,
     int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
     const int64_t w_ = wave_index();
@@ -219,13 +219,13 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
         }
         for (; j < w_; j += 64) p += tile_offs[j];
         dst = wave_sum_i64(p);
-        if (w_ == n_tiles - 1 && lane == 0) *n_out = dst + tile_offs[w_];
+        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst + tile_offs[w_]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
     } else if (mode == 2) {
         const int64_t g = w_ >> 6;
         int64_t p = 0;
         for (int64_t j = lane; j < g; j += 64) p += group_sums[j];
         dst = wave_sum_i64(p) + tile_offs[w_];
-        if (w_ == n_tiles - 1 && lane == 0) *n_out = dst - tile_offs[w_] + group_sums[g];
+        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst - tile_offs[w_] + group_sums[g]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
     } else {
         dst = tile_offs[w_];
     }
@@ -649,6 +649,16 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
                                       float *out_t_ends, uint8_t *out_mask, int64_t *n_out, void *workspace,
                                       void *stream)
 {
+    return nfa_visibility_compact_stamped(ray_indices, t_starts, t_ends, dens, from_alpha, n, early_stop_eps, alpha_thre, out_ray_indices,
+                                          out_t_starts, out_t_ends, out_mask, n_out, 0, workspace, stream);
+}
+
+NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                              const float *dens, int32_t from_alpha, int64_t n, float early_stop_eps,
+                                              float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
+                                              float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace,
+                                              void *stream)
+{
     NFA_REQUIRE(n >= 0, "visibility_compact: n < 0");
     NFA_REQUIRE(n_out != nullptr, "visibility_compact: n_out is NULL");
     hipStream_t s = (hipStream_t)stream;
@@ -675,7 +685,7 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
         if (!out_ray_indices) return NFA_OK;
     }
     hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, tile_rng, mode, T, n_out,
+                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, tile_rng, mode, T, n_out, stamp,
                        out_ray_indices, out_t_starts, out_t_ends);
     return check_launch("visibility_compact_kernel");
 }

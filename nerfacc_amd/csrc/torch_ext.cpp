@@ -14,6 +14,8 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <chrono>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -137,12 +139,36 @@ int64_t *host_ints(int device, hipStream_t s) {
     auto it = slots.find(key);
     if (it != slots.end()) return it->second;
     int64_t *p = nullptr;
-    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
-                "nerfacc_amd: hipHostMalloc failed");
+    // coherent (fine-grained) pinned memory: a kernel's store is visible to a polling host while the kernel runs (wait_stamp)
+    if (hipHostMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(int64_t), hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+                    "nerfacc_amd: hipHostMalloc failed");
+    }
     for (int i = 0; i < 8; ++i) p[i] = 0;
     if (slots.size() > 64) slots.clear();      // (slots of dead streams are leaked: 64 B each)
     slots[key] = p;
     return p;
+}
+
+// The read-backs of this file wait for ONE word: the kernel that produces the integers stores the caller's stamp behind them
+// (system-scope fence), and the host polls that word instead of asking the runtime to synchronise the stream — 1-2 us instead of
+// the 8-9 us a hipStreamSynchronize takes to come back (tools/sync_latency.py), and the host is released when the integers exist,
+// not when the kernel that wrote them (and goes on to write its outputs) has finished.  Bounded: after ~2 ms of polling the
+// stream is synchronised the ordinary way (a launch that failed, a size range whose kernels do not stamp).
+inline int64_t next_stamp() {
+    thread_local int64_t seq = 0;
+    return ++seq;
+}
+inline void wait_stamp(const int64_t *slot, int64_t stamp, hipStream_t s) {
+    py::gil_scoped_release nogil;
+    const volatile int64_t *p = slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t spins = 0;; ++spins) {
+        if (*p == stamp) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    TORCH_CHECK(hipStreamSynchronize(s) == hipSuccess, "nerfacc_amd: hipStreamSynchronize failed");
 }
 
 inline void wait_stream(hipStream_t s) {
@@ -493,16 +519,17 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         Timed t("traverse_count", s);
         check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
     }
-    check_rc(nfa_traverse_offsets(&a, ws.data_ptr(), s));
+    const int64_t stamp = next_stamp();
+    h[3] = 0;
+    check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
     // The emit pass is launched BEFORE the read-back, into outputs sized from the previous call on this device (training
     // steps draw about the same number of samples every time): the GPU goes from the offsets kernel straight into it
     // instead of idling through the host's wake-up, allocation and launch (16 us, tools/step_timeline.py), and the host —
-    // woken by an event recorded before the emit launch — prepares the caller's next kernels while it runs.  A guess that
-    // is too small costs nothing but the second launch the old order always needed.
+    // released by the offsets kernel's stamp, not by the end of the emit pass — prepares the caller's next kernels while it
+    // runs.  A guess that is too small costs nothing but the second launch the old order always needed.
     thread_local std::map<int, int64_t> last_n;
-    thread_local std::map<int, hipEvent_t> events;
     const int dev = rays_o.device().index();
-    const bool speculate = last_n.count(dev) && last_n[dev] > 0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
+    const bool speculate = R > 0 && last_n.count(dev) && last_n[dev] > 0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
     int64_t cap = speculate ? last_n[dev] + last_n[dev] / 4 + 1024 : 0;
     Tensor ray_indices;
     Rows ts(2, cap, f32);
@@ -512,18 +539,11 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         a.sm_ray_indices = ptr<int64_t>(ray_indices);
         a.t_starts = ts.p(0);
         a.t_ends = ts.p(1);
-        hipEvent_t &ev = events[dev];
-        if (!ev) TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "nerfacc_amd: hipEventCreate failed");
-        TORCH_CHECK(hipEventRecord(ev, s) == hipSuccess, "nerfacc_amd: hipEventRecord failed");
-        {
-            Timed t("traverse_fill", s);
-            check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
-        }
-        py::gil_scoped_release nogil;
-        TORCH_CHECK(hipEventSynchronize(ev) == hipSuccess, "nerfacc_amd: hipEventSynchronize failed");
-    } else {
-        wait_stream(s);
+        Timed t("traverse_fill", s);
+        check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
     }
+    if (R > 0) wait_stamp(h + 3, stamp, s);
+    else wait_stream(s);
     const int64_t n = h[1], n_overflow = h[2];
     last_n[dev] = n;
     if (speculate && n <= cap) {
@@ -720,13 +740,16 @@ py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, 
     Guard g(device_of(dens));
     hipStream_t s = stream_of(dens);
     int64_t *h = host_ints(dens.device().index(), s);
+    const int64_t stamp = next_stamp();
     {
         Timed t("visibility", s);
-        check_rc(nfa_visibility_compact(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha, n,
-                                        (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
-                                        ptr<uint8_t>(mask), h, ws.data_ptr(), s));
+        h[1] = 0;
+        check_rc(nfa_visibility_compact_stamped(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha,
+                                                n, (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
+                                                ptr<uint8_t>(mask), h, stamp, ws.data_ptr(), s));
     }
-    wait_stream(s);
+    if (n > 0) wait_stamp(h + 1, stamp, s);
+    else wait_stream(s);
     const int64_t k = n > 0 ? h[0] : 0;
     py::object m = want_mask ? py::cast(mask) : py::none();
     return py::make_tuple(o_idx.narrow(0, 0, k), o_t.row(0).narrow(0, 0, k), o_t.row(1).narrow(0, 0, k), m);

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
+    "nfa_traverse_offsets_stamped": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, c_int64, _P]),    # (extension only)
     "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P, c_int64, c_int64, _P]),
     "nfa_traverse_emit_speculative": (ctypes.c_int, [_P, _P, c_int64, _P]),    # (used by the extension only)
     "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "nfa_sample_positions": (ctypes.c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
     "nfa_visibility_workspace_bytes": (c_int64, [c_int64]),
     "nfa_visibility_compact": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "nfa_visibility_compact_stamped": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P]),    # (extension only)
     "nfa_accumulate_along_rays": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P]),
     "nfa_accumulate_along_rays_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P]),
     "nfa_rendering_fwd": (ctypes.c_int, [_P] * 5 + [c_int64, c_int64, _P, c_int32] + [_P] * 7),
