@@ -109,14 +109,15 @@ template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, int spec, float eps, float alpha_thre,
-    uint8_t *__restrict__ mask, int64_t *__restrict__ tile_cnts, int64_t *__restrict__ tile_rng)
+    uint8_t *__restrict__ mask, int64_t *__restrict__ tile_cnts, int64_t *__restrict__ tile_rng, int64_t *__restrict__ wg_sums)
 {
+    __shared__ int64_t s_kept[kWavesPerBlock];
     const int64_t w = wave_index();
-    if (w * tile >= n) return;
     const int lane = lane_id();
     int64_t kept = 0, rb = 0, re = 0;
     bool first = true;
     float carry = from_alpha ? 1.0f : 0.0f;
+    if (w * tile < n)
     walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, spec,
         [&](int64_t i0) {
             VisIn<E> p;
@@ -163,7 +164,11 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
             }
         },
         [](int64_t) {});
-    if (lane == 0) { tile_cnts[w] = kept; tile_rng[2 * w] = rb; tile_rng[2 * w + 1] = re; }
+    if (lane == 0 && w * tile < n) { tile_cnts[w] = kept; tile_rng[2 * w] = rb; tile_rng[2 * w + 1] = re; }
+    // survivors of the workgroup's four tiles: the compaction adds up one number per workgroup before its own (a quarter of the loads)
+    if (lane == 0) s_kept[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_sums) wg_sums[blockIdx.x] = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
 }
 
 // 2) (only beyond kVisFusedTiles tiles) one wave per group of 64 tiles: exclusive prefix of the
@@ -208,16 +213,21 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t rb = tile_rng[2 * w_], re = tile_rng[2 * w_ + 1];
     int64_t dst;
     if (mode == 1) {
+        // group_sums holds the survivors per WORKGROUP of the mask pass here: add up the workgroups before this wave's, then
+        // the tiles of its own workgroup before it (<= 1024 + 3 loads per wave instead of <= 4096, eight in flight)
+        const int64_t wg = w_ / kWavesPerBlock;
         int64_t p = 0;
         int64_t j = lane;
-        for (; j + 7 * 64 < w_; j += 8 * 64) {             // eight loads in flight: up to 64 rounds of one L2 latency each otherwise
+        for (; j + 7 * 64 < wg; j += 8 * 64) {
             int64_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = tile_offs[j + u * 64];
+            for (int u = 0; u < 8; ++u) v[u] = group_sums[j + u * 64];
 #pragma unroll
             for (int u = 0; u < 8; ++u) p += v[u];
         }
-        for (; j < w_; j += 64) p += tile_offs[j];
+        for (; j < wg; j += 64) p += group_sums[j];
+        const int64_t k = wg * kWavesPerBlock + lane;
+        if (lane < kWavesPerBlock && k < w_) p += tile_offs[k];
         dst = wave_sum_i64(p);
         if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst + tile_offs[w_]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
     } else if (mode == 2) {
@@ -669,11 +679,12 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
     const int64_t tile = pl.tile, T = ceil_div(n, tile);
     int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + ceil_div(n, 16) * 16);
     int64_t *tile_offs = tile_cnts + T, *tile_rng = tile_offs + T;
+    const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
     NFA_LAUNCH_TILED(visibility_mask_kernel, pl, n, s, ray_indices, t_starts, t_ends,
-                     dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, mask, tile_cnts, tile_rng);
+                     dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, mask, tile_cnts, tile_rng,
+                     mode == 1 ? tile_offs : (int64_t *)nullptr);      // (mode 1: the otherwise unused second quarter of the workspace)
     if (int rc = check_launch("visibility_mask_kernel")) return rc;
     if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
-    const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
     int64_t *group_sums = tile_offs;                       // (the second half of the workspace; T / 64 <= T entries)
     if (mode == 2) {
         const int64_t groups = ceil_div(T, 64);
