@@ -527,9 +527,10 @@ inline bool aligned16(std::initializer_list<const void *> ptrs) {
 }
 inline TilePlan pick_plan(int64_t n, bool vec_ok = true) {
     TilePlan p;
-    // (2 samples per lane from 4 M samples: measured equal to 4 per lane within noise for every kernel except rendering_bwd,
-    // which needs 170 VGPRs at 4 and runs 13-15 % faster at 2: profiles/r02_streaming.md)
-    p.e = n >= ((int64_t)1 << 22) ? 2 : 1;
+    // (2 samples per lane from 128 k samples: at roofline scale it measures equal to 4 per lane within noise for every kernel except
+    // rendering_bwd, which needs 170 VGPRs at 4 and runs 13-15 % faster at 2; at the training size (2.6e5 samples) it is 5-15 %
+    // ahead of one per lane back to back, and below ~1e5 samples one per lane wins: profiles/r02_streaming.md)
+    p.e = n >= ((int64_t)1 << 17) ? 2 : 1;
     if (const char *s = getenv("NFA_E")) {               // tuning knobs
         const int v = atoi(s);
         if (v == 1 || v == 2 || v == 4) p.e = v;

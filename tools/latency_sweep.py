@@ -54,6 +54,7 @@ def run(cold=False):
 
 def report(path):
     rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))          # launch order = ascending N
     groups = {}
     for r in rows:
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
@@ -63,7 +64,7 @@ def report(path):
     names = sorted({k[0] for k in groups if "nfa::" in k[0] or "CUDAFunctorOnSelf_add" in k[0] or "AUnaryFunctor" in k[0]})
     for nm in names:
         line = []
-        for (k, grid), v in sorted(groups.items(), key=lambda kv: kv[0][1]):
+        for (k, grid), v in groups.items():                      # (insertion order: the sizes in the order they ran)
             if k == nm and len(v) >= 20:
                 v = sorted(v)
                 line.append("%d:%.1f" % (grid, v[len(v) // 2]))
