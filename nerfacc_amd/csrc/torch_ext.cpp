@@ -478,7 +478,7 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
     return {intervals, samples, terminate};
 }
 
-// k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels take 4 elements per lane then)
+// k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels then use vector accesses: 2 or 4 elements per lane)
 struct Rows {
     Tensor buf;
     int64_t pitch, n;

@@ -422,7 +422,7 @@ def _traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
 
 def _rows(k: int, n: int, device) -> torch.Tensor:
     """k float rows of n elements from one allocation, each row 16-byte aligned (the tiled kernels then take
-    4 elements per lane); rows are x[i] (1-D, contiguous)."""
+    2 or 4 elements per lane); rows are x[i] (1-D, contiguous)."""
     pitch = (n + 3) & ~3
     return torch.empty((k, pitch), dtype=torch.float32, device=device)[:, :n]
 
