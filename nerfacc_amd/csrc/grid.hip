@@ -1378,6 +1378,227 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     NFA_PHASE_END();
 }
 
+// ---- segment walk: several levels, one lane per LEVEL SEGMENT of a ray ---------------------------
+// A ray through G nested grids is a sequence of up to 2 G - 1 segments, each inside one level (grid.cu:129-150).
+// The lane-per-ray walk does them one after the other, every voxel a dependent brick load from L2: its time is
+// one ray's ~250-voxel chain whatever the ray count.  Here the P >= 2 G - 1 adjacent lanes of a ray take ONE
+// segment each and list its occupied<->empty boundaries.  The marching lattice is one chain t <- t + dt from the
+// first live segment's start across all segments (a jump to a later segment's start is the same recurrence), so
+// every lane resolves its own boundaries as absolute positions (T, K) on that chain and the lanes of a ray are
+// stitched in order.  What a segment adds to the single-level stitch: entering a segment while not `continuous`
+// jumps the lattice to its start (grid.cu:157-161) — a virtual empty boundary at seg_lo that only applies in that
+// state; and a first occupied run that continues the previous segment's samples starts no new run record.
+// cone_angle == 0, no step limit, no ray mask; anything odd (stuck lattice, a segment with more than CAP
+// boundaries) goes through the serial walk of the whole ray by the group's first lane.
+template <bool LDS_OCC, int P, int CAP>
+__global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_traverse_args a, GridView gv,
+                                                                         int64_t *__restrict__ block_sums, RunStore rs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NFA_PHASE_BEGIN();
+    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    NFA_PHASE_MARK(0);
+    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][kBlock] times, then [CAP][kBlock] lattice indices
+    int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
+    const int tid = threadIdx.x, part = tid % P;
+    const int group_base = lane_id() - part;
+    const int64_t R = a.n_rays;
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / P) + tid / P;
+    const bool ray_ok = r < R;
+    const int64_t rr = ray_ok ? r : 0;
+    const int G = a.n_grids;
+
+    const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
+    const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const float near = ray_near(a, rr), far = ray_far(a, rr);
+    const float dt = march_dt(0.0f, 0.0f, a.step_size);
+
+    Events<EV_MANY> ev;
+    ev.init(a, rr, o, inv);
+    int level = 0;
+    float seg_lo = 0.f, seg_hi = 0.f;
+    const bool live = ray_ok && part + 1 < 2 * G && segment_of(ev, part, G, near, far, level, seg_lo, seg_hi);
+
+    NFA_PHASE_MARK(1);
+    // the chain starts at the first live segment
+    const unsigned live_parts = group_bits<P>(__ballot(live), group_base);
+    const int first_part = live_parts ? __ffs((int)live_parts) - 1 : 0;
+    const float lo_first = __shfl(seg_lo, group_base + first_part, 64);
+    int64_t k_tmp = 0;
+    bool stuck = false, stuck_any = false;
+    float t_seg = near;
+    if (live_parts) {
+        t_seg = nfa_lattice_until(near, dt, lo_first, &k_tmp, &stuck);
+        stuck_any = stuck;
+    }
+
+    NFA_PHASE_MARK(2);
+    // ---- A: this segment's voxels, boundaries only
+    int n_ev = 0;
+    unsigned ev_occ = 0;
+    bool overflow = false;
+    if (live) {
+        Dda s;
+        dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
+        BrickCache cache;
+        cache.id = -1;
+        cache.bits = 0;
+        bool have_run = false, run_occ = false;
+        float run_exit = 0.f;
+        for (bool more = true; more;) {
+            const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+            const bool oc = occupied(gv, occ, cache, level, s.cx, s.cy, s.cz);
+            if (have_run && oc != run_occ) {
+                if (n_ev == CAP - 1) { overflow = true; break; }
+                ev_lds[n_ev * kBlock + tid] = run_exit;
+                ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+                ++n_ev;
+            }
+            have_run = true;
+            run_occ = oc;
+            run_exit = t_cell;
+            more = dda_advance(s);
+        }
+        if (!overflow) {                                 // the segment's last run
+            ev_lds[n_ev * kBlock + tid] = run_exit;
+            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+            ++n_ev;
+        }
+    }
+
+    NFA_PHASE_MARK(3);
+    // ---- B: positions on the chain: the segment start (the virtual boundary), then the own boundaries
+    float T_lo = t_seg, T_last = t_seg;
+    int64_t K_lo = 0, K_last = 0;
+    int64_t sm_rest = 0;                 // samples / fresh runs of boundaries 1.. (each preceded by an empty boundary of this segment)
+    int fresh_rest = 0;
+    int64_t K_first = 0;
+    bool cont_rest = false;
+    if (live && !overflow) {
+        T_lo = nfa_lattice_until(t_seg, dt, seg_lo, &K_lo, &stuck);
+        stuck_any = stuck_any || stuck;
+        float T = T_lo;
+        int64_t K = K_lo, K_prev = K_lo;
+        for (int j = 0; j < n_ev; ++j) {
+            const float bound = ev_lds[j * kBlock + tid];
+            T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
+            stuck_any = stuck_any || stuck;
+            K += k_tmp;
+            ev_lds[j * kBlock + tid] = T;
+            ev_K[j * kBlock + tid] = (int32_t)K;
+            const bool oj = (ev_occ >> j) & 1u;
+            if (j == 0) K_first = K;
+            else {
+                if (oj && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; cont_rest = true; }
+                else if (!oj) cont_rest = false;
+            }
+            K_prev = K;
+        }
+        K_last = K;
+        T_last = T;
+    }
+    NFA_PHASE_MARK(4);
+    bool bad = stuck_any || overflow || K_last > 0x7fffffffll;
+#ifdef NFA_FORCE_SERIAL
+    bad = true;
+#endif
+    bad = group_bits<P>(__ballot(bad), group_base) != 0u;
+
+    // ---- stitch, segment by segment: (position, continuous) before every part
+    const bool has = live && n_ev > 0;
+    const bool occ_first = ev_occ & 1u;
+    int Kpos = 0;
+    float Tpos = t_seg;
+    bool cont = false, any_has = false;
+    int64_t sm_acc = 0;
+    int fresh_acc = 0;
+    int my_K_start = 0, my_fresh_before = 0;
+    float my_T_start = t_seg;
+    bool my_cont_in = false;
+    int64_t my_sm_before = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int src = group_base + p;
+        const bool has_p = __shfl((int)has, src, 64) != 0;
+        const int Klo_p = __shfl((int)K_lo, src, 64), Kf_p = __shfl((int)K_first, src, 64), Kl_p = __shfl((int)K_last, src, 64);
+        const float Tlo_p = __shfl(T_lo, src, 64), Tl_p = __shfl(T_last, src, 64);
+        const int flags_p = __shfl((occ_first ? 1 : 0) | (cont_rest ? 2 : 0) | (n_ev >= 2 ? 4 : 0), src, 64);
+        const int64_t smr_p = __shfl(sm_rest, src, 64);
+        const int frr_p = __shfl(fresh_rest, src, 64);
+        if (part == p) { my_sm_before = sm_acc; my_fresh_before = fresh_acc; my_cont_in = cont; }
+        if (has_p) {
+            int Ks = Kpos;
+            float Ts = Tpos;
+            if (!cont && Klo_p > Kpos) { Ks = Klo_p; Ts = Tlo_p; }      // entering the segment: jump to its start
+            const bool of = flags_p & 1;
+            const int k1 = of && Kf_p > Ks ? Kf_p - Ks : 0;
+            const bool fresh1 = k1 > 0 && !cont;
+            if (part == p) { my_K_start = Ks; my_T_start = Ts; }
+            sm_acc += k1 + smr_p;
+            fresh_acc += (fresh1 ? 1 : 0) + frr_p;
+            if (of) { if (k1 > 0) cont = true; } else cont = false;
+            if (flags_p & 4) cont = (flags_p & 2) != 0;
+            Kpos = Kl_p;
+            Tpos = Tl_p;
+            any_has = true;
+        }
+    }
+    const int64_t sm_total = sm_acc;
+    const int fresh_total = fresh_acc;
+
+    NFA_PHASE_MARK(5);
+    // run records of this segment
+    if (!bad && rs.t0 && has && fresh_total <= rs.max_runs) {
+        int64_t first = my_sm_before;
+        int K_prev = my_K_start;
+        float T_prev = my_T_start;
+        int idx = my_fresh_before;
+        for (int j = 0; j < n_ev; ++j) {
+            const int K = ev_K[j * kBlock + tid];
+            const float T = ev_lds[j * kBlock + tid];
+            if (((ev_occ >> j) & 1u) && K > K_prev) {
+                if (j > 0 || !my_cont_in) {
+                    rs.t0[(int64_t)idx * R + r] = T_prev;
+                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
+                    ++idx;
+                }
+                first += K - K_prev;
+            }
+            K_prev = K > K_prev ? K : K_prev;
+            T_prev = T;
+        }
+    }
+    NFA_PHASE_MARK(6);
+    int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
+    if (!bad) {
+        if (ray_ok && part == 0) {
+            const bool ovf = fresh_total > rs.max_runs || sm_total > 0x7fffffffll;
+            if (rs.n_runs) rs.n_runs[r] = (uint16_t)(ovf ? kRunsOverflow : fresh_total);
+            out_iv = sm_total + fresh_total;
+            out_sm = sm_total;
+            out_ovf = ovf && sm_total > 0 ? 1 : 0;
+            if (a.terminate_planes) a.terminate_planes[r] = any_has ? Tpos : near;
+        }
+    } else if (ray_ok && part == 0) {
+        CountSink sink{rs, r, R};
+        float t_term = 0.f;
+        traverse_ray_lattice_inline<EV_MANY, LDS_OCC>(a, gv, occ, r, sink, t_term);
+        out_ovf = sink.finish(true) ? 1 : 0;
+        out_iv = sink.n_iv;
+        out_sm = sink.n_sm;
+        if (a.terminate_planes) a.terminate_planes[r] = t_term;
+    }
+    if (ray_ok && part == 0) {
+        if (a.iv_cnts) a.iv_cnts[r] = out_iv;
+        a.sm_cnts[r] = out_sm;
+    }
+    NFA_PHASE_MARK(7);
+    publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);
+    NFA_PHASE_MARK(8);
+    NFA_PHASE_END();
+}
+
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
 // prefix, `total` gets the block total (all threads).
 __device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t *lds /* [kWavesPerBlock] */, int64_t &total) {
@@ -1799,9 +2020,33 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 // sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
 // be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
 // LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
-struct SplitPlan { int P, cap, lds, blk, xt; GridView gv; };
+struct SplitPlan { int P, cap, lds, blk, xt, seg; GridView gv; };
+// several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
+// with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
+// 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off, NFA_SEGMENTS_MAX_RAYS moves the limit
+static int segment_lanes_per_ray(const nfa_traverse_args *a) {
+    const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
+    if (!lattice || a->t_sorted || a->n_grids < 2 || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
+    int64_t max_rays = 24576;
+    if (const char *e = getenv("NFA_SEGMENTS_MAX_RAYS")) max_rays = atoll(e);
+    if (const char *e = getenv("NFA_SEGMENTS")) { if (atoi(e) == 0) return 0; }
+    if (a->n_rays > max_rays) return 0;
+    return 2 * a->n_grids - 1 <= 8 ? 8 : 16;
+}
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
+    p.seg = 0;
+    if (const int ps = segment_lanes_per_ray(a)) {
+        p.P = ps;
+        p.seg = 1;
+        p.blk = kBlock;
+        p.xt = 0;
+        p.lds = 0;
+        p.cap = 16;
+        p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
+        if (p.gv.lds_compact_cap == 0) { p.cap = 32; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
+        return p;
+    }
     p.P = count_lanes_per_ray(a, true);
     p.cap = 16;      // (8-entry lists at P = 16 overflow into the streaming mode on a trained scene: 80 us instead of 44)
     if (const char *e = getenv("NFA_SPLIT_CAP")) { const int v = atoi(e); if (v == 8 || v == 16) p.cap = v; }   // tuning knob
@@ -1847,6 +2092,17 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         const GridView &gv = plan.gv;
         const bool lds_occ = gv.lds_compact_cap > 0;
         const unsigned nbs = (unsigned)ceil_div(a->n_rays, plan.blk / P);
+        if (plan.seg) {
+#define NFA_LAUNCH_SEG(LDSO, PP, CAP)                                                                                           \
+    do {                                                                                                                       \
+        if (int rc = allow_lds(traverse_count_segments_kernel<LDSO, PP, CAP>, lds)) return rc;                                   \
+        hipLaunchKernelGGL((traverse_count_segments_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    } while (0)
+            if (lds_occ) { if (P == 8) NFA_LAUNCH_SEG(true, 8, 16); else NFA_LAUNCH_SEG(true, 16, 16); }
+            else { if (P == 8) NFA_LAUNCH_SEG(false, 8, 32); else NFA_LAUNCH_SEG(false, 16, 32); }
+#undef NFA_LAUNCH_SEG
+            return check_launch("traverse_count_segments_kernel");
+        }
 #define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
     do {                                                                                                                       \
         if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \

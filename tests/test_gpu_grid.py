@@ -188,6 +188,47 @@ def test_sampling_many_rays_serial_and_split_walks_agree():
         assert np.array_equal(n(pk), r_pk)
 
 
+@pytest.mark.parametrize("levels,res,kind", [(2, 32, "blob"), (4, 32, "blob"), (4, 16, "noise"), (5, 24, "noise"), (8, 8, "blob"), (3, (20, 33, 7), "noise")])
+def test_sampling_multi_level_segment_and_serial_count_passes(monkeypatch, levels, res, kind):
+    """several levels, cone_angle = 0: the count pass with one lane per LEVEL SEGMENT of a ray (grid.hip:
+    traverse_count_segments_kernel; 8 lanes per ray up to 4 levels, 16 up to 8) and the lane-per-ray one must both give the oracle's
+    samples, packed_info and terminate planes bit for bit — rays from inside the first level, from outside everything and
+    axis-aligned; a noise grid overflows the segments' boundary lists (the ray then takes the serial walk inside the kernel)
+    and the per-ray run records (those rays are re-walked by the fill pass)"""
+    from nerfacc_amd import cuda as C
+
+    rng = np.random.default_rng(levels * 100 + (res if isinstance(res, int) else sum(res)))
+    res3 = (res,) * 3 if isinstance(res, int) else res
+    c = [(np.arange(r) + 0.5) / r * 2 - 1 for r in res3]
+    X, Y, Z = np.meshgrid(*c, indexing="ij")
+    if kind == "blob":
+        occ = np.stack([((X * 2.0**l) ** 2 + (Y * 2.0**l) ** 2 + (Z * 2.0**l) ** 2 < 0.5**2) | (rng.random(res3) < 0.004 * (l > 0)) for l in range(levels)])
+    else:
+        occ = rng.random((levels,) + res3) < 0.35
+    aabbs = np.stack([np.array([-1, -1, -1, 1, 1, 1], np.float32) * 2.0**l for l in range(levels)])
+    R = 1500
+    v = rng.standard_normal((R, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    o = np.where(np.arange(R)[:, None] % 3 == 0, 0.6 * v, np.where(np.arange(R)[:, None] % 3 == 1, v * 2.0 ** (levels + 1), v * 1.3))
+    d = np.where(np.arange(R)[:, None] % 3 == 1, -v + 0.2 * rng.standard_normal((R, 3)), rng.standard_normal((R, 3)))
+    d[::7, rng.integers(0, 3)] = 0.0
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    near = (rng.random(R) * 0.2).astype(np.float32)
+    far = np.where(rng.random(R) < 0.7, 1e10, 2.0 ** (levels - 1)).astype(np.float32)
+    step = 7e-3
+    r_iv, r_sm, r_term = oracle.traverse_grids(o, d, occ, aabbs, near, far, step, 0.0)
+    r_ts, r_te = r_iv["vals"][r_iv["is_left"]], r_iv["vals"][r_iv["is_right"]]
+    assert r_sm["ray_indices"].shape[0] > 2000
+    live = r_sm["packed_info"][:, 1] > 0               # (rays without samples: the reference leaves their terminate plane unwritten)
+    for seg in ("1", "0"):
+        monkeypatch.setenv("NFA_SEGMENTS", seg)
+        ri, ts, te, pk, term = C.sample_occgrid(t(o), t(d), t(occ), t(aabbs), t(near), t(far), step, 0.0, with_terminate_planes=True)
+        assert np.array_equal(n(ri), r_sm["ray_indices"]) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
+        assert np.array_equal(n(pk), r_sm["packed_info"])
+        assert np.array_equal(n(term)[live], r_term[live])
+
+
 def test_sample_positions_bit_identical_to_the_torch_expression():
     import nerfacc_amd as nerfacc
 

@@ -22,7 +22,7 @@ occ = []
 for l in range(levels):                                   # a blob at the centre + sparse far clutter
     s = 2.0**l
     blob = (X * s) ** 2 + (Y * s) ** 2 + (Z * s) ** 2 < 0.5**2
-    clutter = g.random((res, res, res)) < (0.002 if l else 0.0)
+    clutter = g.random((res, res, res)) < (float(os.environ.get("ML_CLUTTER", "0.002")) if l else 0.0)
     occ.append(blob | clutter)
 occ = np.stack(occ)
 aabbs = np.stack([np.array([-1, -1, -1, 1, 1, 1], np.float32) * 2.0**l for l in range(levels)])
@@ -40,7 +40,7 @@ def gpu_ms(fn, reps=10):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ms.append(e0.elapsed_time(e1))
     return sorted(ms)[len(ms) // 2]
 
-for step, cone in ((1e-3, 0.004), (1e-3, 0.0), (4e-3, 0.0)):
+for step, cone in (((1e-3, 0.0),) if os.environ.get("ML_ONLY_LATTICE") else ((1e-3, 0.004), (1e-3, 0.0), (4e-3, 0.0))):
     ri, ts, te, pk = C.sample_occgrid(O, D, OCC, AABB, NEAR, FAR, step, cone)
     t0 = time.perf_counter()
     iv, sm, _ = oracle.traverse_grids(o, d, occ, aabbs, near, far, step, cone)

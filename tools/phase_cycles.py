@@ -54,6 +54,23 @@ elif os.environ.get("NFA_PHASE_WORKLOAD") == "m1-random":
     aabbs = torch.tensor([[0.0, 0, 0, 1, 1, 1]], device=dev)
     step = 5e-3 / 3
     near = torch.zeros(n, device=dev)
+elif os.environ.get("NFA_PHASE_WORKLOAD") == "levels4":        # tools/multilevel_bench.py's scene: 4 levels, segment-per-lane count pass
+    import numpy as np
+    g = np.random.default_rng(0)
+    c = (np.arange(128) + 0.5) / 128 * 2 - 1
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    occ = np.stack([((X * 2.0**l) ** 2 + (Y * 2.0**l) ** 2 + (Z * 2.0**l) ** 2 < 0.25) | (g.random((128, 128, 128)) < (float(os.environ.get("ML_CLUTTER", "0.002")) if l else 0.0))
+                    for l in range(4)])
+    v = g.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    d = g.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pool_o, pool_d = torch.from_numpy((0.6 * v).astype(np.float32)).to(dev), torch.from_numpy(d.astype(np.float32)).to(dev)
+    binaries = torch.from_numpy(occ).to(dev)
+    aabbs = torch.from_numpy(np.stack([np.array([-1, -1, -1, 1, 1, 1], np.float32) * 2.0**l for l in range(4)])).to(dev)
+    step = 1e-3
+    near = torch.full((n,), 0.2, device=dev)
+    names = ["stage occupancy into LDS (+barrier)", "ray loads, 4 slab tests + event sort, segment_of", "lattice to the first segment's start",
+             "A: voxel walk of the segment", "B: lattice positions (segment start + own boundaries)", "stitch over the segments",
+             "run records", "per-ray outputs (+ serial fallback)", "block sums"]
 else:
     field = bench.DenseGridField(bench.AABB, 128).to(dev)
     est = nerfacc.OccGridEstimator(roi_aabb=bench.AABB, resolution=128, levels=1).to(dev)
@@ -78,7 +95,7 @@ for _ in range(iters):
 torch.cuda.synchronize()
 lib.nfa_debug_phase_cycles(buf, 0)
 waves = buf[15]
-names = ["stage occupancy into LDS (+barrier)", "ray loads, slab test, lattice to segment start, DDA setup",
+names = globals().get("names") or ["stage occupancy into LDS (+barrier)", "ray loads, slab test, lattice to segment start, DDA setup",
          "end-of-walk times (3 closed forms), major axis", "seam restart (closed-form DDA state at the part start)",
          "A: voxel walk of the part", "B: lattice position of own boundaries", "stitch across the P lanes + run records",
          "per-ray outputs (+ serial fallback)", "block sums"]
