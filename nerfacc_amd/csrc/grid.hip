@@ -1434,38 +1434,79 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     }
 
     NFA_PHASE_MARK(2);
-    // ---- A: this segment's voxels, boundaries only
-    int n_ev = 0;
-    unsigned ev_occ = 0;
-    bool overflow = false;
-    if (live) {
+#ifndef NFA_SEG_BATCH
+#define NFA_SEG_BATCH 4
+#endif
+    // the segment's voxel walk: on_boundary(t_exit, run_was_occupied) for every occupied<->empty boundary and for the last run;
+    // returning false stops the walk.  NFA_SEG_BATCH voxels per trip: the DDA does not depend on the occupancy, so the steps of a
+    // batch run first, their brick words are requested together (one LDS / L2 latency per batch instead of one per voxel:
+    // 126 k -> 93 k cycles per wave) and the boundaries are found afterwards, in order.
+    auto walk = [&](auto &&on_boundary) {
         Dda s;
         dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
-        BrickCache cache;
-        cache.id = -1;
-        cache.bits = 0;
-        bool have_run = false, run_occ = false;
+        bool have_run = false, run_occ = false, stop = false;
         float run_exit = 0.f;
+        const uint32_t *lc = (const uint32_t *)occ.smem;
         for (bool more = true; more;) {
-            const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-            const bool oc = occupied(gv, occ, cache, level, s.cx, s.cy, s.cz);
-            if (have_run && oc != run_occ) {
-                if (n_ev == CAP - 1) { overflow = true; break; }
-                ev_lds[n_ev * kBlock + tid] = run_exit;
-                ev_occ |= (run_occ ? 1u : 0u) << n_ev;
-                ++n_ev;
+            bool valid[NFA_SEG_BATCH];
+            float tc[NFA_SEG_BATCH];
+            int id[NFA_SEG_BATCH], bp[NFA_SEG_BATCH];
+#pragma unroll
+            for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+                valid[k] = more;
+                tc[k] = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+                id[k] = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + level * gv.bricks_per_grid;
+                bp[k] = ((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3);
+                if (more) more = dda_advance(s);
             }
-            have_run = true;
-            run_occ = oc;
-            run_exit = t_cell;
-            more = dda_advance(s);
+            uint64_t bits[NFA_SEG_BATCH];
+            if (LDS_OCC) {
+                uint2 wr[NFA_SEG_BATCH];
+#pragma unroll
+                for (int k = 0; k < NFA_SEG_BATCH; ++k) wr[k] = valid[k] ? ((const uint2 *)occ.smem)[id[k] >> 5] : make_uint2(0u, 0u);
+#pragma unroll
+                for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+                    const uint32_t bit = 1u << (id[k] & 31);
+                    bits[k] = (wr[k].x & bit) ? ((const uint64_t *)(lc + 2 * occ.w4))[(int)wr[k].y + __popc(wr[k].x & (bit - 1u))] : 0ull;
+                }
+            } else if (occ.bytes > 0) {
+                uint32_t w[NFA_SEG_BATCH];
+#pragma unroll
+                for (int k = 0; k < NFA_SEG_BATCH; ++k) w[k] = valid[k] ? lc[id[k] >> 5] : 0u;
+#pragma unroll
+                for (int k = 0; k < NFA_SEG_BATCH; ++k) bits[k] = (w[k] & (1u << (id[k] & 31))) ? gv.bricks[id[k]] : 0ull;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NFA_SEG_BATCH; ++k) bits[k] = valid[k] ? gv.bricks[id[k]] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+                if (valid[k] && !stop) {
+                    const bool oc = (bits[k] >> bp[k]) & 1ull;
+                    if (have_run && oc != run_occ) stop = !on_boundary(run_exit, run_occ);
+                    have_run = true;
+                    run_occ = oc;
+                    run_exit = tc[k];
+                }
+            }
+            if (stop) more = false;
         }
-        if (!overflow) {                                 // the segment's last run
-            ev_lds[n_ev * kBlock + tid] = run_exit;
-            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+        if (!stop) on_boundary(run_exit, run_occ);             // the segment's last run
+    };
+
+    // ---- A: this segment's boundaries into the lane's list; a segment with more than CAP of them is STREAMED: its boundaries
+    // are resolved as a second walk finds them (aggregates only) and its run records written by a third one
+    int n_ev = 0;
+    unsigned ev_occ = 0;
+    bool streaming = false;
+    if (live)
+        walk([&](float t_exit, bool oc) {
+            if (n_ev == CAP) { streaming = true; return false; }
+            ev_lds[n_ev * kBlock + tid] = t_exit;
+            ev_occ |= (oc ? 1u : 0u) << n_ev;
             ++n_ev;
-        }
-    }
+            return true;
+        });
 
     NFA_PHASE_MARK(3);
     // ---- B: positions on the chain: the segment start (the virtual boundary), then the own boundaries
@@ -1474,40 +1515,49 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     int64_t sm_rest = 0;                 // samples / fresh runs of boundaries 1.. (each preceded by an empty boundary of this segment)
     int fresh_rest = 0;
     int64_t K_first = 0;
-    bool cont_rest = false;
-    if (live && !overflow) {
+    bool cont_rest = false, occ_first = false;
+    if (live) {
         T_lo = nfa_lattice_until(t_seg, dt, seg_lo, &K_lo, &stuck);
         stuck_any = stuck_any || stuck;
         float T = T_lo;
         int64_t K = K_lo, K_prev = K_lo;
-        for (int j = 0; j < n_ev; ++j) {
-            const float bound = ev_lds[j * kBlock + tid];
+        int j = 0;
+        auto resolve = [&](float bound, bool oj) {
             T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
             stuck_any = stuck_any || stuck;
             K += k_tmp;
-            ev_lds[j * kBlock + tid] = T;
-            ev_K[j * kBlock + tid] = (int32_t)K;
-            const bool oj = (ev_occ >> j) & 1u;
-            if (j == 0) K_first = K;
-            else {
-                if (oj && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; cont_rest = true; }
-                else if (!oj) cont_rest = false;
-            }
+            if (j == 0) { K_first = K; occ_first = oj; }
+            else if (oj && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; cont_rest = true; }
+            else if (!oj) cont_rest = false;
             K_prev = K;
+            ++j;
+        };
+        if (!streaming) {
+            for (int q = 0; q < n_ev; ++q) {
+                resolve(ev_lds[q * kBlock + tid], (ev_occ >> q) & 1u);
+                ev_lds[q * kBlock + tid] = T;
+                ev_K[q * kBlock + tid] = (int32_t)K;
+            }
+        } else {
+            walk([&](float t_exit, bool oc) { resolve(t_exit, oc); return true; });
+            n_ev = j;
         }
         K_last = K;
         T_last = T;
     }
     NFA_PHASE_MARK(4);
-    bool bad = stuck_any || overflow || K_last > 0x7fffffffll;
+    bool bad = stuck_any || K_last > 0x7fffffffll;
 #ifdef NFA_FORCE_SERIAL
     bad = true;
 #endif
     bad = group_bits<P>(__ballot(bad), group_base) != 0u;
+#ifdef NFA_PHASE_CYCLES
+    ph_[12] = __popcll(__ballot(bad && ray_ok && part == 0));          // rays of this wave that take the serial walk
+    ph_[13] = __popcll(__ballot(streaming));                           // streamed segments
+#endif
 
     // ---- stitch, segment by segment: (position, continuous) before every part
     const bool has = live && n_ev > 0;
-    const bool occ_first = ev_occ & 1u;
     int Kpos = 0;
     float Tpos = t_seg;
     bool cont = false, any_has = false;
@@ -1551,13 +1601,11 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     // run records of this segment
     if (!bad && rs.t0 && has && fresh_total <= rs.max_runs) {
         int64_t first = my_sm_before;
-        int K_prev = my_K_start;
+        int64_t K_prev = my_K_start;
         float T_prev = my_T_start;
-        int idx = my_fresh_before;
-        for (int j = 0; j < n_ev; ++j) {
-            const int K = ev_K[j * kBlock + tid];
-            const float T = ev_lds[j * kBlock + tid];
-            if (((ev_occ >> j) & 1u) && K > K_prev) {
+        int idx = my_fresh_before, j = 0;
+        auto record = [&](int64_t K, float T, bool oj) {
+            if (oj && K > K_prev) {
                 if (j > 0 || !my_cont_in) {
                     rs.t0[(int64_t)idx * R + r] = T_prev;
                     rs.first[(int64_t)idx * R + r] = (int32_t)first;
@@ -1567,6 +1615,20 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
             }
             K_prev = K > K_prev ? K : K_prev;
             T_prev = T;
+            ++j;
+        };
+        if (!streaming) {
+            for (int q = 0; q < n_ev; ++q) record(ev_K[q * kBlock + tid], ev_lds[q * kBlock + tid], (ev_occ >> q) & 1u);
+        } else {
+            float T = T_lo;
+            int64_t K = K_lo;
+            walk([&](float t_exit, bool oc) {
+                int64_t k; bool st;
+                T = nfa_lattice_until(T, dt, t_exit, &k, &st);
+                K += k;
+                record(K, T, oc);
+                return true;
+            });
         }
     }
     NFA_PHASE_MARK(6);
@@ -2042,9 +2104,13 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
         p.blk = kBlock;
         p.xt = 0;
         p.lds = 0;
-        p.cap = 16;
-        p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
-        if (p.gv.lds_compact_cap == 0) { p.cap = 32; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
+        // 32-entry boundary lists always (a segment with more is streamed: three walks); the brick image joins them in LDS when
+        // it fits in what a workgroup alone on its CU can have — the lists alone already keep a second workgroup off the CU
+        p.cap = 32;
+        // (beyond one workgroup per CU the image stays in L2 so that two workgroups share a CU's 160 KB: the walk is as fast
+        // from L2 — it is bound by its instructions — and 16 k rays take 145 instead of 208 us)
+        const bool one_round = ceil_div(a->n_rays, kBlock / ps) <= kNumCU;
+        p.gv = make_view(a, p.cap * kBlock * 8, &p.lds, one_round ? 156 * 1024 : 80 * 1024);
         return p;
     }
     p.P = count_lanes_per_ray(a, true);
@@ -2098,7 +2164,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (int rc = allow_lds(traverse_count_segments_kernel<LDSO, PP, CAP>, lds)) return rc;                                   \
         hipLaunchKernelGGL((traverse_count_segments_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
     } while (0)
-            if (lds_occ) { if (P == 8) NFA_LAUNCH_SEG(true, 8, 16); else NFA_LAUNCH_SEG(true, 16, 16); }
+            if (lds_occ) { if (P == 8) NFA_LAUNCH_SEG(true, 8, 32); else NFA_LAUNCH_SEG(true, 16, 32); }
             else { if (P == 8) NFA_LAUNCH_SEG(false, 8, 32); else NFA_LAUNCH_SEG(false, 16, 32); }
 #undef NFA_LAUNCH_SEG
             return check_launch("traverse_count_segments_kernel");

@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out_dir = os.path.join(ROOT, "tools", "_prof")
 os.makedirs(out_dir, exist_ok=True)
-so = os.path.join(out_dir, "libnerfacc_hip_prof.so")
+extra = os.environ.get("NFA_PHASE_EXTRA", "").split()          # further -D flags (A/B builds), e.g. NFA_PHASE_EXTRA="-DNFA_SEG_BATCH=1"
+so = os.path.join(out_dir, "libnerfacc_hip_prof" + "".join(c if c.isalnum() else "_" for c in "".join(extra)) + ".so")
 srcs = sorted(glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hip")))
 hdrs = glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hpp")) + [os.path.join(ROOT, "include", "nerfacc_hip.h")]
 if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs + hdrs):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                           "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", "-shared", *srcs, "-o", so])
+                           "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", *extra, "-shared", *srcs, "-o", so])
 if "--build-only" in sys.argv:
     sys.exit(0)
 os.environ["NERFACC_AMD_BACKEND"] = "ctypes"     # the instrumented copy is loaded through the ctypes face
