@@ -604,6 +604,25 @@ def main():
         stats["samples"] += n_samples
         state["step"] += 1
 
+    # ---- the path alone: the same ray draws, sampling and rendering calls (forward + backward), the field replaced by slices of
+    # two constant tensors — what the path sustains per step when the user's field costs nothing (an auxiliary figure, not the metric)
+    free_sig = torch.rand(1 << 21, device=device) * 20.0
+    free_rgb = torch.rand(1 << 21, 3, device=device)
+
+    def step_path_only():
+        n = state["num_rays"]
+        idx = torch.randint(0, args.pool, (n,), device=device)
+        rays_o, rays_d = pool_o[idx], pool_d[idx]
+        ri, ts, te = est.sampling(rays_o, rays_d, sigma_fn=lambda a, b, r: free_sig[:a.shape[0]], near_plane=0.0, far_plane=1e10,
+                                  render_step_size=RENDER_STEP, stratified=True, cone_angle=0.0, alpha_thre=0.0)
+        k = ts.shape[0]
+        leaves = (free_rgb[:k].detach().requires_grad_(True), free_sig[:k].detach().requires_grad_(True))
+        rgb, _, _, _ = nerfacc.rendering(ts, te, ri, n_rays=n, rgb_sigma_fn=lambda a, b, r: leaves, render_bkgd=bkgd)
+        if k > 0:
+            rgb.sum().backward()
+        stats["rays"] += n
+        stats["samples"] += k
+
     steps = {"api": step_api, "overlap": step_overlap}
 
     def timed_region(step_fn, n_steps, with_timer):
@@ -653,6 +672,12 @@ def main():
             steps[other_mode]()
         other = (other_mode, timed_region(steps[other_mode], args.steps, with_timer=False))
         state.pop("proposal", None)
+
+    path_only = None
+    if not args.no_other_mode and world_size == 1 and state["num_rays"] * 200 < free_sig.shape[0] * 4:
+        for _ in range(min(args.warmup, 10)):
+            step_path_only()
+        path_only = timed_region(step_path_only, args.steps, with_timer=False)
 
     prof = None
     if not args.no_profile and world_size == 1:
@@ -738,6 +763,11 @@ def main():
             name, r = other
             out["other_loop"] = {"loop": name, "ms_per_step": r["elapsed"] / args.steps * 1e3, "rays_per_sec": r["rays"] / r["elapsed"],
                                  "samples_per_sec": r["samples"] / r["elapsed"]}
+        if path_only is not None:
+            out["path_only_loop"] = {"ms_per_step": path_only["elapsed"] / args.steps * 1e3, "rays_per_sec": path_only["rays"] / path_only["elapsed"],
+                                     "samples_per_sec": path_only["samples"] / path_only["elapsed"],
+                                     "note": "estimator.sampling (visibility filter included) + nerfacc.rendering forward and backward on the same ray "
+                                             "draws with the field replaced by slices of constant tensors: the path without the stand-in field; not the metric"}
         if prof is not None:
             if "error" in prof:
                 out["gpu_activity"] = prof
