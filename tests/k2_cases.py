@@ -134,6 +134,17 @@ def _case(name):
     elif name == "degenerate":
         o, d, aabbs, binaries = _degenerate(rng, 1024, 32)
         kw = dict(step_size=3e-3)
+    elif name == "levels4_inside":    # the unbounded-scene shape: cameras inside the first of four levels, a blob + sparse far clutter
+        R, res = 4096, 64
+        c = (np.arange(res) + 0.5) / res * 2 - 1
+        X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+        binaries = np.stack([(((X * 2.0**l) ** 2 + (Y * 2.0**l) ** 2 + (Z * 2.0**l) ** 2) < 0.25) | (rng.random((res,) * 3) < (0.004 if l else 0.0))
+                             for l in range(4)])
+        o = (0.6 * _unit(rng.standard_normal((R, 3)).astype(np.float32))).astype(np.float32)
+        d = _unit(rng.standard_normal((R, 3)).astype(np.float32))
+        aabbs = _levels([-1, -1, -1, 1, 1, 1], 4)
+        extra["near_planes"] = np.full(R, 0.2, np.float32)
+        kw = dict(step_size=2e-3)
     else:
         raise KeyError(name)
     return dict(rays_o=o, rays_d=d, aabbs=aabbs, binaries=binaries, extra=extra, kw=kw)
@@ -141,7 +152,7 @@ def _case(name):
 
 # "ref_test_grid" (tests/test_grid.py:38-68 with torch's CPU generator, seed 42) stores its inputs in the fixture
 GENERATED = ["m1_noise", "m1_sphere", "lego_4k", "lego_70k", "two_level_256", "cone_angle", "cone_angle_levels",
-             "per_voxel", "steps_limit", "over_allocate", "near_far", "non_cubic", "degenerate"]
+             "per_voxel", "steps_limit", "over_allocate", "near_far", "non_cubic", "degenerate", "levels4_inside"]
 ALL = ["ref_test_grid"] + GENERATED
 FULL_LIMIT = 30000      # cases with fewer samples keep every output array in the fixture; the others digests
 

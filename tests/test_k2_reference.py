@@ -137,7 +137,7 @@ def test_hip_reproduces_reference_k2(name, k2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["m1_sphere", "lego_4k", "lego_70k", "near_far", "degenerate", "two_level_256", "non_cubic"])
+@pytest.mark.parametrize("name", ["m1_sphere", "lego_4k", "lego_70k", "near_far", "degenerate", "two_level_256", "non_cubic", "levels4_inside"])
 def test_hip_sampling_reproduces_reference_k2(name, k2):
     """OccGridEstimator.sampling (the fused count/emit kernels, not the general fill kernel) against the same
     fixture: ray_indices, t_starts = vals[is_left], t_ends = vals[is_right] (occ_grid.py:166-176)"""
