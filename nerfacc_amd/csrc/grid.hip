@@ -1873,6 +1873,60 @@ __global__ __launch_bounds__(1024) void excl_sum_i64_kernel(const int64_t *__res
     if (threadIdx.x == 0 && total) *total = carry_s;
 }
 
+// hierarchical form of the same scan for long arrays (nfa_exclusive_sum_i64): see the host function
+constexpr int64_t kScanSingleMax = 8192;
+__global__ __launch_bounds__(kBlock) void excl_sum_chunks_kernel(const int64_t *__restrict__ cnts, int64_t n, int64_t chunk,
+                                                                 int64_t *__restrict__ starts)
+{
+    __shared__ int64_t lds[kWavesPerBlock];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int64_t carry = 0;
+    for (int64_t base = lo; base < hi; base += kBlock) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < hi ? cnts[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_excl_scan_i64(v, lds, tot);
+        if (i < hi && i != lo) starts[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) starts[lo] = carry;            // the chunk's total, parked in the slot whose local value is 0
+}
+__global__ __launch_bounds__(1024) void excl_sum_parked_kernel(int64_t *__restrict__ starts, int64_t chunk, int64_t nb,
+                                                               int64_t *__restrict__ total)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t b = base + threadIdx.x;
+        const int64_t v = b < nb ? starts[b * chunk] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int64_t x = wsum[w]; if (w < wave) woff += x; tot += x; }
+        const int64_t carry = carry_s;
+        if (b < nb) starts[b * chunk] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+__global__ __launch_bounds__(kBlock) void excl_sum_add_kernel(int64_t *__restrict__ starts, int64_t n, int64_t chunk)
+{
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const int64_t off = starts[lo];
+    for (int64_t i = lo + 1 + threadIdx.x; i < hi; i += kBlock) starts[i] += off;
+}
+
 int validate_traverse(const nfa_traverse_args *a) {
     NFA_REQUIRE(a != nullptr, "traverse: args is NULL");
     NFA_REQUIRE(a->n_rays >= 0, "traverse: n_rays < 0");
@@ -2299,8 +2353,22 @@ NFA_EXPORT int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *st
         return NFA_OK;
     }
     NFA_REQUIRE(cnts && starts, "exclusive_sum_i64: NULL pointer");
-    hipLaunchKernelGGL(excl_sum_i64_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnts, n, starts, total);
-    return check_launch("excl_sum_i64_kernel");
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= kScanSingleMax) {
+        hipLaunchKernelGGL(excl_sum_i64_kernel, dim3(1), dim3(1024), 0, s, cnts, n, starts, total);
+        return check_launch("excl_sum_i64_kernel");
+    }
+    // three launches, in place, no scratch (the test-time marcher scans 640 000 counts four times per round: one workgroup
+    // crawling through them took 905 us): chunks of >= 2048 counts scanned locally by a workgroup each, the chunk's total
+    // parked in its FIRST slot (whose local value is always 0); the parked totals scanned in place by one workgroup — that IS
+    // the final value of those slots; every chunk then adds its first slot to its other slots.  At most 4096 chunks.
+    int64_t chunk = ceil_div(ceil_div(n, 4096), kBlock) * kBlock;
+    if (chunk < 2048) chunk = 2048;
+    const int64_t nb = ceil_div(n, chunk);
+    hipLaunchKernelGGL(excl_sum_chunks_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, cnts, n, chunk, starts);
+    hipLaunchKernelGGL(excl_sum_parked_kernel, dim3(1), dim3(1024), 0, s, starts, chunk, nb, total);
+    hipLaunchKernelGGL(excl_sum_add_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, starts, n, chunk);
+    return check_launch("excl_sum_chunks_kernel");
 }
 
 #ifdef NFA_PHASE_CYCLES

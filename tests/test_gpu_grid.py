@@ -229,6 +229,31 @@ def test_sampling_multi_level_segment_and_serial_count_passes(monkeypatch, level
         assert np.array_equal(n(term)[live], r_term[live])
 
 
+@pytest.mark.parametrize("n_", [1, 1000, 8192, 8193, 100000, 640000, 5_000_001])
+def test_exclusive_sum_i64_all_sizes(n_):
+    """data_spec.hpp:86-106 (chunk_starts = cumsum(cnts) - cnts, total): one workgroup up to 8192 counts, beyond that chunks
+    scanned by a workgroup each with the chunk totals parked in place — the over-allocated test-time pass scans one count per ray
+    of a frame"""
+    import ctypes
+
+    from nerfacc_amd.cuda import _backend
+
+    L = _backend.load_library()
+    g = torch.Generator(device=DEV).manual_seed(n_)
+    cnts = torch.randint(0, 1 << 20, (n_,), device=DEV, generator=g, dtype=torch.int64)
+    cnts[torch.rand(n_, device=DEV, generator=g) < 0.3] = 0
+    starts = torch.full((n_,), -1, device=DEV, dtype=torch.int64)
+    total = torch.full((1,), -1, device=DEV, dtype=torch.int64)
+    s = torch.cuda.current_stream().cuda_stream
+    for tot in (total, None):
+        rc = L.nfa_exclusive_sum_i64(ctypes.c_void_p(cnts.data_ptr()), n_, ctypes.c_void_p(starts.data_ptr()),
+                                     ctypes.c_void_p(tot.data_ptr()) if tot is not None else None, ctypes.c_void_p(s))
+        assert rc == 0
+        want = torch.cumsum(cnts, 0) - cnts
+        assert torch.equal(starts, want)
+    assert int(total) == int(cnts.sum())
+
+
 def test_sample_positions_bit_identical_to_the_torch_expression():
     import nerfacc_amd as nerfacc
 
