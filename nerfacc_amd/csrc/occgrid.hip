@@ -65,7 +65,17 @@ __global__ __launch_bounds__(kBlock) void grid_mean_partials_kernel(const float 
 {
     __shared__ double s_sum[kWavesPerBlock], s_cnt[kWavesPerBlock];
     double sum = 0.0, cnt = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    // four cells per load (the grid is a whole tensor: 16-byte aligned), the n % 4 cells at the end by the first threads
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(occs) & 15u) == 0 ? n >> 2 : 0;
+    const float4 *occs4 = reinterpret_cast<const float4 *>(occs);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const float4 v = occs4[i];
+        if (v.x >= 0.0f) { sum += (double)v.x; cnt += 1.0; }
+        if (v.y >= 0.0f) { sum += (double)v.y; cnt += 1.0; }
+        if (v.z >= 0.0f) { sum += (double)v.z; cnt += 1.0; }
+        if (v.w >= 0.0f) { sum += (double)v.w; cnt += 1.0; }
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const float v = occs[i];
         if (v >= 0.0f) { sum += (double)v; cnt += 1.0; }
     }
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void grid_mark_invisible_kernel(
 
 namespace nfa {
 int launch_grid_mean_partials(const float *occs, int64_t n_cells, double *partials, hipStream_t s) {
-    int nb = (int)blocks_for(n_cells);
+    int nb = (int)blocks_for(ceil_div(n_cells, 4));
     if (nb > kReduceBlocks) nb = kReduceBlocks;
     hipLaunchKernelGGL(grid_mean_partials_kernel, dim3(nb), dim3(kBlock), 0, s, occs, n_cells, partials);
     return nb;
