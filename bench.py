@@ -373,6 +373,96 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
 
 
 # ------------------------------------------------------------------------------------------
+# auxiliary leg: one PropNet training step (BASELINE.json configs[2]; examples/train_ngp_nerf_prop.py:150-245 with
+# examples/utils.py:170-264).  Not the metric: a few steps so that the pdf path is driver-measured too.
+# ------------------------------------------------------------------------------------------
+class DensityGrid(torch.nn.Module):
+    """proposal network stand-in (NGPDensityField is tiny-cuda-nn): sigma = exp(trilinear lookup in one res^3 grid)"""
+
+    def __init__(self, aabb, res):
+        super().__init__()
+        a = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("u_scale", 2.0 / (a[3:] - a[:3]))
+        self.register_buffer("u_shift", -2.0 * a[:3] / (a[3:] - a[:3]) - 1.0)
+        self.grid = torch.nn.Parameter(torch.full((1, 1, res, res, res), math.log(0.5)))
+
+    def forward(self, x):
+        u = torch.addcmul(self.u_shift, x.reshape(-1, 3), self.u_scale).view(1, 1, 1, -1, 3)
+        out = F.grid_sample(self.grid, u, mode="bilinear", padding_mode="border", align_corners=False)
+        return torch.exp(out.view(*x.shape[:-1], 1))
+
+
+def propnet_step_leg(field, pool_o, pool_d, pool_rgb, bkgd, n_steps, n_warmup, n_rays=4096,
+                     num_samples=48, num_samples_per_prop=(256, 96), near_plane=2.0, far_plane=6.0):
+    """configs[2]'s shapes (4096 rays, proposal levels of 256 and 96 samples, 48 final samples, lindisp, opaque background, two
+    proposal networks) on the bench scene; the radiance field is a copy of the bench's field, the proposal networks are 64^3 /
+    128^3 density grids.  A step = PropNetEstimator.sampling (2 x importance_sampling + transmittance per level, proposal
+    gradients on the reference's schedule: every 5th step after its first 1000) + batched rendering + update_every_n_steps
+    (searchsorted-based histogram loss, proposal optimizer) + smooth-L1 loss, backward, Adam."""
+    import copy
+
+    device = pool_o.device
+    rf = copy.deepcopy(field)
+    props = [DensityGrid(AABB, 64).to(device), DensityGrid(AABB, 128).to(device)]
+    prop_opt = torch.optim.Adam([q for m in props for q in m.parameters()], lr=1e-2, eps=1e-15, fused=True)
+    est = nerfacc.PropNetEstimator(prop_opt, None).to(device)
+    opt = torch.optim.Adam(rf.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
+    wants_grad = nerfacc.estimators.prop_net.get_proposal_requires_grad_fn()
+    counter = {"step": 1000}                      # the schedule's steady state: proposal gradients every 5th step
+
+    def step():
+        idx = torch.randint(0, pool_o.shape[0], (n_rays,), device=device)
+        o, d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
+
+        def prop_sigma_fn(t_starts, t_ends, net):
+            sig = net(o[:, None, :] + d[:, None, :] * (t_starts + t_ends)[..., None] / 2.0).clone()
+            sig[..., -1, :] = torch.inf                                  # opaque_bkgd
+            return sig.squeeze(-1)
+
+        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            pos = o[:, None, :] + d[:, None, :] * (t_starts + t_ends)[..., None] / 2.0
+            rgb, sig = rf(pos.reshape(-1, 3))
+            rgb, sig = rgb.reshape(*pos.shape[:-1], 3), sig.reshape(*pos.shape[:-1], 1).clone()
+            sig[..., -1, :] = torch.inf
+            return rgb, sig.squeeze(-1)
+
+        req = wants_grad(counter["step"])
+        t_starts, t_ends = est.sampling(prop_sigma_fns=[lambda *a, n=n: prop_sigma_fn(*a, n) for n in props],
+                                        prop_samples=list(num_samples_per_prop), num_samples=num_samples, n_rays=n_rays,
+                                        near_plane=near_plane, far_plane=far_plane, sampling_type="lindisp", stratified=True,
+                                        requires_grad=req)
+        rgb, _, _, extras = nerfacc.rendering(t_starts, t_ends, ray_indices=None, n_rays=None, rgb_sigma_fn=rgb_sigma_fn,
+                                              render_bkgd=bkgd)
+        est.update_every_n_steps(extras["trans"], req, loss_scaler=1024)
+        loss = F.smooth_l1_loss(rgb, pixels)
+        opt.zero_grad()
+        (loss * 1024.0).backward()
+        opt.step()
+        counter["step"] += 1
+
+    for _ in range(n_warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = profile_steps(step, min(n_steps, 10))
+    per_ray = num_samples + sum(num_samples_per_prop)
+    out = {"workload": f"configs[2] shapes on the bench scene: {n_rays} rays x proposal levels {list(num_samples_per_prop)} -> {num_samples} "
+                       "samples, lindisp, opaque background, 2 proposal density grids (64^3, 128^3) + the bench's field; proposal "
+                       "gradients every 5th step (the reference schedule's steady state)",
+           "steps": n_steps, "ms_per_step": el / n_steps * 1e3, "rays_per_sec": n_rays * n_steps / el,
+           "samples_per_sec": n_rays * num_samples * n_steps / el, "field_queries_per_sec": n_rays * per_ray * n_steps / el}
+    if prof is not None and "error" not in prof:
+        out["path_us_per_step"] = prof["nfa_us_per_step"]
+        out["gpu_busy_us_per_step"] = prof["busy_us_per_step"]
+        out["top_kernels_us_per_step"] = prof["top_kernels_us_per_step"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 # GPU activity of a few profiled steps: union of kernel intervals (idle fraction) and the nfa:: share
 # ------------------------------------------------------------------------------------------
 def profile_steps(step_fn, n_steps):
@@ -456,10 +546,29 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="dry run of the N > 1 code path on a single GPU (with --dist-backend gloo): every rank uses cuda:0")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of --steps steps each (every one bracketed by barrier + synchronize); ms_per_step / value are "
+                         "the MEDIAN window's, all of them are printed as ms_per_step_windows")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (and use ExchangeAdam's exchange) even with one rank: the RCCL world-1 smoke test")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (configs[4] 256^3 grid, configs[2] PropNet step)")
+    ap.add_argument("--aux-steps", type=int, default=40, help="timed steps of each auxiliary leg")
     ap.add_argument("--dump-sampling-state", default="",
                     help="write the occupancy grid and one ray batch of the timed steady state to this .npz "
                          "(tools/traverse_replay.py replays the sampling call on it under rocprofv3)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves, exactly as the driver would
+        # (torch.distributed.run, one rank per GPU); rank 0's line is the only thing on stdout
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -469,11 +578,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world_size > 1:
+    exchanging = world_size > 1 or args.force_dist
+    if exchanging:
+        if "MASTER_ADDR" not in os.environ:                  # --force-dist outside a launcher
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world_size)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
     fixed_rays = args.rays_per_iter // world_size if args.rays_per_iter > 0 else 0
 
     torch.manual_seed(42)
@@ -484,7 +599,7 @@ def main():
         field.grid[:, 1:].zero_()
     est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
     est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
-    if world_size > 1:
+    if exchanging:
         optimizer = sharding.ExchangeAdam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=args.grad_chunks)
     else:
         optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
@@ -509,7 +624,7 @@ def main():
     est.train()
     torch.manual_seed(1000 + rank)
 
-    state = {"num_rays": fixed_rays or INIT_RAYS, "step": 0}
+    state = {"num_rays": fixed_rays or INIT_RAYS, "step": 0, "est": est}     # state["est"]: the estimator the step functions use
     stats = {"rays": 0, "samples": 0}
     side = torch.cuda.Stream(device=device)
 
@@ -525,12 +640,12 @@ def main():
             loss = F.smooth_l1_loss(rgb, pixels)
             (loss * loss_scale).backward()
         # every rank takes part in the exchange every step, samples or not (ExchangeAdam.step all-reduces)
-        if n_samples > 0 or world_size > 1:
+        if n_samples > 0 or exchanging:
             optimizer.step()
 
     def refresh_grid(step):
         with sharding.synchronized_rng(5000 + step, device):
-            est.update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+            state["est"].update_every_n_steps(step=step, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
 
     # ---- the reference examples' step, through the public API only ------------------------------------------------
     def step_api():
@@ -540,7 +655,7 @@ def main():
         n = state["num_rays"]
         idx = torch.randint(0, args.pool, (n,), device=device)
         rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
-        rgb, _, _, n_samples = render_rays_reference_style(field, est, rays_o, rays_d, bkgd, True)
+        rgb, _, _, n_samples = render_rays_reference_style(field, state["est"], rays_o, rays_d, bkgd, True)
         pending = sharding.allreduce_counts_begin(n_samples, n, device)
         backward_and_update(rgb, pixels, n_samples)
         next_num_rays(*sharding.allreduce_counts_end(pending))
@@ -558,7 +673,8 @@ def main():
             rays_o, rays_d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
             near = torch.rand(n, device=device) * RENDER_STEP          # near_plane 0 + stratified jitter (occ_grid.py:162-163)
             far = torch.full((n,), 1e10, device=device)
-            ri, ts, te, _ = nerfacc.cuda.sample_occgrid(rays_o, rays_d, est.binaries, est.aabbs, near, far, RENDER_STEP, 0.0)
+            e = state["est"]
+            ri, ts, te, _ = nerfacc.cuda.sample_occgrid(rays_o, rays_d, e.binaries, e.aabbs, near, far, RENDER_STEP, 0.0)
         return dict(n=n, rays_o=rays_o, rays_d=rays_d, pixels=pixels, ri=ri, ts=ts, te=te)
 
     def render_proposed(prop):
@@ -613,7 +729,7 @@ def main():
         n = state["num_rays"]
         idx = torch.randint(0, args.pool, (n,), device=device)
         rays_o, rays_d = pool_o[idx], pool_d[idx]
-        ri, ts, te = est.sampling(rays_o, rays_d, sigma_fn=lambda a, b, r: free_sig[:a.shape[0]], near_plane=0.0, far_plane=1e10,
+        ri, ts, te = state["est"].sampling(rays_o, rays_d, sigma_fn=lambda a, b, r: free_sig[:a.shape[0]], near_plane=0.0, far_plane=1e10,
                                   render_step_size=RENDER_STEP, stratified=True, cone_angle=0.0, alpha_thre=0.0)
         k = ts.shape[0]
         leaves = (free_rgb[:k].detach().requires_grad_(True), free_sig[:k].detach().requires_grad_(True))
@@ -662,7 +778,13 @@ def main():
     state["step"] += (-state["step"]) % 16 + 1           # the timed region starts one step after a grid refresh
     for _ in range(args.warmup):
         steps[args.mode]()
-    main_run = timed_region(steps[args.mode], args.steps, with_timer=True)
+    if hasattr(optimizer, "timing"):
+        optimizer.timing = True
+    windows = [timed_region(steps[args.mode], args.steps, with_timer=True) for _ in range(max(1, args.windows))]
+    comm = optimizer.comm_stats() if hasattr(optimizer, "comm_stats") else None
+    if hasattr(optimizer, "timing"):
+        optimizer.timing = False
+    main_run = sorted(windows, key=lambda w: w["elapsed"])[(len(windows) - 1) // 2]      # the median window
     state.pop("proposal", None)
 
     other = None
@@ -685,6 +807,34 @@ def main():
             steps[args.mode]()
         prof = profile_steps(steps[args.mode], min(args.steps, 32))
         state.pop("proposal", None)
+
+    path_prof = None
+    if path_only is not None and not args.no_profile:
+        path_prof = profile_steps(step_path_only, min(args.steps, 32))
+
+    aux = {}
+    if not args.no_aux and world_size == 1:
+        if args.occ_res != 256:
+            # configs[4]'s grid size: the SAME step with a 256^3 occupancy grid built from the trained field
+            est256 = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=256, levels=1).to(device)
+            est256.train()
+            with sharding.synchronized_rng(777, device):
+                for _ in range(4):
+                    est256._update(step=0, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+            saved = (state["est"], state["num_rays"], state["step"])
+            state["est"] = est256
+            state["step"] += (-state["step"]) % 16 + 1
+            for _ in range(min(args.warmup, 10)):
+                step_api()
+            r = timed_region(step_api, args.aux_steps, with_timer=False)
+            aux["configs4_occgrid_256"] = {
+                "workload": "the configs[1] step of this line with a 256^3 occupancy grid (configs[4]'s grid size) on the same scene and field",
+                "steps": args.aux_steps, "ms_per_step": r["elapsed"] / args.aux_steps * 1e3, "rays_per_sec": r["rays"] / r["elapsed"],
+                "samples_per_sec": r["samples"] / r["elapsed"], "rays_per_iter": r["local_rays"] / args.aux_steps,
+                "occupied_fraction": est256.binaries.float().mean().item()}
+            state["est"], state["num_rays"], state["step"] = saved
+            del est256
+        aux["configs2_propnet_step"] = propnet_step_leg(field, pool_o, pool_d, pool_rgb, bkgd, args.aux_steps, min(args.warmup, 10))
 
     if rank == 0:
         elapsed = main_run["elapsed"]
@@ -742,6 +892,7 @@ def main():
             "samples_per_sec": main_run["samples"] / elapsed,
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_windows": [w["elapsed"] / args.steps * 1e3 for w in windows],
             "higher_is_better": True, "scaling": "strong" if fixed_rays else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
@@ -768,6 +919,18 @@ def main():
                                      "samples_per_sec": path_only["samples"] / path_only["elapsed"],
                                      "note": "estimator.sampling (visibility filter included) + nerfacc.rendering forward and backward on the same ray "
                                              "draws with the field replaced by slices of constant tensors: the path without the stand-in field; not the metric"}
+        if path_prof is not None and "error" not in path_prof and "path_only_loop" in out:
+            po = out["path_only_loop"]
+            po["path_us_per_step"] = path_prof["nfa_us_per_step"]
+            po["gpu_idle_frac"] = max(0.0, 1.0 - path_prof["busy_us_per_step"] / (po["ms_per_step"] * 1e3))
+        if aux:
+            out["aux"] = aux
+        if comm is not None and comm["steps"] > 0:
+            out["comm_ms_per_step"] = comm["wait_ms"]
+            out["comm_window_ms_per_step"] = comm["window_ms"]
+            out["exchange_bytes"] = comm["exchange_bytes"]
+            out["comm_note"] = ("comm_ms_per_step = time the compute stream stood still waiting for gradient chunks (exposed exchange), "
+                                "comm_window = first all-reduce launch (inside backward) to last chunk's arrival; rank 0's events")
         if prof is not None:
             if "error" in prof:
                 out["gpu_activity"] = prof
@@ -778,7 +941,7 @@ def main():
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(field, est, pool_o, pool_d)
         print(json.dumps(out))
-    if world_size > 1:
+    if exchanging:
         dist.destroy_process_group()
 
 

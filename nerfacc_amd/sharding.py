@@ -111,25 +111,45 @@ def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
 
 class ExchangeAdam:
     """Adam over ONE flat fp32 parameter buffer with the gradient exchange folded in: the flat gradient is cut
-    into `n_chunks` contiguous chunks, every chunk's all-reduce is started at once (async), and the Adam update
-    of chunk k runs as soon as chunk k has arrived — while chunks k+1.. are still on the wire.  With one
-    rank (or no process group) it is a plain chunked Adam.  Same update rule as torch.optim.Adam
-    (L2 weight decay added to the gradient, bias correction, eps outside the square root).
+    into `n_chunks` contiguous chunks, every chunk is all-reduced asynchronously, and the Adam update of chunk k
+    runs as soon as chunk k has arrived — while the other chunks are still on the wire.  Same update rule as
+    torch.optim.Adam (L2 weight decay added to the gradient, bias correction, eps outside the square root).
 
     `params`: parameters whose storage is packed into the flat buffer (their .data / .grad become views of
-    it, so autograd accumulates straight into the exchange buffer: no staging copies)."""
+    it, so autograd accumulates straight into the exchange buffer: no staging copies).
+
+    **When a chunk's all-reduce starts.**  With `overlap_backward` (default) every parameter carries a
+    post-accumulate-grad hook: a chunk is launched from inside the backward pass as soon as every parameter that
+    overlaps it has its gradient — in a FIXED order, last chunk first (autograd reaches the last parameters of a
+    model first), so that all ranks issue the same sequence of collectives whatever their graphs look like; a
+    chunk that becomes ready out of turn waits for its predecessors.  `step()` launches what is left (ranks whose
+    backward did not run — no samples this step — or parameters the loss did not reach) in the same order.  A
+    field that is ONE tensor (bench.py's voxel grid) gets all its chunks launched by that tensor's hook, i.e. at
+    the end of its backward kernel: nothing of the backward pass is left to overlap with, only the host time up
+    to `optimizer.step()` and the Adam passes of the earlier chunks.  Use `overlap_backward=False` when gradients
+    are accumulated over several backward passes per step.
+
+    The exchange runs whenever a process group is initialised — also with one rank (an RCCL all-reduce over a
+    world of 1 is a valid collective: the single-GPU smoke test of this path); without a process group it is a
+    plain chunked Adam.
+
+    `timing = True` records HIP events around the exchange (`comm_stats()`): `wait_ms` — how long the compute
+    stream stood still waiting for chunks (the exposed communication), `window_ms` — first launch to last arrival.
+    """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-2, betas=(0.9, 0.999), eps=1e-15,
-                 weight_decay=0.0, n_chunks: int = 4, average: bool = True):
+                 weight_decay=0.0, n_chunks: int = 4, average: bool = True, overlap_backward: bool = True):
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets: List[int] = []
         off = 0
         for p in self.params:
             k = p.numel()
+            self.offsets.append(off)
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
             p.grad = self.grad[off:off + k].view_as(p.data)
@@ -144,10 +164,85 @@ class ExchangeAdam:
         self.bounds = [(a, min(a + size, total)) for a in range(0, total, size)]
         self.step_tensor = torch.zeros((), dtype=torch.float32, device=dev)
         self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
+        # chunk k is complete when `_need[k]` parameters have reported; parameter i reports to `_chunks_of[i]`
+        self._chunks_of: List[List[int]] = []
+        self._need = [0] * len(self.bounds)
+        for off, p in zip(self.offsets, self.params):
+            ks = [k for k, (a, b) in enumerate(self.bounds) if off < b and off + p.numel() > a]
+            self._chunks_of.append(ks)
+            for k in ks:
+                self._need[k] += 1
+        self._have = [0] * len(self.bounds)
+        self._reported = [False] * len(self.params)
+        self._works: List = [None] * len(self.bounds)
+        self._next = len(self.bounds) - 1                    # chunks are launched last to first
+        self.overlap_backward = bool(overlap_backward) and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
+        self._hooks = []
+        if self.overlap_backward:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.timing = False
+        self._events: List = []
+        self._first_launch = None
+        self.exchange_bytes = 4 * total
 
-    def zero_grad(self) -> None:
+    # ---- bookkeeping ----------------------------------------------------------------------------------------------
+    def _exchanging(self) -> bool:
+        return dist.is_available() and dist.is_initialized()
+
+    def _slot(self, i: int) -> torch.Tensor:
+        p, off = self.params[i], self.offsets[i]
+        return self.grad[off:off + p.numel()].view_as(p.data)
+
+    def _bound(self, i: int) -> bool:
+        g = self.params[i].grad
+        return g is not None and g.data_ptr() == self.grad.data_ptr() + 4 * self.offsets[i] and g.is_contiguous()
+
+    def _rebind(self, i: int) -> None:
+        """p.grad was set to None (zero_grad(set_to_none=True)) or replaced: autograd then allocates gradients outside
+        the flat buffer.  Move what is there into the parameter's slot and make p.grad the view again."""
+        p, slot = self.params[i], self._slot(i)
+        if p.grad is None:
+            slot.zero_()
+        else:
+            slot.copy_(p.grad.to(torch.float32).reshape(slot.shape))
+        p.grad = slot
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """zeroes the flat gradient; the parameters' .grad stay views of it whatever `set_to_none` says"""
         self.grad.zero_()
+        for i in range(len(self.params)):
+            if not self._bound(i):
+                self.params[i].grad = self._slot(i)
 
+    def _make_hook(self, i: int):
+        def hook(_param):
+            if self._reported[i] or not self._exchanging():
+                return
+            if not self._bound(i):
+                self._rebind(i)
+            self._report(i)
+            self._launch_ready()
+        return hook
+
+    def _report(self, i: int) -> None:
+        self._reported[i] = True
+        for k in self._chunks_of[i]:
+            self._have[k] += 1
+
+    def _launch(self, k: int) -> None:
+        a, b = self.bounds[k]
+        if self.timing and self._first_launch is None and self.grad.is_cuda:
+            self._first_launch = torch.cuda.Event(enable_timing=True)
+            self._first_launch.record()
+        self._works[k] = dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _launch_ready(self) -> None:
+        while self._next >= 0 and self._have[self._next] >= self._need[self._next]:
+            self._launch(self._next)
+            self._next -= 1
+
+    # ---- the step -------------------------------------------------------------------------------------------------
     def _adam(self, a: int, b: int) -> None:
         p, g, m, v = self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b]
         b1, b2 = self.betas
@@ -167,20 +262,77 @@ class ExchangeAdam:
         p.addcdiv_(m, denom, value=-self.lr / bc1)
 
     def step(self) -> None:
-        """all-reduce (average) the flat gradient chunk by chunk and update every chunk as it arrives"""
-        rank, ws = world()
+        """finish the exchange (launch the chunks the backward pass did not, in the fixed order) and update every chunk
+        as it arrives, in arrival (= launch) order"""
         self.t += 1
         self.step_tensor += 1
-        works = []
-        if ws > 1:
-            for a, b in self.bounds:
-                works.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
-        for k, (a, b) in enumerate(self.bounds):
-            if works:
-                works[k].wait()                              # the current stream waits for this chunk only
-                if self.average:
+        exchanging = self._exchanging()
+        ws = dist.get_world_size() if exchanging else 1
+        for i in range(len(self.params)):                    # gradients that were produced outside the flat buffer
+            if not self._bound(i):
+                assert not self._reported[i], "ExchangeAdam: a gradient was replaced after its chunk had been sent"
+                self._rebind(i)
+        if exchanging:
+            for i in range(len(self.params)):
+                if not self._reported[i]:
+                    self._report(i)
+            self._launch_ready()
+            assert self._next < 0
+        timed = self.timing and self.grad.is_cuda and exchanging
+        waits = []
+        for k in range(len(self.bounds) - 1, -1, -1):
+            a, b = self.bounds[k]
+            if exchanging:
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                self._works[k].wait()                        # the current stream waits for this chunk only
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    waits.append((e0, e1))
+                if self.average and ws > 1:
                     self.grad[a:b].div_(ws)
             self._adam(a, b)
+        if timed:
+            self._events.append((self._first_launch, waits))
+        self._first_launch = None
+        self._works = [None] * len(self.bounds)
+        self._have = [0] * len(self.bounds)
+        self._reported = [False] * len(self.params)
+        self._next = len(self.bounds) - 1
+
+    def comm_stats(self, reset: bool = True) -> dict:
+        """per-step averages over the steps taken with `timing = True` (synchronises the device)"""
+        if not self._events:
+            return {"steps": 0, "wait_ms": 0.0, "window_ms": 0.0, "exchange_bytes": self.exchange_bytes}
+        torch.cuda.synchronize(self.grad.device)
+        wait = window = 0.0
+        for first, waits in self._events:
+            wait += sum(e0.elapsed_time(e1) for e0, e1 in waits)
+            window += first.elapsed_time(waits[-1][1]) if first is not None else 0.0
+        n = len(self._events)
+        if reset:
+            self._events = []
+        return {"steps": n, "wait_ms": wait / n, "window_ms": window / n, "exchange_bytes": self.exchange_bytes}
+
+    # ---- checkpointing --------------------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        return {"flat": self.flat.clone(), "m": self.m.clone(), "v": self.v.clone(), "t": self.t,
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay},
+                "numels": [p.numel() for p in self.params]}
+
+    def load_state_dict(self, state: dict) -> None:
+        assert list(state["numels"]) == [p.numel() for p in self.params], "ExchangeAdam: parameter layout differs"
+        with torch.no_grad():
+            self.flat.copy_(state["flat"])
+            self.m.copy_(state["m"])
+            self.v.copy_(state["v"])
+        self.t = int(state["t"])
+        self.step_tensor.fill_(float(self.t))
+        h = state.get("hyper", {})
+        self.lr, self.eps, self.weight_decay = h.get("lr", self.lr), h.get("eps", self.eps), h.get("weight_decay", self.weight_decay)
+        self.betas = tuple(h.get("betas", self.betas))
 
 
 def broadcast_grid(estimator, src: int = 0) -> None:

@@ -301,7 +301,13 @@ def accumulate_along_rays(
     if ray_indices is not None:
         assert n_rays is not None, "n_rays must be provided"
         assert weights.dim() == 1, "weights must be flattened"
-        # flattened layout = HIP kernel, always (device tensors only; raises otherwise)
+        if not weights.is_cuda:
+            # host tensors: the reference's function is a pure-torch `index_add_` here and device-agnostic
+            # (volrend.py:549-558) — the same composition, no native code and nothing of oracle/ involved
+            src = weights[..., None] if values is None else weights[..., None] * values
+            out = torch.zeros((int(n_rays), src.shape[-1]), device=src.device, dtype=src.dtype)
+            return out.index_add_(0, ray_indices, src)
+        # device tensors, flattened layout = HIP kernel, always
         return _Accumulate.apply(ray_indices.contiguous(), weights, values, int(n_rays))
     src = weights[..., None] if values is None else weights[..., None] * values
     return torch.sum(src, dim=-2)
@@ -319,6 +325,9 @@ def accumulate_along_rays_(
         assert weights.dim() == 1, "weights must be flattened"
         D = 1 if values is None else values.shape[-1]
         assert outputs.dim() == 2 and outputs.shape[-1] == D, "outputs must be of shape (n_rays, D)"
+        if not weights.is_cuda:               # host tensors: the reference's own `index_add_` (volrend.py:582-584)
+            outputs.index_add_(0, ray_indices, weights[..., None] if values is None else weights[..., None] * values)
+            return
         with torch.no_grad():
             _C.accumulate_along_rays(ray_indices.contiguous(), weights.contiguous(),
                                      None if values is None else values.contiguous(), outputs.shape[0], outputs)

@@ -23,12 +23,27 @@ def _free_port():
     return p
 
 
+def _clean_env():
+    """the launch styles under test must not inherit a rendezvous from whatever runs pytest"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("launch", ["torchrun", "self-spawn"])
 @pytest.mark.parametrize("extra", [[], ["--rays-per-iter", "4096"]])
-def test_two_ranks_on_one_device(extra):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--pretrain", "40", "--pool", "65536", "--dist-backend", "gloo", "--all-ranks-on-device0"] + extra
-    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+def test_two_ranks_on_one_device(extra, launch):
+    """launch = torchrun: the driver's N > 1 command; self-spawn: `python bench.py --gpus 2` with no launcher around it
+    (the shape of the driver's N = 1 command) starts its own ranks and still prints ONE line."""
+    bench_args = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "2", "--pretrain", "40", "--pool", "65536",
+                  "--dist-backend", "gloo", "--all-ranks-on-device0"] + extra
+    if launch == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + bench_args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=_clean_env())
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints ONE line
@@ -39,3 +54,51 @@ def test_two_ranks_on_one_device(extra):
     if extra:
         assert out["config"]["rays_per_iter_per_gpu"] == 2048       # 4096 global rays / 2 ranks
     assert "other_loop" in out and out["other_loop"]["ms_per_step"] > 0
+    assert len(out["ms_per_step_windows"]) == 2 and out["ms_per_step"] in out["ms_per_step_windows"]
+    assert out["exchange_bytes"] == 4 * 4 * 128**3 and out["comm_ms_per_step"] >= 0 and out["comm_window_ms_per_step"] >= 0
+
+
+def test_rccl_world_of_one():
+    """the first RCCL initialisation of this repository: backend "nccl" with ONE rank, the step through ExchangeAdam's chunked
+    all-reduce (launched from the gradient hook inside backward) + fused per-chunk Adam, comm figures on the line"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "4",
+           "--warmup", "2", "--windows", "1", "--pretrain", "40", "--pool", "65536", "--no-cpu-baseline", "--no-aux", "--no-profile"]
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=_clean_env())
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and math.isfinite(out["value"]) and out["value"] > 0
+    assert out["exchange_bytes"] == 4 * 4 * 128**3 and out["comm_window_ms_per_step"] > 0
+
+
+def test_exchange_adam_on_rccl_matches_fused_adam():
+    """4 steps through ExchangeAdam over an RCCL world of one == torch.optim.Adam(fused) on the same gradients"""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from nerfacc_amd import sharding
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+torch.manual_seed(0)
+a = [torch.nn.Parameter(torch.randn(1 << 20, device=dev)), torch.nn.Parameter(torch.randn(300, 7, device=dev))]
+b = [torch.nn.Parameter(x.detach().clone()) for x in a]
+oa = torch.optim.Adam(a, lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
+ob = sharding.ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=4)
+ob.timing = True
+for it in range(4):
+    for ps, o in ((a, oa), (b, ob)):
+        o.zero_grad()
+        (sum(((p * 1.3 - 0.2) ** 2).sum() for p in ps) * (it + 1)).backward()
+        o.step()
+st = ob.comm_stats()
+assert st["steps"] == 4 and st["window_ms"] > 0, st
+for x, y in zip(a, b):
+    assert torch.allclose(x, y, atol=1e-6, rtol=1e-5), (x - y).abs().max()
+dist.destroy_process_group()
+print("ok", st)
+''' % (ROOT, str(_free_port()))
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                         env=_clean_env())
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]

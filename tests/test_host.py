@@ -55,8 +55,17 @@ def test_native_paths_refuse_cpu_tensors():
         nerfacc.pack_info(ri, 2)
     with pytest.raises(RuntimeError):
         nerfacc.render_weight_from_density(x, x + 1, x, ray_indices=ri)
-    with pytest.raises(RuntimeError):
-        nerfacc.accumulate_along_rays(x, None, ri, 2)
+    # ... except where the reference's function is a device-agnostic torch composition: flattened accumulate is
+    # `index_add_` on host tensors (reference volrend.py:549-558, 582-584)
+    v = torch.rand(3, 2, requires_grad=True)
+    out = nerfacc.accumulate_along_rays(x, v, ri, 2)
+    assert torch.allclose(out, torch.stack([x[0] * v[0] + x[1] * v[1], x[2] * v[2]]))
+    out.sum().backward()
+    assert torch.allclose(v.grad, x[:, None].expand(3, 2))
+    acc = torch.ones(2, 1)
+    from nerfacc_amd.volrend import accumulate_along_rays_
+    accumulate_along_rays_(x, None, ri, acc)
+    assert torch.allclose(acc[:, 0], 1 + torch.stack([x[0] + x[1], x[2]]))
     with pytest.raises(RuntimeError):
         nerfacc.exclusive_sum(x, indices=ri)
     est = nerfacc.OccGridEstimator([-1.0, -1, -1, 1, 1, 1], 8)

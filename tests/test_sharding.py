@@ -65,7 +65,10 @@ def _worker(rank, world, port, out_dir):
         net = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.Tanh(), torch.nn.Linear(32, 3))
         opt = sharding.ExchangeAdam(net.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=3)
         for it in range(4):
-            opt.zero_grad()
+            if it == 1:
+                net.zero_grad(set_to_none=True)              # detaches the flat-buffer views: the hooks / step() re-bind them
+            else:
+                opt.zero_grad()
             if not (rank == 1 and it == 2):                  # a rank without samples still joins the exchange (zero grads)
                 torch.nn.functional.smooth_l1_loss(net(rays[b:e]), target[b:e]).mul(1024.0).backward()
             opt.step()
@@ -153,4 +156,49 @@ def test_exchange_adam_single_process_matches_torch_adam():
             (sum(((p * 1.3 - 0.2) ** 2).sum() for p in ps) * (it + 1)).backward()
             o.step()
     for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)
+
+
+def test_exchange_adam_survives_detached_grads_and_checkpoints():
+    """model.zero_grad(set_to_none=True) / p.grad = None detach the flat-buffer views; step() must notice,
+    pull the freshly allocated gradients in and re-bind.  state_dict / load_state_dict resume bit-identically."""
+    torch.manual_seed(1)
+    a = [torch.nn.Parameter(torch.randn(300, 3)), torch.nn.Parameter(torch.randn(77)), torch.nn.Parameter(torch.randn(5, 5))]
+    b = [torch.nn.Parameter(x.detach().clone()) for x in a]
+    oa = torch.optim.Adam(a, lr=1e-2, eps=1e-15, weight_decay=1e-6)
+    ob = sharding.ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=4)
+
+    def loss(ps, it):
+        # the last parameter gets no gradient at it == 3 (set_to_none leaves it None: counts as zero)
+        return sum(((p * 1.3 - 0.2) ** 2).sum() for p in (ps[:2] if it == 3 else ps)) * (it + 1)
+
+    snap = None
+    for it in range(8):
+        oa.zero_grad(set_to_none=False)
+        if it % 2:
+            for p in b:                      # what torch's Module.zero_grad() does by default
+                p.grad = None
+        else:
+            ob.zero_grad()
+        if it == 5:
+            b[1].grad = torch.zeros(77)      # a replaced gradient tensor
+        for ps in (a, b):
+            loss(ps, it).backward()
+        oa.step()
+        ob.step()
+        assert all(ob._bound(i) for i in range(3))
+        if it == 3:
+            snap = ob.state_dict()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)
+    # resume from the snapshot taken after step 4 (it == 3) in a fresh optimizer over fresh parameters
+    c = [torch.nn.Parameter(torch.zeros_like(x)) for x in a]
+    oc = sharding.ExchangeAdam(c, lr=1.0, n_chunks=2)
+    oc.load_state_dict(snap)
+    assert oc.t == 4 and oc.lr == 1e-2 and float(oc.step_tensor) == 4.0
+    for it in range(4, 8):
+        oc.zero_grad()
+        loss(c, it).backward()
+        oc.step()
+    for x, y in zip(b, c):
         assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)
