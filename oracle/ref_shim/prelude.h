@@ -102,3 +102,21 @@ struct OptionalCUDAGuard {
     template <class T> explicit OptionalCUDAGuard(T&&) {}
 };
 }}  // namespace at::cuda
+
+// --- float -> int conversion rule (build `gpu` only, -DREF_GPU_F2I) ----------------------------------------------------
+// The reference converts with C casts `int(a.x)` (utils_math.cuh:177-179, reached from utils_grid.cuh:72-82, 104).  On a GPU
+// that cast saturates and maps NaN to 0 (cvt.rzi.s32.f32 / v_cvt_i32_f32); x86's cvttss2si returns INT_MIN for both.  The
+// two differ only for rays lying IN a bounding plane of a level (0 * inf = NaN in the slab test).  A function-like macro
+// named `int` re-routes exactly the `int(expr)` casts of the sources parsed after this point; declarations (`int x`) are
+// not function-like uses and stay as they are.  Every header the sources need is already included above.
+#ifdef REF_GPU_F2I
+#include <climits>
+template <class T> static inline int ref_f2i(T v) { return static_cast<int>(v); }
+template <> inline int ref_f2i<float>(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT_MAX;
+    if (v <= -2147483648.0f) return INT_MIN;
+    return static_cast<int>(v);
+}
+#define int(x) ref_f2i(x)
+#endif

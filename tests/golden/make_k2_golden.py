@@ -34,13 +34,15 @@ def main():
 
     assert nerfacc.__file__.startswith(REF), nerfacc.__file__
     builds = {k: importlib.import_module("nerfacc_ref_" + k) for k in ("off", "fma")}
+    gpu_rule_build = importlib.import_module("nerfacc_ref_gpu")      # fma + the GPU's float -> int conversion rule (prelude.h)
+    only_inplane = "--only-inplane" in sys.argv
     import k2_cases as K
 
     sys.path.append(ROOT)
     import oracle
 
     def run_reference(build, c):
-        backend._C = builds[build]
+        backend._C = builds[build] if isinstance(build, str) else build
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
         extra = {k: tt(v) for k, v in c["extra"].items()}
         iv, sm, term = G.traverse_grids(tt(c["rays_o"]), tt(c["rays_d"]), tt(c["binaries"]), tt(c["aabbs"]), **extra, **c["kw"])
@@ -70,6 +72,26 @@ def main():
                     ray_of = np.searchsorted(starts, np.flatnonzero(neq), side="right") - 1
                     bad[np.unique(ray_of)] = True
         return int(bad.sum()), R
+
+    # ---- rays lying IN bounding planes of a level: pinned by the reference built with the GPU's conversion rule -------------
+    fx, rep = {}, {}
+    for name in K.GPU_RULE:
+        c = K.build_case(name)
+        # (the x86-rule builds cannot run these rays: INT_MIN indices make the reference's walk read outside the grid — segfault)
+        out, orc = run_reference(gpu_rule_build, c), run_oracle(c)
+        d_orc, R = differing_rays(out, orc)
+        rep[name] = dict(rays=R, samples=int(out["sm_chunk_cnts"].sum()), rays_differing_oracle_vs_gpu_rule=d_orc, fixture_build="gpu")
+        fx[f"{name}/input_sha"] = np.array(K.input_digest(c))
+        for k in K.OUTPUT_KEYS:
+            fx[f"{name}/sha/{k}"] = np.array(K.sha(out[k]))
+        fx[f"{name}/cnts/sm_chunk_cnts"] = out["sm_chunk_cnts"].astype(np.int32)
+        fx[f"{name}/cnts/iv_chunk_cnts"] = out["iv_chunk_cnts"].astype(np.int32)
+        print(f"{name:20s} rays {R:6d} samples {rep[name]['samples']:8d}  oracle != gpu-rule build {d_orc:4d}")
+    np.savez_compressed(os.path.join(HERE, "k2_inplane.npz"), **fx)
+    with open(os.path.join(HERE, "k2_inplane.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    if only_inplane:
+        return
 
     fixture, report = {}, {}
     # ---- the reference's own test configuration (tests/test_grid.py:38-68), torch CPU generator ---------------

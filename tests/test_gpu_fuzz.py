@@ -128,3 +128,36 @@ def test_many_transitions_overflow_paths():
             assert fused(o, d, g[None], aabbs, 2e-3) > 0
     finally:
         os.environ.pop("NFA_SPLIT_P", None)
+
+
+def test_randomised_fuzz_time_boxed():
+    """A fresh seed from the clock on every run (printed on failure; NFA_FUZZ_SEED replays it), ~18 s of the long campaigns'
+    generators (tests/fuzz_cases.py): one-level grids under every lanes-per-ray form of the count pass, several levels under
+    both count passes with and without a cone angle, and the reference-API call with per-voxel mode / step limits /
+    over-allocation / ray masks — HIP vs oracle, bit for bit."""
+    import os
+    import time
+
+    import fuzz_cases as F
+
+    seed = int(os.environ.get("NFA_FUZZ_SEED", time.time_ns() % (1 << 31)))
+    budget = float(os.environ.get("NFA_FUZZ_SECONDS", 18.0))
+    g = np.random.default_rng(seed)
+    bad, total, cases = [], 0, 0
+    t0 = time.time()
+    while time.time() - t0 < budget and not bad:
+        which = cases % 4
+        if which == 0:
+            b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000)), "NFA_SPLIT_P", F.SPLIT_P_FORMS)
+        elif which == 1:
+            b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 5, 64, 700, 4096)), "NFA_SEGMENTS", F.SEGMENT_FORMS)
+        elif which == 2:
+            b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_SEGMENTS", F.SEGMENT_FORMS)
+        else:
+            b, k = F.check_api(F.api_case(g, ray_counts=(3, 100, 2000)))
+        bad += b
+        total += k
+        cases += 1
+    assert not bad, f"seed {seed} (NFA_FUZZ_SEED={seed} replays), case {cases - 1}: " + "; ".join(bad[:3])
+    assert cases >= 4 and total > 0, (cases, total)
+    print(f"fuzz seed {seed}: {cases} scenes, {total} oracle samples, 0 mismatches")

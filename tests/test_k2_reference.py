@@ -167,3 +167,84 @@ def test_hip_sampling_reproduces_reference_k2(name, k2):
     # midpoints of the fixture = (t_start + t_end) * 0.5 with the same rounding (grid.cu:252)
     mids = ((te + ts) * np.float32(0.5)).astype(np.float32)
     assert K.sha(mids) == str(k2[f"{name}/sha/sm_vals"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rays lying IN a bounding plane of a level: only defined under the GPU's float -> int conversion rule (saturating, NaN -> 0).
+# tests/golden/k2_inplane.npz comes from the reference's grid.cu built with that rule (oracle/ref_shim `gpu` build:
+# prelude.h re-routes the sources' `int(float)` casts; the x86-rule builds read outside the grid on these rays and crash).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def k2_inplane():
+    return dict(np.load(os.path.join(GOLD, "k2_inplane.npz")))
+
+
+@pytest.mark.parametrize("name", K.GPU_RULE)
+def test_oracle_reproduces_reference_inplane(name, k2_inplane):
+    import oracle
+
+    c = _inputs(name, k2_inplane)
+    with np.errstate(all="ignore"):
+        slab = (c["aabbs"].reshape(1, -1, 2, 3) - c["rays_o"][:, None, None, :]) * (np.float32(1) / c["rays_d"])[:, None, None, :]
+    assert np.isnan(slab).any(axis=(1, 2, 3)).mean() > 0.9          # the case is what it claims to be
+    iv, sm, term = oracle.traverse_grids(c["rays_o"], c["rays_d"], c["binaries"], c["aabbs"], **c["extra"], **c["kw"])
+    assert K.check_against_fixture(name, K.pack_outputs(iv, sm, term, None), k2_inplane) > 100000
+    rep = json.load(open(os.path.join(GOLD, "k2_inplane.json")))
+    assert rep[name]["fixture_build"] == "gpu" and rep[name]["rays_differing_oracle_vs_gpu_rule"] == 0
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/nerfacc") and os.path.isdir(os.path.join(ROOT, "oracle", "_ref"))
+                         and any(f.startswith("nerfacc_ref_gpu") for f in os.listdir(os.path.join(ROOT, "oracle", "_ref")))),
+                    reason="oracle/_ref (host build of the reference) only exists in the build container")
+@pytest.mark.parametrize("name", K.GPU_RULE)
+def test_reference_gpu_rule_build_reproduces_inplane_fixture(name, k2_inplane):
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    try:
+        ref = importlib.import_module("nerfacc_ref_gpu")
+    finally:
+        sys.path.pop(0)
+    c = _inputs(name, k2_inplane)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    o, d = tt(c["rays_o"]), tt(c["rays_d"])
+    R = o.shape[0]
+    tmin, tmax, hits = ref.ray_aabb_intersect(o, d, tt(c["aabbs"]), -float("inf"), float("inf"), float("inf"))
+    ts, ti = torch.sort(torch.cat([tmin, tmax], -1), -1)            # grid.py:156-162
+    iv, sm, term = ref.traverse_grids(o, d, torch.ones(R, dtype=torch.bool), tt(c["binaries"]), tt(c["aabbs"]), ts, ti, hits,
+                                      torch.zeros(R), torch.full((R,), float("inf")), c["kw"]["step_size"], 0.0, True, True, True, -1, False)
+    m = lambda s, keys: {k: getattr(s, k).numpy() for k in keys}
+    out = K.pack_outputs(m(iv, ("vals", "ray_indices", "is_left", "is_right", "chunk_starts", "chunk_cnts")),
+                         m(sm, ("vals", "ray_indices", "is_valid", "chunk_starts", "chunk_cnts")), term.numpy(), None)
+    K.check_against_fixture(name, out, k2_inplane)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", K.GPU_RULE)
+def test_hip_reproduces_reference_inplane(name, k2_inplane):
+    """both routes: the reference-API call (general fill kernel) and OccGridEstimator.sampling (segment count pass + emit)"""
+    import torch
+
+    from gpu_utils import n, t
+    from nerfacc_amd import OccGridEstimator
+    from nerfacc_amd.grid import traverse_grids
+
+    c = _inputs(name, k2_inplane)
+    iv, sm, term = traverse_grids(t(c["rays_o"]), t(c["rays_d"]), t(c["binaries"]), t(c["aabbs"]), **c["kw"])
+    torch.cuda.synchronize()
+    as_map = lambda s, flags: dict(vals=n(s.vals), ray_indices=n(s.ray_indices), chunk_starts=n(s.packed_info[:, 0]),
+                                   chunk_cnts=n(s.packed_info[:, 1]), **{f: n(getattr(s, f)) for f in flags})
+    K.check_against_fixture(name, K.pack_outputs(as_map(iv, ("is_left", "is_right")), as_map(sm, ("is_valid",)), n(term), None), k2_inplane)
+    est = OccGridEstimator(roi_aabb=c["aabbs"][0].tolist(), resolution=list(c["binaries"].shape[1:]), levels=c["binaries"].shape[0]).to("cuda:0")
+    est.binaries = t(c["binaries"])
+    for seg in ("1", "0"):
+        os.environ["NFA_SEGMENTS"] = seg
+        try:
+            ri, ts, te = est.sampling(t(c["rays_o"]), t(c["rays_d"]), near_plane=0.0, far_plane=float("inf"),
+                                      render_step_size=c["kw"]["step_size"])
+        finally:
+            os.environ.pop("NFA_SEGMENTS", None)
+        ri, ts, te = n(ri), n(ts), n(te)
+        assert K.sha(ri.astype(np.int64)) == str(k2_inplane[f"{name}/sha/sm_ray_indices"])
+        assert np.array_equal(np.bincount(ri, minlength=c["rays_o"].shape[0]), k2_inplane[f"{name}/cnts/sm_chunk_cnts"])
+        assert K.sha(((te + ts) * np.float32(0.5)).astype(np.float32)) == str(k2_inplane[f"{name}/sha/sm_vals"])
