@@ -1523,6 +1523,11 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
         int64_t K = K_lo, K_prev = K_lo;
         int j = 0;
         auto resolve = [&](float bound, bool oj) {
+            // A voxel exit BEFORE the segment's start (a ray lying in a bounding plane of a level: its slab test returns an
+            // infinite exit, the level's segment outlasts the box, and the next segment's first voxel lies behind the ray) has
+            // no position relative to this segment's start; where the chain stands then depends on the segments before it.
+            // Such rays take the serial walk (tests/golden/k2_inplane.npz pins them).
+            stuck_any = stuck_any || bound < seg_lo;
             T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
             stuck_any = stuck_any || stuck;
             K += k_tmp;

@@ -84,11 +84,11 @@ def _degenerate(rng, R, res):
     return o, d, aabbs, rng.random((2, res, res, res)) < 0.35
 
 
-def _in_plane(rng, R, res):
+def _in_plane(rng, R, res, levels=2):
     """rays lying IN a bounding plane of a level (origin on the plane, zero direction component along its axis): the slab
     test forms 0 * inf = NaN and setup_traversal converts inf / NaN to int (utils_grid.cuh:72-82).  Only meaningful with the
     GPU's conversion rule: the fixture for this case comes from the `gpu` build of oracle/ref_shim (prelude.h, REF_GPU_F2I)."""
-    aabbs = _levels([-1, -1, -1, 1, 1, 1], 2)
+    aabbs = _levels([-1, -1, -1, 1, 1, 1], levels)
     o = (rng.random((R, 3)) * 3.0 - 1.5).astype(np.float32)
     d = rng.standard_normal((R, 3)).astype(np.float32)
     k = np.arange(R)
@@ -102,7 +102,7 @@ def _in_plane(rng, R, res):
     d[two, ax2[two]] = 0.0
     neg0 = k % 7 == 0                      # -0.0 instead of +0.0: the sign of 1/d flips the infinities
     d[neg0, ax[neg0]] = -0.0
-    return o, _unit(d), aabbs, rng.random((2, res, res, res)) < 0.35
+    return o, _unit(d), aabbs, rng.random((levels, res, res, res)) < 0.35
 
 
 # name -> (builder, traverse kwargs).  builder(rng) -> rays_o, rays_d, aabbs, binaries, extra dict of per-ray arrays
@@ -169,6 +169,9 @@ def _case(name):
     elif name == "in_plane":
         o, d, aabbs, binaries = _in_plane(rng, 1536, 32)
         kw = dict(step_size=3e-3)
+    elif name in ("in_plane_one_level", "in_plane_four_levels"):
+        o, d, aabbs, binaries = _in_plane(rng, 1536, 32, levels=1 if name == "in_plane_one_level" else 4)
+        kw = dict(step_size=3e-3)
     else:
         raise KeyError(name)
     return dict(rays_o=o, rays_d=d, aabbs=aabbs, binaries=binaries, extra=extra, kw=kw)
@@ -178,7 +181,7 @@ def _case(name):
 GENERATED = ["m1_noise", "m1_sphere", "lego_4k", "lego_70k", "two_level_256", "cone_angle", "cone_angle_levels",
              "per_voxel", "steps_limit", "over_allocate", "near_far", "non_cubic", "degenerate", "levels4_inside"]
 ALL = ["ref_test_grid"] + GENERATED
-GPU_RULE = ["in_plane"]     # tests/golden/k2_inplane.npz: the reference built with the GPU's float -> int conversion rule
+GPU_RULE = ["in_plane", "in_plane_one_level", "in_plane_four_levels"]     # tests/golden/k2_inplane.npz: the reference built with the GPU's float -> int conversion rule
 FULL_LIMIT = 30000      # cases with fewer samples keep every output array in the fixture; the others digests
 
 
