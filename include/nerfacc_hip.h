@@ -145,6 +145,11 @@ typedef struct nfa_traverse_args {
     const float *t_min, *t_max; /* [n_rays] */
     const float *jitter;        /* [n_rays] uniform [0,1) numbers of the caller's generator */
     float jitter_scale;
+    /* bytes of the workspace handed to nfa_traverse_count / _offsets / _fill / _emit_speculative with these args.  0 (or
+     * anything below nfa_traverse_workspace_bytes_for(args)) = the caller sized it with nfa_traverse_workspace_bytes(n_rays):
+     * count passes that need the larger workspace (cone_angle != 0: one lane per level segment + a serial chain over
+     * per-voxel records) are then not selected. */
+    int64_t workspace_bytes;
 } nfa_traverse_args;
 
 /* pass 1 (grid.cu:413), one kernel: per-ray counts into iv_cnts / sm_cnts, terminate_planes when
@@ -152,6 +157,10 @@ typedef struct nfa_traverse_args {
  * length) in `workspace` — the records let pass 2 emit samples without touching the grid again.
  * workspace: nfa_traverse_workspace_bytes(n_rays) bytes of device scratch. */
 int64_t nfa_traverse_workspace_bytes(int64_t n_rays);
+/* the workspace these args can make use of (>= nfa_traverse_workspace_bytes(args->n_rays)); pass the size actually
+ * allocated in args->workspace_bytes.  Reads n_rays, n_grids, res, step_size, cone_angle, traverse_steps_limit and which of
+ * rays_mask / t_sorted are given. */
+int64_t nfa_traverse_workspace_bytes_for(const nfa_traverse_args *args);
 int nfa_traverse_count(const nfa_traverse_args *args, void *workspace, void *stream);
 /* pass 1b (the cumsum of data_spec.hpp:90), one kernel: iv_starts / sm_starts = exclusive sums of
  * the counts, totals = {n_edges, n_samples, rays whose runs did not fit (re-traversed by pass 2), 0}.

@@ -1666,6 +1666,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     NFA_PHASE_END();
 }
 
+#include "cone_walk.hpp"
+
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
 // prefix, `total` gets the block total (all threads).
 __device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t *lds /* [kWavesPerBlock] */, int64_t &total) {
@@ -1998,6 +2000,26 @@ inline int64_t ws_totals_offset(int64_t n_rays) {
     const int64_t R = n_rays > 0 ? n_rays : 1;
     return ws_block_sums_bytes(R) + (int64_t)run_capacity(R) * R * 8 + ceil_div(2 * R, 16) * 16;
 }
+// cone_angle != 0 (cone_walk.hpp): [ ... totals ][ voxel records: count workgroups * (rx + ry + rz) * kBlock u32 ], 256-byte aligned
+inline int64_t ws_voxels_offset(int64_t n_rays) { return (ws_totals_offset(n_rays) + 4 * (int64_t)sizeof(int64_t) + 255) & ~255ll; }
+inline int cone_lanes_for_levels(int n_grids) { return n_grids == 1 ? 1 : (2 * n_grids - 1 <= 8 ? 8 : 16); }
+inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
+    const int P = cone_lanes_for_levels(a->n_grids);
+    return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / P) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 8 /* VoxelStore::kSlack */) * kBlock * 4;
+}
+// lanes per ray of the cone count pass, 0 = the general lane-per-ray kernel.  Needs the larger workspace
+// (nfa_traverse_workspace_bytes_for) announced through args.workspace_bytes.
+static int cone_lanes_per_ray(const nfa_traverse_args *a) {
+    if (!(a->step_size > 0.0f) || a->cone_angle == 0.0f) return 0;
+    if (a->t_sorted || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
+    int64_t max_rays = 32768;       // beyond, a lane per ray fills the chip (and the voxel planes grow with the ray count)
+    if (const char *e = getenv("NFA_CONE_MAX_RAYS")) max_rays = atoll(e);
+    if (const char *e = getenv("NFA_CONE")) { if (atoi(e) == 0) return 0; }
+    if (a->n_rays > max_rays) return 0;
+    if (a->workspace_bytes < ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a)) return 0;
+    return cone_lanes_for_levels(a->n_grids);
+}
+
 RunStore make_runs(void *workspace, int64_t n_rays) {
     RunStore rs;
     uint8_t *p = (uint8_t *)workspace + ws_block_sums_bytes(n_rays);
@@ -2105,6 +2127,16 @@ NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     return ws_totals_offset(R) + 4 * (int64_t)sizeof(int64_t);
 }
 
+NFA_EXPORT int64_t nfa_traverse_workspace_bytes_for(const nfa_traverse_args *a) {
+    if (!a) return 0;
+    const int64_t base = nfa_traverse_workspace_bytes(a->n_rays);
+    if (a->n_rays <= 0 || a->n_grids < 1 || a->n_grids > NFA_MAX_GRID_LEVELS) return base;
+    nfa_traverse_args probe = *a;
+    probe.workspace_bytes = INT64_MAX;
+    if (!cone_lanes_per_ray(&probe)) return base;
+    return ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a);
+}
+
 // lanes per ray of the count pass for this call (1 = lane-per-ray kernels).  `sparse`: the full
 // occupancy image fits in LDS (few non-empty bricks: a blob-like grid, few occupied<->empty
 // boundaries per ray).
@@ -2157,6 +2189,18 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
     p.seg = 0;
+    if (const int pc = cone_lanes_per_ray(a)) {
+        p.P = pc;
+        p.seg = 2;                  // cone_walk.hpp
+        p.blk = kBlock;
+        p.xt = 0;
+        p.cap = 0;
+        p.lds = 0;
+        // the per-lane segment table (8 B per lane) sits behind the occupancy image; the image only when it leaves room for
+        // several workgroups per CU (the walk is bound by its instructions, not by where the brick words come from)
+        p.gv = make_view(a, kBlock * 8, &p.lds, 40 * 1024);
+        return p;
+    }
     if (const int ps = segment_lanes_per_ray(a)) {
         p.P = ps;
         p.seg = 1;
@@ -2212,6 +2256,24 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
     const SplitPlan plan = plan_split(a);
     const int P = plan.P;
+    if (plan.seg == 2) {
+        const int lds = plan.lds;
+        const GridView &gv = plan.gv;
+        const bool lds_occ = gv.lds_compact_cap > 0;
+        const unsigned nbs = (unsigned)ceil_div(a->n_rays, kBlock / P);
+        VoxelStore vs;
+        vs.rec = (uint32_t *)((uint8_t *)workspace + ws_voxels_offset(a->n_rays));
+        vs.cap = a->res[0] + a->res[1] + a->res[2];
+#define NFA_LAUNCH_CONE(LDSO, PP)                                                                                               \
+    do {                                                                                                                       \
+        if (int rc = allow_lds(traverse_count_cone_kernel<LDSO, PP>, lds)) return rc;                                           \
+        hipLaunchKernelGGL((traverse_count_cone_kernel<LDSO, PP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs, vs); \
+    } while (0)
+        if (lds_occ) { if (P == 1) NFA_LAUNCH_CONE(true, 1); else if (P == 8) NFA_LAUNCH_CONE(true, 8); else NFA_LAUNCH_CONE(true, 16); }
+        else { if (P == 1) NFA_LAUNCH_CONE(false, 1); else if (P == 8) NFA_LAUNCH_CONE(false, 8); else NFA_LAUNCH_CONE(false, 16); }
+#undef NFA_LAUNCH_CONE
+        return check_launch("traverse_count_cone_kernel");
+    }
     if (P > 1) {
         const int lds = plan.lds;
         const GridView &gv = plan.gv;

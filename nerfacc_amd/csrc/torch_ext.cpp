@@ -435,7 +435,8 @@ std::tuple<RaySegmentsSpec, RaySegmentsSpec, OptTensor> traverse_grids(
         if (compute_intervals) { iv_cnts = at::empty({R}, i64); iv_starts = at::empty({R}, i64); }
         sm_cnts = at::empty({R}, i64);
         sm_starts = at::empty({R}, i64);
-        ws = at::empty({std::max<int64_t>(nfa_traverse_workspace_bytes(R), 16)}, opts(rays_o, at::kByte));
+        a.workspace_bytes = nfa_traverse_workspace_bytes_for(&a);
+        ws = at::empty({std::max<int64_t>(a.workspace_bytes, 16)}, opts(rays_o, at::kByte));
         int64_t *h = host_ints(rays_o.device().index(), s);
         a.iv_cnts = ptr<int64_t>(iv_cnts); a.iv_starts = ptr<int64_t>(iv_starts);
         a.sm_cnts = ptr<int64_t>(sm_cnts); a.sm_starts = ptr<int64_t>(sm_starts);
@@ -504,7 +505,8 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
                                         near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep, near_plane, far_plane,
                                         t_min, t_max, jitter, jitter_scale);
     Tensor packed = at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
-    Tensor ws = at::empty({std::max<int64_t>(nfa_traverse_workspace_bytes(R), 16)}, opts(rays_o, at::kByte));
+    a.workspace_bytes = nfa_traverse_workspace_bytes_for(&a);
+    Tensor ws = at::empty({std::max<int64_t>(a.workspace_bytes, 16)}, opts(rays_o, at::kByte));
     int64_t *h = host_ints(rays_o.device().index(), s);
     a.sm_starts = ptr<int64_t>(packed);
     a.sm_cnts = ptr<int64_t>(packed) + R;

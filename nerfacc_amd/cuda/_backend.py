@@ -45,7 +45,7 @@ class _TraverseArgs(ctypes.Structure):
         ("sm_vals", c_void_p), ("sm_ray_indices", c_void_p), ("sm_is_valid", c_void_p),
         ("t_starts", c_void_p), ("t_ends", c_void_p), ("terminate_planes", c_void_p),
         ("near_plane", c_float), ("far_plane", c_float), ("t_min", c_void_p), ("t_max", c_void_p),
-        ("jitter", c_void_p), ("jitter_scale", c_float),
+        ("jitter", c_void_p), ("jitter_scale", c_float), ("workspace_bytes", c_int64),
     ]
 
 
@@ -74,6 +74,7 @@ _SIGNATURES = {
     "nfa_grid_threshold": (ctypes.c_int, [_P, c_int64, c_float, _P, _P, _P, _P]),
     "nfa_grid_threshold_packed": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P]),
     "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
+    "nfa_traverse_workspace_bytes_for": (c_int64, [_P]),
     "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
     "nfa_traverse_offsets_stamped": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, c_int64, _P]),    # (extension only)
@@ -495,7 +496,8 @@ class _CtypesC:
                 iv_starts = torch.empty(R, **i64) if compute_intervals else None
                 sm_cnts, sm_starts = torch.empty(R, **i64), torch.empty(R, **i64)
                 totals = _host_ints(dev)
-                ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
+                a.workspace_bytes = L.nfa_traverse_workspace_bytes_for(ctypes.byref(a))
+                ws = torch.empty(max(a.workspace_bytes, 16), dtype=torch.uint8, device=dev)
                 a.iv_cnts, a.iv_starts = _ptr(iv_cnts), _ptr(iv_starts)
                 a.sm_cnts, a.sm_starts, a.totals = _ptr(sm_cnts), _ptr(sm_starts), _ptr(totals)
                 a.terminate_planes = _ptr(terminate)
@@ -710,7 +712,8 @@ class _CtypesC:
                                jitter_scale)
             packed = torch.empty((2, R), **i64)          # [starts; cnts], stacked to [R,2] below
             totals = _host_ints(dev)
-            ws = torch.empty(max(L.nfa_traverse_workspace_bytes(R), 16), dtype=torch.uint8, device=dev)
+            a.workspace_bytes = L.nfa_traverse_workspace_bytes_for(ctypes.byref(a))
+            ws = torch.empty(max(a.workspace_bytes, 16), dtype=torch.uint8, device=dev)
             a.sm_starts, a.sm_cnts, a.totals = packed[0].data_ptr(), packed[1].data_ptr(), _ptr(totals)
             term = None
             if with_terminate_planes:

@@ -34,7 +34,7 @@ def _unit(d):
 
 
 # ------------------------------------------------------------------------------------------ fused, one level
-def fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000, 20000, 40000)):
+def fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000, 20000, 40000), cones=(0.0,)):
     res = [int(g.choice([16, 24, 32, 48, 64, 96, 128])) for _ in range(3)]
     if g.random() < 0.5:
         res = [res[0]] * 3
@@ -77,8 +77,9 @@ def fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000, 20000, 40000)):
     step = float(np.float32(ext.max() / g.choice([40, 150, 600, 2000])))
     near = (g.random(R) * step * g.choice([0.0, 1.0, 50.0])).astype(np.float32)
     far = np.full(R, 1e10, np.float32) if g.random() < 0.7 else (near + g.random(R).astype(np.float32) * 3).astype(np.float32)
-    return dict(o=o.astype(np.float32), d=_unit(d), occ=occ[None], aabbs=aabb, near=near, far=far, step=step, cone=0.0,
-                desc=f"fused_single res={res} kind={kind} mode={mode} R={R} step={step}")
+    cone = float(g.choice(cones))
+    return dict(o=o.astype(np.float32), d=_unit(d), occ=occ[None], aabbs=aabb, near=near, far=far, step=step, cone=cone,
+                desc=f"fused_single res={res} kind={kind} mode={mode} R={R} step={step} cone={cone}")
 
 
 # ------------------------------------------------------------------------------------------ fused, several levels
@@ -208,3 +209,4 @@ def check_api(case):
 
 SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 SEGMENT_FORMS = ("1", "0")
+CONE_FORMS = ("1", "0")          # NFA_CONE: lane-per-segment walk + serial chain (cone_walk.hpp) / the general lane-per-ray kernel

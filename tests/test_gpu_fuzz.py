@@ -146,8 +146,12 @@ def test_randomised_fuzz_time_boxed():
     bad, total, cases = [], 0, 0
     t0 = time.time()
     while time.time() - t0 < budget and not bad:
-        which = cases % 4
-        if which == 0:
+        which = cases % 6
+        if which == 4:      # cone angles: one level (a lane per ray walks, then chains) ...
+            b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 64, 500, 3000), cones=(0.004, 0.05)), "NFA_CONE", F.CONE_FORMS)
+        elif which == 5:    # ... and several (a lane per level segment walks, the ray's first lane chains)
+            b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_CONE", F.CONE_FORMS)
+        elif which == 0:
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000)), "NFA_SPLIT_P", F.SPLIT_P_FORMS)
         elif which == 1:
             b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 5, 64, 700, 4096)), "NFA_SEGMENTS", F.SEGMENT_FORMS)

@@ -18,7 +18,8 @@ seed0 = int(argv[1]) if len(argv) > 1 else 0
 bad = total = 0
 t_begin = time.time()
 for case in range(n_cases):
-    b, n = F.check_fused(F.fused_levels_case(np.random.default_rng(seed0 * 1000003 + case), cones=cones), "NFA_SEGMENTS", F.SEGMENT_FORMS)
+    c = F.fused_levels_case(np.random.default_rng(seed0 * 1000003 + case), cones=cones)
+    b, n = F.check_fused(c, "NFA_SEGMENTS", F.SEGMENT_FORMS) if c["cone"] == 0.0 else F.check_fused(c, "NFA_CONE", F.CONE_FORMS)
     bad += len(b); total += n
     for line in b:
         print("MISMATCH", f"case {case}", line, flush=True)

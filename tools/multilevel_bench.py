@@ -40,11 +40,16 @@ def gpu_ms(fn, reps=10):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ms.append(e0.elapsed_time(e1))
     return sorted(ms)[len(ms) // 2]
 
-for step, cone in (((1e-3, 0.0),) if os.environ.get("ML_ONLY_LATTICE") else ((1e-3, 0.004), (1e-3, 0.0), (4e-3, 0.0))):
+cases = ((1e-3, 0.004), (1e-3, 0.0), (4e-3, 0.0))
+if os.environ.get("ML_ONLY_LATTICE"):
+    cases = ((1e-3, 0.0),)
+if os.environ.get("ML_ONLY_CONE"):
+    cases = ((1e-3, 0.004),)
+for step, cone in cases:
     ri, ts, te, pk = C.sample_occgrid(O, D, OCC, AABB, NEAR, FAR, step, cone)
     t0 = time.perf_counter()
     iv, sm, _ = oracle.traverse_grids(o, d, occ, aabbs, near, far, step, cone)
     cpu = (time.perf_counter() - t0) * 1e3
-    assert np.array_equal(ri.cpu().numpy(), sm["ray_indices"]) and np.array_equal(ts.cpu().numpy(), iv["vals"][iv["is_left"]])
+    assert os.environ.get("ML_NO_CHECK") or np.array_equal(ri.cpu().numpy(), sm["ray_indices"]) and np.array_equal(ts.cpu().numpy(), iv["vals"][iv["is_left"]])
     ms = gpu_ms(lambda: C.sample_occgrid(O, D, OCC, AABB, NEAR, FAR, step, cone))
     print(f"{levels} levels {res}^3, {R} rays, step {step:g}, cone {cone:g}: {ri.shape[0]} samples  GPU {ms*1e3:9.1f} us   CPU oracle {cpu:8.2f} ms   x{cpu/ms:6.0f}")
