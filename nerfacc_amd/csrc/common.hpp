@@ -91,6 +91,22 @@ __device__ __forceinline__ void st_stream(T *p, T v) {
 #endif
 }
 
+// load of a per-sample input that this kernel reads exactly once
+// NT: non-temporal.  On MI355X a read-only 16-byte-lane stream reaches 7.0 TB/s with non-temporal loads against 6.2-6.3 with
+// plain ones (tools/ubench/ceiling.py), and weight_fwd / rendering_fwd gain 10 % at N = 2^24 (4.43 -> 4.89, 4.16 -> 4.59 TB/s);
+// the kernels that move few bytes per sample (scans 16 B, accumulate 12-24 B) LOSE 12-20 % with them at that size — their
+// inputs are served by the 256 MB Infinity Cache when a benchmark repeats a call, which a non-temporal load forgoes.  So the
+// choice is per kernel (profiles/r03_streaming.md); -DNFA_NT_LOADS forces them everywhere.
+template <bool NT = false, class V>
+__device__ __forceinline__ V ld_stream(const V *p) {
+#ifdef NFA_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+#endif
+}
+
 // --- cross-lane moves on the DPP path ----------------------------------------------------
 // ds_bpermute shuffles go through the LDS crossbar (~100+ cycles each, and a scan is a chain of
 // dependent ones); DPP operand modifiers move data inside the VALU in a few cycles.  gfx950
@@ -231,11 +247,11 @@ struct RayChunk {
 };
 
 // aligned E-wide loads / stores (i0 is a multiple of E by construction; elements at or beyond n are filled / skipped)
-template <int E, class T>
+template <int E, class T, bool NT = false>
 __device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int64_t n, T fill, T (&out)[E]) {
     typedef T vec_t __attribute__((ext_vector_type(E)));
     if (i0 + E <= n) {
-        const vec_t v = *reinterpret_cast<const vec_t *>(p + i0);
+        const vec_t v = ld_stream<NT>(reinterpret_cast<const vec_t *>(p + i0));
 #pragma unroll
         for (int e = 0; e < E; ++e) out[e] = v[e];
     } else {
@@ -244,14 +260,14 @@ __device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int6
     }
 }
 // S interleaved channels per element (rgb: S = 3): out[e][c]
-template <int E, int S>
+template <int E, int S, bool NT = false>
 __device__ __forceinline__ void ld_vec_strided(const float *__restrict__ p, int64_t i0, int64_t n, float fill, float (&out)[E][S]) {
     if (E > 1 && i0 + E <= n) {
         typedef float vec_t __attribute__((ext_vector_type(E)));
         float flat[E * S];
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            const vec_t v = *reinterpret_cast<const vec_t *>(p + i0 * S + j * E);
+            const vec_t v = ld_stream<NT>(reinterpret_cast<const vec_t *>(p + i0 * S + j * E));
 #pragma unroll
             for (int e = 0; e < E; ++e) flat[j * E + e] = v[e];
         }
@@ -340,11 +356,17 @@ __device__ __forceinline__ void seg_scan_bwd(const float (&v)[E], const SegBwd<E
     }
 }
 
+// payload types whose kernels stream their keys with non-temporal loads too (see ld_stream) say `static constexpr bool kStreamKeys = true;`
+template <class P, class = void>
+struct StreamKeys { static constexpr bool value = false; };
+template <class P>
+struct StreamKeys<P, decltype((void)P::kStreamKeys)> { static constexpr bool value = P::kStreamKeys; };
+
 template <int E, class P, class Load>
 __device__ __forceinline__ RayChunk<E, P> fetch_chunk(const int64_t *__restrict__ keys, int64_t n, int64_t base, int lane, Load &load) {
     RayChunk<E, P> c;
     const int64_t i0 = base + (int64_t)lane * E;
-    ld_vec<E, int64_t>(keys, i0, n, (int64_t)0, c.key);
+    ld_vec<E, int64_t, StreamKeys<P>::value>(keys, i0, n, (int64_t)0, c.key);
     c.p = load(i0);
     return c;
 }

@@ -26,7 +26,7 @@ __device__ __forceinline__ int64_t wave_index() { return (int64_t)blockIdx.x * k
 // weights / transmittance / alpha from density
 // ----------------------------------------------------------------------------------------
 template <int E>
-struct WeightFwdIn { float t0[E], t1[E], sg[E], pf[E]; };
+struct WeightFwdIn { float t0[E], t1[E], sg[E], pf[E]; static constexpr bool kStreamKeys = true; };
 template <int E>
 __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
@@ -37,10 +37,10 @@ __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
     walk_rays_fwd<E, NFA_PF, WeightFwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             WeightFwdIn<E> p;
-            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
-            ld_vec<E>(te, i0, n, 0.0f, p.t1);
-            ld_vec<E>(sigmas, i0, n, 0.0f, p.sg);
-            if (prefix) ld_vec<E>(prefix, i0, n, 1.0f, p.pf);
+            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0);          // non-temporal: common.hpp, ld_stream
+            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1);
+            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg);
+            if (prefix) ld_vec<E, float, true>(prefix, i0, n, 1.0f, p.pf);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const WeightFwdIn<E> &p) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void fill_rays_kernel(int64_t n_rays, const
 }
 
 template <int E>
-struct RenderFwdIn { float t0[E], t1[E], sg[E], rgb[E][3]; };
+struct RenderFwdIn { float t0[E], t1[E], sg[E], rgb[E][3]; static constexpr bool kStreamKeys = true; };
 template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     walk_rays_fwd<E, NFA_PF, RenderFwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             RenderFwdIn<E> p;
-            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
-            ld_vec<E>(te, i0, n, 0.0f, p.t1);
-            ld_vec<E>(sigmas, i0, n, 0.0f, p.sg);
-            ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb);
+            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0);          // non-temporal: common.hpp, ld_stream
+            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1);
+            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg);
+            ld_vec_strided<E, 3, true>(rgbs, i0, n, 0.0f, p.rgb);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&tail)[E], const RenderFwdIn<E> &p) {

@@ -63,6 +63,16 @@ x = torch.rand(N, device=dev, generator=g)
 buf = torch.empty(N * 8, device=dev)
 src = torch.rand(N * 8, device=dev)
 bench("torch copy (read+write, reference point)", 2 * 4 * N * 8, lambda: buf.copy_(src))
+# this box's own ceilings: tuned 16-byte-lane copy / read-only / write-only kernels, best of a sweep (tools/ubench/ceiling.py)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench"))
+try:
+    import ceiling
+    for kind, (gbs, cfg) in ceiling.ceilings(4 * N * 8).items():
+        rows.append((f"tuned {kind} kernel of this box ({cfg})", 0.0, 0.0, gbs, gbs / PEAK))
+        print(f"{'tuned ' + kind + ' (' + cfg + ')':100s} {gbs:8.1f} GB/s {100*gbs/PEAK:5.1f} % of 8 TB/s", flush=True)
+    rows.append(("guide's float4 copy (MI355X_MICROARCH.md:35)", 0.0, 0.0, 6290.0, 6290.0 / PEAK))
+except Exception as e:      # noqa: BLE001
+    print("ceiling ubench unavailable:", e)
 bench("weight_fwd_kernel (ray_indices)", 32 * N, lambda: C.render_weight_from_density_fwd(ri, ts, te, sig, None))
 bench("weight_bwd_kernel", 36 * N, lambda: C.render_weight_from_density_bwd(ri, ts, te, sig, T, a, gw, None, None))
 bench("rendering_fwd_kernel (+fill_rays)", 44 * N + 20 * R, lambda: C.rendering_fwd(ri, ts, te, sig, rgb, R, bk, True))
