@@ -78,20 +78,12 @@ struct OpProd {
     static __device__ __forceinline__ float apply(float a, float b) { return a * b; }
 };
 
-// store of a per-sample output that a LATER kernel reads.  Non-temporal stores (-DNFA_NT_STORES) were measured and
-// are NOT the default: at N = 2^24 weight_fwd drops from 3.93 to 3.35 TB/s and rendering_fwd from 3.53 to 3.40 with
-// them (profiles/r02_streaming.md) — the 1.15-1.22x write traffic of these kernels is not a write-allocate effect
-// that bypassing the cache removes.
+// store of a per-sample output that a LATER kernel reads: a plain store.  (Non-temporal stores were measured in rounds 1 and 2:
+// weight_fwd 3.93 -> 3.35 TB/s, rendering_fwd 3.53 -> 3.40 at N = 2^24, profiles/r02_streaming.md; a pure fill does not care,
+// tools/ubench/ceiling.py.)
 template <class T>
-__device__ __forceinline__ void st_stream(T *p, T v) {
-#ifdef NFA_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void st_stream(T *p, T v) { *p = v; }
 
-// load of a per-sample input that this kernel reads exactly once
 // NT: non-temporal.  On MI355X a read-only 16-byte-lane stream reaches 7.0 TB/s with non-temporal loads against 6.2-6.3 with
 // plain ones (tools/ubench/ceiling.py), and weight_fwd / rendering_fwd gain 10 % at N = 2^24 (4.43 -> 4.89, 4.16 -> 4.59 TB/s);
 // the kernels that move few bytes per sample (scans 16 B, accumulate 12-24 B) LOSE 12-20 % with them at that size — their

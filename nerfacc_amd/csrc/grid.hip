@@ -1434,11 +1434,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     }
 
     NFA_PHASE_MARK(2);
-#ifndef NFA_SEG_BATCH
-#define NFA_SEG_BATCH 4
-#endif
+    constexpr int kSegBatch = 4;
     // the segment's voxel walk: on_boundary(t_exit, run_was_occupied) for every occupied<->empty boundary and for the last run;
-    // returning false stops the walk.  NFA_SEG_BATCH voxels per trip: the DDA does not depend on the occupancy, so the steps of a
+    // returning false stops the walk.  kSegBatch voxels per trip: the DDA does not depend on the occupancy, so the steps of a
     // batch run first, their brick words are requested together (one LDS / L2 latency per batch instead of one per voxel:
     // 126 k -> 93 k cycles per wave) and the boundaries are found afterwards, in order.
     auto walk = [&](auto &&on_boundary) {
@@ -1448,39 +1446,39 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
         float run_exit = 0.f;
         const uint32_t *lc = (const uint32_t *)occ.smem;
         for (bool more = true; more;) {
-            bool valid[NFA_SEG_BATCH];
-            float tc[NFA_SEG_BATCH];
-            int id[NFA_SEG_BATCH], bp[NFA_SEG_BATCH];
+            bool valid[kSegBatch];
+            float tc[kSegBatch];
+            int id[kSegBatch], bp[kSegBatch];
 #pragma unroll
-            for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+            for (int k = 0; k < kSegBatch; ++k) {
                 valid[k] = more;
                 tc[k] = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
                 id[k] = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + level * gv.bricks_per_grid;
                 bp[k] = ((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3);
                 if (more) more = dda_advance(s);
             }
-            uint64_t bits[NFA_SEG_BATCH];
+            uint64_t bits[kSegBatch];
             if (LDS_OCC) {
-                uint2 wr[NFA_SEG_BATCH];
+                uint2 wr[kSegBatch];
 #pragma unroll
-                for (int k = 0; k < NFA_SEG_BATCH; ++k) wr[k] = valid[k] ? ((const uint2 *)occ.smem)[id[k] >> 5] : make_uint2(0u, 0u);
+                for (int k = 0; k < kSegBatch; ++k) wr[k] = valid[k] ? ((const uint2 *)occ.smem)[id[k] >> 5] : make_uint2(0u, 0u);
 #pragma unroll
-                for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+                for (int k = 0; k < kSegBatch; ++k) {
                     const uint32_t bit = 1u << (id[k] & 31);
                     bits[k] = (wr[k].x & bit) ? ((const uint64_t *)(lc + 2 * occ.w4))[(int)wr[k].y + __popc(wr[k].x & (bit - 1u))] : 0ull;
                 }
             } else if (occ.bytes > 0) {
-                uint32_t w[NFA_SEG_BATCH];
+                uint32_t w[kSegBatch];
 #pragma unroll
-                for (int k = 0; k < NFA_SEG_BATCH; ++k) w[k] = valid[k] ? lc[id[k] >> 5] : 0u;
+                for (int k = 0; k < kSegBatch; ++k) w[k] = valid[k] ? lc[id[k] >> 5] : 0u;
 #pragma unroll
-                for (int k = 0; k < NFA_SEG_BATCH; ++k) bits[k] = (w[k] & (1u << (id[k] & 31))) ? gv.bricks[id[k]] : 0ull;
+                for (int k = 0; k < kSegBatch; ++k) bits[k] = (w[k] & (1u << (id[k] & 31))) ? gv.bricks[id[k]] : 0ull;
             } else {
 #pragma unroll
-                for (int k = 0; k < NFA_SEG_BATCH; ++k) bits[k] = valid[k] ? gv.bricks[id[k]] : 0ull;
+                for (int k = 0; k < kSegBatch; ++k) bits[k] = valid[k] ? gv.bricks[id[k]] : 0ull;
             }
 #pragma unroll
-            for (int k = 0; k < NFA_SEG_BATCH; ++k) {
+            for (int k = 0; k < kSegBatch; ++k) {
                 if (valid[k] && !stop) {
                     const bool oc = (bits[k] >> bp[k]) & 1ull;
                     if (have_run && oc != run_occ) stop = !on_boundary(run_exit, run_occ);
@@ -2086,6 +2084,7 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
                                  uint64_t *bricks, void *stream)
 {
     NFA_REQUIRE(n_grids > 0 && rx > 0 && ry > 0 && rz > 0, "pack_binaries: empty grid");
+    NFA_REQUIRE(n_grids <= NFA_MAX_GRID_LEVELS, "pack_binaries: n_grids=%d > %d (the header holds one count per level)", n_grids, NFA_MAX_GRID_LEVELS);
     NFA_REQUIRE(binaries && bricks, "pack_binaries: NULL pointer");
     const PackedLayout L = packed_layout(n_grids, rx, ry, rz);
     NFA_REQUIRE(L.n_bricks < (1ll << 24), "pack_binaries: grid too large (more than 2^24 bricks)");
@@ -2106,6 +2105,7 @@ NFA_EXPORT int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int
                                          void *workspace, uint8_t *binaries, float *threshold_out, uint64_t *bricks, void *stream)
 {
     NFA_REQUIRE(n_grids > 0 && rx > 0 && ry > 0 && rz > 0, "grid_threshold_packed: empty grid");
+    NFA_REQUIRE(n_grids <= NFA_MAX_GRID_LEVELS, "grid_threshold_packed: n_grids=%d > %d (the header holds one count per level)", n_grids, NFA_MAX_GRID_LEVELS);
     NFA_REQUIRE(occs && workspace && binaries && bricks, "grid_threshold_packed: NULL pointer");
     const PackedLayout L = packed_layout(n_grids, rx, ry, rz);
     NFA_REQUIRE(L.n_bricks < (1ll << 24), "grid_threshold_packed: grid too large (more than 2^24 bricks)");
@@ -2164,6 +2164,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
+            if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for LDS-resident grids: they never won)
         }
     }
     return P;
@@ -2218,7 +2219,6 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     }
     p.P = count_lanes_per_ray(a, true);
     p.cap = 16;      // (8-entry lists at P = 16 overflow into the streaming mode on a trained scene: 80 us instead of 44)
-    if (const char *e = getenv("NFA_SPLIT_CAP")) { const int v = atoi(e); if (v == 8 || v == 16) p.cap = v; }   // tuning knob
     p.lds = 0;
     p.blk = kBlock;
     p.xt = 0;
@@ -2302,9 +2302,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ) {
-            if (P == 2) NFA_LAUNCH_SPLIT(true, 2, 16); else if (P == 4) NFA_LAUNCH_SPLIT(true, 4, 16);
-            else if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16);
-            else if (plan.cap == 16) NFA_LAUNCH_SPLIT(true, 16, 16); else NFA_LAUNCH_SPLIT(true, 16, 8);
+            if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16); else NFA_LAUNCH_SPLIT(true, 16, 16);
         } else {
             if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 32); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 32);
             else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 32); else NFA_LAUNCH_SPLIT(false, 16, 32);

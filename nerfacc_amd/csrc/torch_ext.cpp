@@ -529,10 +529,12 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     // instead of idling through the host's wake-up, allocation and launch (16 us, tools/step_timeline.py), and the host —
     // released by the offsets kernel's stamp, not by the end of the emit pass — prepares the caller's next kernels while it
     // runs.  A guess that is too small costs nothing but the second launch the old order always needed.
-    thread_local std::map<int, int64_t> last_n;
-    const int dev = rays_o.device().index();
-    const bool speculate = R > 0 && last_n.count(dev) && last_n[dev] > 0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
-    int64_t cap = speculate ? last_n[dev] + last_n[dev] / 4 + 1024 : 0;
+    // The guess is SAMPLES PER RAY of the previous call of the same kind on this device (training batches, eval chunks and
+    // marcher rounds differ by orders of magnitude in size but much less in samples per ray), times this call's ray count.
+    thread_local std::map<int, double> last_spr;
+    const int dev = rays_o.device().index() * 4 + (rays_mask.has_value() ? 1 : 0) + (traverse_steps_limit > 0 ? 2 : 0);
+    const bool speculate = R > 0 && last_spr.count(dev) && last_spr[dev] > 0.0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
+    int64_t cap = speculate ? (int64_t)(1.25 * last_spr[dev] * (double)R) + 1024 : 0;
     Tensor ray_indices;
     Rows ts(2, cap, f32);
     a.terminate_planes = nullptr;                     // written by the count pass only
@@ -547,11 +549,20 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     if (R > 0) wait_stamp(h + 3, stamp, s);
     else wait_stream(s);
     const int64_t n = h[1], n_overflow = h[2];
-    last_n[dev] = n;
+    last_spr[dev] = R > 0 ? (double)n / (double)R : 0.0;
     if (speculate && n <= cap) {
         if (n_overflow > 0) check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), 0, n_overflow, s));     // the rays the count pass flagged
         ray_indices = ray_indices.narrow(0, 0, n);
         ts.n = n;
+        if (cap > (1 << 20) && n < cap / 4) {
+            // a guess far too large: the caller would keep the whole over-sized storage alive through these views
+            // (and torch.save would write it) — hand out right-sized copies instead
+            ray_indices = ray_indices.clone();
+            Rows exact(2, n, f32);
+            exact.row(0).copy_(ts.row(0));
+            exact.row(1).copy_(ts.row(1));
+            ts = exact;
+        }
     } else {
         ray_indices = at::empty({n}, i64);
         ts = Rows(2, n, f32);

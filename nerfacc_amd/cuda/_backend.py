@@ -986,18 +986,26 @@ def _select_backend():
     want = os.environ.get("NERFACC_AMD_BACKEND", "ext").lower()
     if want not in ("ext", "ctypes"):
         raise ImportError(f"NERFACC_AMD_BACKEND must be 'ext' or 'ctypes', got {want!r}")
+    if want == "ext" and os.environ.get("NERFACC_AMD_LIB"):
+        # an explicitly named library (instrumented / variant builds) is only honoured by the ctypes face: the extension
+        # links the in-tree library through its rpath
+        want = "ctypes"
     if want == "ext":
         import glob
         import importlib
+        import warnings
 
         if not glob.glob(os.path.join(_PKG, "_hip*.so")):
             _jit_build()
         if glob.glob(os.path.join(_PKG, "_hip*.so")):
-            return importlib.import_module("nerfacc_amd._hip"), "ext"
-        import warnings
-
-        warnings.warn("nerfacc_amd: the torch extension nerfacc_amd/_hip*.so is not built; using the ctypes backend "
-                      "(python -m nerfacc_amd.build builds both)")
+            try:
+                return importlib.import_module("nerfacc_amd._hip"), "ext"
+            except ImportError as e:           # a stale build (another torch / ABI): say so and use the other face
+                warnings.warn(f"nerfacc_amd: the torch extension nerfacc_amd/_hip*.so does not import ({e}); using the ctypes "
+                              "backend (python -m nerfacc_amd.build --force rebuilds it)")
+        else:
+            warnings.warn("nerfacc_amd: the torch extension nerfacc_amd/_hip*.so is not built; using the ctypes backend "
+                          "(python -m nerfacc_amd.build builds both)")
     load_library()
     return _CtypesC, "ctypes"
 

@@ -203,7 +203,7 @@ class OccGridEstimator(AbstractEstimator):
         for lvl in range(self.levels):
             uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
             uniform = uniform[self.occs[lvl * self.cells_per_lvl + uniform] >= 0.0]
-            if self.binaries.is_cuda and self.levels <= 8:
+            if self.binaries.is_cuda and self.levels <= 8 and hasattr(torch, "nonzero_static"):
                 # the number of occupied cells is in the header of the packed grid (read back once per grid state, together
                 # with what the traversal needs): `nonzero` can size its output without its own host sync
                 cnt = _C.grid_occupied_counts(self.binaries)[lvl]

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out_dir = os.path.join(ROOT, "tools", "_prof")
 os.makedirs(out_dir, exist_ok=True)
-extra = os.environ.get("NFA_PHASE_EXTRA", "").split()          # further -D flags (A/B builds), e.g. NFA_PHASE_EXTRA="-DNFA_SEG_BATCH=1"
+extra = os.environ.get("NFA_PHASE_EXTRA", "").split()          # further -D flags (A/B builds), e.g. NFA_PHASE_EXTRA="-DNFA_EVCAP=8"
 so = os.path.join(out_dir, "libnerfacc_hip_prof" + "".join(c if c.isalnum() else "_" for c in "".join(extra)) + ".so")
 srcs = sorted(glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hip")))
 hdrs = glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hpp")) + [os.path.join(ROOT, "include", "nerfacc_hip.h")]
