@@ -363,8 +363,10 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
         uint2 *lw = (uint2 *)smem;
         uint64_t *lb = (uint64_t *)(lc + 2 * l.w4);
         for (int i = threadIdx.x; i < g.lds_words; i += blockDim.x) lw[i] = make_uint2(g.coarse[i], g.prefix[i]);
-        int n_compact = (int)g.header[0];
-        if (n_compact > g.lds_compact_cap) n_compact = g.lds_compact_cap;
+        // make_view selects this variant only when the caller gave the number of non-empty bricks and sized the image for
+        // exactly that many (args.n_nonempty_bricks "MUST be that value"): no dependent load of the header word in front of
+        // the copy loop — one L2 round trip less at the start of every traversal workgroup
+        const int n_compact = g.lds_compact_cap;
         for (int i = threadIdx.x; i < n_compact; i += blockDim.x) lb[i] = g.compact[i];
         l.cap = n_compact;
         l.bytes = (2 * l.w4 * 4 + g.lds_compact_cap * 8 + 15) & ~15;
@@ -985,19 +987,19 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NFA_PHASE_BEGIN();
-    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
-    NFA_PHASE_MARK(0);
-    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][BLK] times, then [CAP][BLK] indices
     const int tid = threadIdx.x, part = tid % P;
     const int64_t R = a.n_rays;
     const int64_t r = (int64_t)blockIdx.x * (BLK / P) + tid / P;
     const bool ray_ok = r < R;
     const int64_t rr = ray_ok ? r : 0;
-
+    // the ray's loads are requested BEFORE the occupancy image is staged: their L2 round trip overlaps the image's
     const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
     const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
-    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     const float near = ray_near(a, rr), far = ray_far(a, rr);
+    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    NFA_PHASE_MARK(0);
+    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][BLK] times, then [CAP][BLK] indices
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     const float dt = march_dt(0.0f, 0.0f, a.step_size);
 
     // the single segment (grid.cu:129-150 with one level)
