@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
             int64_t n_sm = 0;
             int n_runs = 0;
             const bool store_runs = rs.t0 != nullptr;
+            const bool fast_chain = near >= 0.0f && cone >= 0.0f && step_size >= 1.0e-30f;     // t >= near; halves of dt are exact
             unsigned rem = live_parts;
 #if defined(NFA_CONE_DBG) && NFA_CONE_DBG == 1
             rem = 0u;
@@ -166,18 +167,23 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                     }
                     cont = oc ? (cont || go) : false;               // grid.cu:205, 256
                     if (go) {
-                        // The lattice can only get stuck (t + dt == t) when dt is at most half an ulp of t.  t stays below e in
-                        // this voxel and dt does not shrink (cone >= 0: dt = max(t * cone, step) grows with t), so if HALF of
-                        // dt moves e (dt >= ulp(e)), dt moves every t in [0, e]: the step loop then needs no stuck test — ten
-                        // instructions per step instead of twenty, and the steps are what this phase's time is made of.
-                        if (t >= 0.0f && cone >= 0.0f && e + h != e) {
+                        // The step loop, written for its dependent instruction count (the steps are what this phase's time
+                        // is made of).  (1) No stuck test: the lattice can only get stuck (t + dt == t) when dt is at most half
+                        // an ulp of t; t stays below e in this voxel and dt does not shrink (cone >= 0), so if HALF of dt moves
+                        // e (dt >= ulp(e)), dt moves every t in [0, e].  (2) No upper clamp: t < e, so t * cone <= e * cone
+                        // < 1e10 when checked once.  (3) No select between "dt re-evaluated" (occupied) and "dt as at the
+                        // voxel's entry" (empty): dt = max(t * cA, floor) with cA = cone / 0 and floor = step / dt.  (4) the
+                        // test t + dt/2 < e as ONE fma: dt * 0.5 is exact, so fma(dt, 0.5, t) rounds the same sum once.
+                        // add, mul, max, fma, compare: 8 instructions per step with the loop's own three (13 before, 20 with the
+                        // stuck test).
+                        if (fast_chain && e + h != e && e * cone < 1.0e10f) {
+                            const float cA = oc ? cone : 0.0f, fl = oc ? step_size : dt;
                             int k = 0;
                             do {
                                 t = t + dt;
-                                const float d2 = march_dt(t, cone, step_size);
-                                dt = oc ? d2 : dt;
+                                dt = fmaxf(t * cA, fl);
                                 ++k;
-                            } while (t + dt * 0.5f < e);
+                            } while (fmaf(dt, 0.5f, t) < e);
                             n_sm += oc ? k : 0;
                         } else {
                             while (go) {

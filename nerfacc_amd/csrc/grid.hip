@@ -2002,9 +2002,18 @@ inline int64_t ws_totals_offset(int64_t n_rays) {
 }
 // cone_angle != 0 (cone_walk.hpp): [ ... totals ][ voxel records: count workgroups * (rx + ry + rz) * kBlock u32 ], 256-byte aligned
 inline int64_t ws_voxels_offset(int64_t n_rays) { return (ws_totals_offset(n_rays) + 4 * (int64_t)sizeof(int64_t) + 255) & ~255ll; }
-inline int cone_lanes_for_levels(int n_grids) { return n_grids == 1 ? 1 : (2 * n_grids - 1 <= 8 ? 8 : 16); }
+// lanes per ray: one per level segment (2 G - 1 of them); 16 although 8 would do up to 8192 rays (two waves per SIMD): the chain
+// phase then has 4 rays per wave instead of 8, and a wave pays the longest of its rays at every voxel (measured, 4 x 128^3:
+// 2 k rays 341 -> 309 us, 4 k 344 -> 325, 8 k 373 -> 307; 16 k 346 -> 399 and 32 k 509 -> 702 the other way)
+inline int cone_lanes_for_levels(int n_grids, int64_t n_rays) {
+    if (n_grids == 1) return 1;
+    int P = 2 * n_grids - 1 <= 8 ? 8 : 16;
+    if (P == 8 && n_rays <= 8192) P = 16;
+    if (const char *e = getenv("NFA_CONE_P")) { const int v = atoi(e); if ((v == 8 && 2 * n_grids - 1 <= 8) || v == 16) P = v; }
+    return P;
+}
 inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
-    const int P = cone_lanes_for_levels(a->n_grids);
+    const int P = cone_lanes_for_levels(a->n_grids, a->n_rays);
     return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / P) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 8 /* VoxelStore::kSlack */) * kBlock * 4;
 }
 // lanes per ray of the cone count pass, 0 = the general lane-per-ray kernel.  Needs the larger workspace
@@ -2017,7 +2026,7 @@ static int cone_lanes_per_ray(const nfa_traverse_args *a) {
     if (const char *e = getenv("NFA_CONE")) { if (atoi(e) == 0) return 0; }
     if (a->n_rays > max_rays) return 0;
     if (a->workspace_bytes < ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a)) return 0;
-    return cone_lanes_for_levels(a->n_grids);
+    return cone_lanes_for_levels(a->n_grids, a->n_rays);
 }
 
 RunStore make_runs(void *workspace, int64_t n_rays) {
