@@ -975,7 +975,7 @@ __device__ __forceinline__ int64_t group_incl_sum_i64(int64_t v, int part) {
 // the group's P bits of a wave-wide ballot
 template <int P>
 __device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int group_base) {
-    return (unsigned)((ballot >> group_base) & ((1ull << P) - 1ull));
+    return (unsigned)((ballot >> group_base) & ((1ull << (P < 32 ? P : 32)) - 1ull));     // (groups wider than 32 lanes only use the low bits: <= 15 segments)
 }
 
 // XT: the plane-crossing times of the ray's three axes are written out in LDS (lanes 1..3 of the ray walk the x / y / z chains
@@ -1993,8 +1993,8 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int
 }
 
 // workspace layout (bytes): [ block_sums: 3 int64 per count workgroup ][ run t0: max_runs*R f32 ][ run first: max_runs*R i32 ][ n_runs: R u16 ]
-// one triple per wave; the finest granularity any count kernel publishes is 4 rays per wave (P = 16)
-inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * (ceil_div(n_rays > 0 ? n_rays : 1, 4) + 2 * kWavesPerBlock); }
+// one triple per wave; the finest granularity any count kernel publishes is 1 ray per wave (the cone kernel's P = 64)
+inline int64_t ws_block_sums_bytes(int64_t n_rays) { return 24 * ((n_rays > 0 ? n_rays : 1) + 2 * kWavesPerBlock); }
 // [ block sums | run records | n_runs ] [ totals: 4 int64, the device copy of what nfa_traverse_offsets stores in args.totals ]
 inline int64_t ws_totals_offset(int64_t n_rays) {
     const int64_t R = n_rays > 0 ? n_rays : 1;
@@ -2002,19 +2002,30 @@ inline int64_t ws_totals_offset(int64_t n_rays) {
 }
 // cone_angle != 0 (cone_walk.hpp): [ ... totals ][ voxel records: count workgroups * (rx + ry + rz) * kBlock u32 ], 256-byte aligned
 inline int64_t ws_voxels_offset(int64_t n_rays) { return (ws_totals_offset(n_rays) + 4 * (int64_t)sizeof(int64_t) + 255) & ~255ll; }
-// lanes per ray: one per level segment (2 G - 1 of them); 16 although 8 would do up to 8192 rays (two waves per SIMD): the chain
-// phase then has 4 rays per wave instead of 8, and a wave pays the longest of its rays at every voxel (measured, 4 x 128^3:
-// 2 k rays 341 -> 309 us, 4 k 344 -> 325, 8 k 373 -> 307; 16 k 346 -> 399 and 32 k 509 -> 702 the other way)
+// lanes per ray: one per level segment (2 G - 1 of them) would do, but (i) the chain phase runs on ONE lane per ray and a wave
+// pays the longest of its rays at every voxel, and (ii) with 32 / 64 lanes per ray a segment is walked by 4 / 8 lanes (parts,
+// cone_walk.hpp) — so small launches get more lanes per ray, as long as the waves still find free SIMDs
+// (measured, 4 x 128^3, cone 0.004, sample_occgrid end to end, us; profiles/r03_cone.md):
+//   rays      8 lanes   16     32     64
+//   1 024       -      314     -     192
+//   2 048      341     309     -     185
+//   4 096      344     328    229    236
+//   8 192      373     305    299    382
+//  16 384      347     393    499    636
 inline int cone_lanes_for_levels(int n_grids, int64_t n_rays) {
     if (n_grids == 1) return 1;
     int P = 2 * n_grids - 1 <= 8 ? 8 : 16;
-    if (P == 8 && n_rays <= 8192) P = 16;
-    if (const char *e = getenv("NFA_CONE_P")) { const int v = atoi(e); if ((v == 8 && 2 * n_grids - 1 <= 8) || v == 16) P = v; }
+    if (n_rays <= 2048) P = 64;
+    else if (n_rays <= 8192) P = 32;
+    if (const char *e = getenv("NFA_CONE_P")) { const int v = atoi(e); if ((v == 8 && 2 * n_grids - 1 <= 8) || v == 16 || v == 32 || v == 64) P = v; }
     return P;
 }
 inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
     const int P = cone_lanes_for_levels(a->n_grids, a->n_rays);
-    return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / P) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 8 /* VoxelStore::kSlack */) * kBlock * 4;
+    const int64_t nb = ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / P);
+    int64_t bytes = nb * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 8 /* VoxelStore::kSlack */) * kBlock * 4;
+    if (P >= 32) bytes += nb * (kBlock / 4) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 3) * 4 + 256;      // crossing-time arrays (K >= 4 lanes per slot)
+    return bytes;
 }
 // lanes per ray of the cone count pass, 0 = the general lane-per-ray kernel.  Needs the larger workspace
 // (nfa_traverse_workspace_bytes_for) announced through args.workspace_bytes.
@@ -2208,9 +2219,9 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
         p.xt = 0;
         p.cap = 0;
         p.lds = 0;
-        // the per-lane segment table (8 B per lane) sits behind the occupancy image; the image only when it leaves room for
+        // the per-lane segment table (12 B per lane) sits behind the occupancy image; the image only when it leaves room for
         // several workgroups per CU (the walk is bound by its instructions, not by where the brick words come from)
-        p.gv = make_view(a, kBlock * 8, &p.lds, 40 * 1024);
+        p.gv = make_view(a, kBlock * 12, &p.lds, 40 * 1024);
         return p;
     }
     if (const int ps = segment_lanes_per_ray(a)) {
@@ -2275,13 +2286,16 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         VoxelStore vs;
         vs.rec = (uint32_t *)((uint8_t *)workspace + ws_voxels_offset(a->n_rays));
         vs.cap = a->res[0] + a->res[1] + a->res[2];
+        vs.xt = nullptr;
+        if (P >= 32 && !getenv("NFA_CONE_NO_PARTS"))
+            vs.xt = (float *)((uint8_t *)vs.rec + ((nbs * (int64_t)(vs.cap + VoxelStore::kSlack) * kBlock * 4 + 255) & ~255ll));
 #define NFA_LAUNCH_CONE(LDSO, PP)                                                                                               \
     do {                                                                                                                       \
         if (int rc = allow_lds(traverse_count_cone_kernel<LDSO, PP>, lds)) return rc;                                           \
         hipLaunchKernelGGL((traverse_count_cone_kernel<LDSO, PP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs, vs); \
     } while (0)
-        if (lds_occ) { if (P == 1) NFA_LAUNCH_CONE(true, 1); else if (P == 8) NFA_LAUNCH_CONE(true, 8); else NFA_LAUNCH_CONE(true, 16); }
-        else { if (P == 1) NFA_LAUNCH_CONE(false, 1); else if (P == 8) NFA_LAUNCH_CONE(false, 8); else NFA_LAUNCH_CONE(false, 16); }
+        if (lds_occ) { if (P == 1) NFA_LAUNCH_CONE(true, 1); else if (P == 8) NFA_LAUNCH_CONE(true, 8); else if (P == 16) NFA_LAUNCH_CONE(true, 16); else if (P == 32) NFA_LAUNCH_CONE(true, 32); else NFA_LAUNCH_CONE(true, 64); }
+        else { if (P == 1) NFA_LAUNCH_CONE(false, 1); else if (P == 8) NFA_LAUNCH_CONE(false, 8); else if (P == 16) NFA_LAUNCH_CONE(false, 16); else if (P == 32) NFA_LAUNCH_CONE(false, 32); else NFA_LAUNCH_CONE(false, 64); }
 #undef NFA_LAUNCH_CONE
         return check_launch("traverse_count_cone_kernel");
     }

@@ -210,3 +210,4 @@ def check_api(case):
 SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 SEGMENT_FORMS = ("1", "0")
 CONE_FORMS = ("1", "0")          # NFA_CONE: lane-per-segment walk + serial chain (cone_walk.hpp) / the general lane-per-ray kernel
+CONE_P_FORMS = ("8", "16", "32", "64")      # NFA_CONE_P: lanes per ray of the two-phase kernel (8 only applies up to 4 levels)

@@ -146,8 +146,10 @@ def test_randomised_fuzz_time_boxed():
     bad, total, cases = [], 0, 0
     t0 = time.time()
     while time.time() - t0 < budget and not bad:
-        which = cases % 6
-        if which == 4:      # cone angles: one level (a lane per ray walks, then chains) ...
+        which = cases % 7
+        if which == 6:      # ... under every lanes-per-ray form of the two-phase kernel
+            b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_CONE_P", F.CONE_P_FORMS)
+        elif which == 4:    # (renumbered below)
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 64, 500, 3000), cones=(0.004, 0.05)), "NFA_CONE", F.CONE_FORMS)
         elif which == 5:    # ... and several (a lane per level segment walks, the ray's first lane chains)
             b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_CONE", F.CONE_FORMS)

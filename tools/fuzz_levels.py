@@ -19,7 +19,12 @@ bad = total = 0
 t_begin = time.time()
 for case in range(n_cases):
     c = F.fused_levels_case(np.random.default_rng(seed0 * 1000003 + case), cones=cones)
-    b, n = F.check_fused(c, "NFA_SEGMENTS", F.SEGMENT_FORMS) if c["cone"] == 0.0 else F.check_fused(c, "NFA_CONE", F.CONE_FORMS)
+    if c["cone"] == 0.0:
+        b, n = F.check_fused(c, "NFA_SEGMENTS", F.SEGMENT_FORMS)
+    else:
+        b, n = F.check_fused(c, "NFA_CONE", F.CONE_FORMS)
+        b2, _ = F.check_fused(c, "NFA_CONE_P", F.CONE_P_FORMS)
+        b += b2
     bad += len(b); total += n
     for line in b:
         print("MISMATCH", f"case {case}", line, flush=True)
