@@ -1392,9 +1392,15 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
 // state; and a first occupied run that continues the previous segment's samples starts no new run record.
 // cone_angle == 0, no step limit, no ray mask; anything odd (stuck lattice, a segment with more than CAP
 // boundaries) goes through the serial walk of the whole ray by the group's first lane.
-template <bool LDS_OCC, int P, int CAP>
+// K > 1 (round 3; P = 32 lanes per ray, K = 4 per segment slot, up to 4 levels and 4096 rays): a launch that small has lanes to
+// spare, and a segment's walk — 100-190 voxels at ~1000 cycles each, more than half of this kernel — is cut into K PARTS at
+// crossings of its major axis, as the single-level kernel cuts a ray: three lanes of the slot write the plane-crossing times of
+// the segment's x / y / z chains into scratch (`xt`, plain adds: exact by construction), every part then finds its start state
+// with reads and two binary searches and inherits the occupancy of the voxel before its seam.  A part's boundaries are positions on
+// the ray's ONE chain like a segment's; only the first lane WITH boundaries of a slot applies the jump to the segment's start.
+template <bool LDS_OCC, int P, int CAP, int KP = 1>
 __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_traverse_args a, GridView gv,
-                                                                         int64_t *__restrict__ block_sums, RunStore rs)
+                                                                         int64_t *__restrict__ block_sums, RunStore rs, float *__restrict__ xt)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NFA_PHASE_BEGIN();
@@ -1420,7 +1426,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     ev.init(a, rr, o, inv);
     int level = 0;
     float seg_lo = 0.f, seg_hi = 0.f;
-    const bool live = ray_ok && part + 1 < 2 * G && segment_of(ev, part, G, near, far, level, seg_lo, seg_hi);
+    const int slot = part / KP, sub = part % KP;
+    const bool live = ray_ok && slot + 1 < 2 * G && segment_of(ev, slot, G, near, far, level, seg_lo, seg_hi);
 
     NFA_PHASE_MARK(1);
     // the chain starts at the first live segment
@@ -1441,11 +1448,82 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     // returning false stops the walk.  kSegBatch voxels per trip: the DDA does not depend on the occupancy, so the steps of a
     // batch run first, their brick words are requested together (one LDS / L2 latency per batch instead of one per voxel:
     // 126 k -> 93 k cycles per wave) and the boundaries are found afterwards, in order.
+    // the lane's start state: the segment's first voxel, or (K > 1) the first voxel behind the part's seam
+    Dda s0;
+    s0.tx = s0.ty = s0.tz = 0.f; s0.dx = s0.dy = s0.dz = 0.f;
+    s0.sx = s0.sy = s0.sz = 0; s0.cx = s0.cy = s0.cz = 0; s0.ox = s0.oy = s0.oz = 0;
+    if (live) dda_setup(s0, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
+    bool part_live = live, have_run0 = false, run_occ0 = false;
+    float run_exit0 = 0.f;
+    int major0 = 0, j_end = 0x7fffffff, m_rank = 0;
+    if (KP > 1) {
+        const int nx = s0.sx ? (s0.ox - s0.cx) * s0.sx : 1, ny = s0.sy ? (s0.oy - s0.cy) * s0.sy : 1, nz = s0.sz ? (s0.oz - s0.cz) * s0.sz : 1;
+        const bool regular = live && nx > 0 && ny > 0 && nz > 0 && nx <= gv.res[0] && ny <= gv.res[1] && nz <= gv.res[2];
+        const int oy_ = gv.res[0] + 1, oz_ = gv.res[0] + gv.res[1] + 2;
+        float *const A = xt + ((int64_t)blockIdx.x * (kBlock / KP) + tid / KP) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
+        if (regular && sub < 3) {                          // the chain of axis `sub`: entry i = time of its crossing i
+            float t = sub == 0 ? s0.tx : (sub == 1 ? s0.ty : s0.tz);
+            const float dd = sub == 0 ? s0.dx : (sub == 1 ? s0.dy : s0.dz);
+            const int na = sub == 0 ? nx : (sub == 1 ? ny : nz);
+            float *dst = A + (sub == 0 ? 0 : (sub == 1 ? oy_ : oz_));
+            for (int i = 0; i <= na; ++i) { dst[i] = t; t = t + dd; }
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();                   // (the K lanes of a slot are lanes of one wave)
+        if (regular) {
+            const float Tx = A[nx - 1], Ty = A[oy_ + ny - 1], Tz = A[oz_ + nz - 1];       // the walk ends with the earliest of these
+            int end_rank = 2; float T_end = Tx;                                       // ranks: z 0, y 1, x 2
+            if (crossing_precedes(Ty, 1, T_end, end_rank)) { T_end = Ty; end_rank = 1; }
+            if (crossing_precedes(Tz, 0, T_end, end_rank)) { T_end = Tz; end_rank = 0; }
+            m_rank = (nx >= ny && nx >= nz) ? 2 : (ny >= nz ? 1 : 0);
+            const int n_major = m_rank == 2 ? nx : (m_rank == 1 ? ny : nz);
+            const int j_begin = (int)(((int64_t)sub * n_major) / KP);
+            j_end = (sub == KP - 1) ? 0x7fffffff : (int)(((int64_t)(sub + 1) * n_major) / KP);
+            major0 = j_begin;
+            part_live = j_begin < j_end;
+            if (part_live && j_begin > 0) {
+                const float T_seam = A[(m_rank == 2 ? 0 : (m_rank == 1 ? oy_ : oz_)) + j_begin - 1];   // time of major crossing j_begin
+                if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;   // the walk ends before this seam
+                else {
+                    const bool xm = m_rank == 2, zm = m_rank == 0;
+                    const float *A1 = A + (xm ? oy_ : 0), *A2 = A + (zm ? oy_ : oz_);
+                    const int r1 = xm ? 1 : 2, r2 = zm ? 1 : 0;
+                    const int n1 = xm ? ny : nx, n2 = zm ? ny : nz;
+                    int lo1 = 0, hi1 = n1, lo2 = 0, hi2 = n2;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                        const float v1 = A1[m1], v2 = A2[m2];
+                        if (lo1 < hi1) { if (crossing_precedes(v1, r1, T_seam, m_rank)) lo1 = m1 + 1; else hi1 = m1; }
+                        if (lo2 < hi2) { if (crossing_precedes(v2, r2, T_seam, m_rank)) lo2 = m2 + 1; else hi2 = m2; }
+                    }
+                    const float pend1 = A1[lo1], pend2 = A2[lo2];
+                    if (!xm) { s0.cx += lo1 * s0.sx; s0.tx = pend1; }
+                    if (xm) { s0.cy += lo1 * s0.sy; s0.ty = pend1; }
+                    if (zm) { s0.cy += lo2 * s0.sy; s0.ty = pend2; }
+                    if (!zm) { s0.cz += lo2 * s0.sz; s0.tz = pend2; }
+                    // the voxel just before the seam: the run state the part inherits
+                    int px = s0.cx, py = s0.cy, pz = s0.cz;
+                    if (m_rank == 2) { px += (j_begin - 1) * s0.sx; s0.cx += j_begin * s0.sx; s0.tx = T_seam + s0.dx; }
+                    else if (m_rank == 1) { py += (j_begin - 1) * s0.sy; s0.cy += j_begin * s0.sy; s0.ty = T_seam + s0.dy; }
+                    else { pz += (j_begin - 1) * s0.sz; s0.cz += j_begin * s0.sz; s0.tz = T_seam + s0.dz; }
+                    BrickCache cache;
+                    cache.id = -1;
+                    cache.bits = 0;
+                    have_run0 = true;
+                    run_occ0 = occupied(gv, occ, cache, level, px, py, pz);
+                    run_exit0 = fminf(T_seam, seg_hi);
+                }
+            }
+        } else {
+            part_live = live && sub == 0;                  // odd index bookkeeping: the slot's first lane walks the whole segment
+        }
+    }
     auto walk = [&](auto &&on_boundary) {
-        Dda s;
-        dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
-        bool have_run = false, run_occ = false, stop = false;
-        float run_exit = 0.f;
+        Dda s = s0;
+        bool have_run = have_run0, run_occ = run_occ0, stop = false, ended = true;
+        float run_exit = run_exit0;
+        int major_done = major0;
         const uint32_t *lc = (const uint32_t *)occ.smem;
         for (bool more = true; more;) {
             bool valid[kSegBatch];
@@ -1457,7 +1535,17 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
                 tc[k] = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
                 id[k] = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + level * gv.bricks_per_grid;
                 bp[k] = ((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3);
-                if (more) more = dda_advance(s);
+                if (more) {
+                    if (KP > 1) {
+                        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+                        more = dda_advance(s);
+                        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+                        major_done += (cm_after != cm_before) ? 1 : 0;
+                        if (more && major_done >= j_end) { more = false; ended = false; }     // the next part's seam: the run stays open
+                    } else {
+                        more = dda_advance(s);
+                    }
+                }
             }
             uint64_t bits[kSegBatch];
             if (LDS_OCC) {
@@ -1491,7 +1579,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
             }
             if (stop) more = false;
         }
-        if (!stop) on_boundary(run_exit, run_occ);             // the segment's last run
+        if (!stop && ended) on_boundary(run_exit, run_occ);    // the segment's last run
     };
 
     // ---- A: this segment's boundaries into the lane's list; a segment with more than CAP of them is STREAMED: its boundaries
@@ -1499,7 +1587,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     int n_ev = 0;
     unsigned ev_occ = 0;
     bool streaming = false;
-    if (live)
+    if (part_live)
         walk([&](float t_exit, bool oc) {
             if (n_ev == CAP) { streaming = true; return false; }
             ev_lds[n_ev * kBlock + tid] = t_exit;
@@ -1516,7 +1604,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
     int fresh_rest = 0;
     int64_t K_first = 0;
     bool cont_rest = false, occ_first = false;
-    if (live) {
+    if (part_live) {
         T_lo = nfa_lattice_until(t_seg, dt, seg_lo, &K_lo, &stuck);
         stuck_any = stuck_any || stuck;
         float T = T_lo;
@@ -1562,7 +1650,11 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
 #endif
 
     // ---- stitch, segment by segment: (position, continuous) before every part
-    const bool has = live && n_ev > 0;
+    const bool has = part_live && n_ev > 0;
+    // the jump to a segment's start (entering it while not continuous) belongs to the first lane WITH boundaries of its slot
+    const unsigned has_lanes = group_bits<P>(__ballot(has), group_base);
+    const unsigned slot_lanes = ((1u << KP) - 1u) << (slot * KP);
+    const bool enters = has && (has_lanes & slot_lanes & ((1u << part) - 1u)) == 0u;
     int Kpos = 0;
     float Tpos = t_seg;
     bool cont = false, any_has = false;
@@ -1578,14 +1670,14 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
         const bool has_p = __shfl((int)has, src, 64) != 0;
         const int Klo_p = __shfl((int)K_lo, src, 64), Kf_p = __shfl((int)K_first, src, 64), Kl_p = __shfl((int)K_last, src, 64);
         const float Tlo_p = __shfl(T_lo, src, 64), Tl_p = __shfl(T_last, src, 64);
-        const int flags_p = __shfl((occ_first ? 1 : 0) | (cont_rest ? 2 : 0) | (n_ev >= 2 ? 4 : 0), src, 64);
+        const int flags_p = __shfl((occ_first ? 1 : 0) | (cont_rest ? 2 : 0) | (n_ev >= 2 ? 4 : 0) | (enters ? 8 : 0), src, 64);
         const int64_t smr_p = __shfl(sm_rest, src, 64);
         const int frr_p = __shfl(fresh_rest, src, 64);
         if (part == p) { my_sm_before = sm_acc; my_fresh_before = fresh_acc; my_cont_in = cont; }
         if (has_p) {
             int Ks = Kpos;
             float Ts = Tpos;
-            if (!cont && Klo_p > Kpos) { Ks = Klo_p; Ts = Tlo_p; }      // entering the segment: jump to its start
+            if ((flags_p & 8) && !cont && Klo_p > Kpos) { Ks = Klo_p; Ts = Tlo_p; }      // entering the segment: jump to its start
             const bool of = flags_p & 1;
             const int k1 = of && Kf_p > Ks ? Kf_p - Ks : 0;
             const bool fresh1 = k1 > 0 && !cont;
@@ -2149,14 +2241,17 @@ NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
     return ws_totals_offset(R) + 4 * (int64_t)sizeof(int64_t);
 }
 
+static int segment_lanes_per_ray(const nfa_traverse_args *a);
+static int64_t seg_parts_bytes_fwd(const nfa_traverse_args *a);
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes_for(const nfa_traverse_args *a) {
     if (!a) return 0;
     const int64_t base = nfa_traverse_workspace_bytes(a->n_rays);
     if (a->n_rays <= 0 || a->n_grids < 1 || a->n_grids > NFA_MAX_GRID_LEVELS) return base;
     nfa_traverse_args probe = *a;
     probe.workspace_bytes = INT64_MAX;
-    if (!cone_lanes_per_ray(&probe)) return base;
-    return ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a);
+    if (cone_lanes_per_ray(&probe)) return ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a);
+    if (segment_lanes_per_ray(&probe) == 32) return ws_voxels_offset(a->n_rays) + seg_parts_bytes_fwd(a);
+    return base;
 }
 
 // lanes per ray of the count pass for this call (1 = lane-per-ray kernels).  `sparse`: the full
@@ -2200,6 +2295,11 @@ struct SplitPlan { int P, cap, lds, blk, xt, seg; GridView gv; };
 // several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
 // with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
 // 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off, NFA_SEGMENTS_MAX_RAYS moves the limit
+// crossing-time arrays of the segment kernel's parts: one (rx + ry + rz + 3)-float array per segment slot, 8 slots per ray
+inline int64_t seg_parts_bytes(const nfa_traverse_args *a) {
+    return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / 32) * (kBlock / 4) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 3) * 4 + 256;
+}
+static int64_t seg_parts_bytes_fwd(const nfa_traverse_args *a) { return seg_parts_bytes(a); }
 static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     if (!lattice || a->t_sorted || a->n_grids < 2 || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
@@ -2207,7 +2307,13 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     if (const char *e = getenv("NFA_SEGMENTS_MAX_RAYS")) max_rays = atoll(e);
     if (const char *e = getenv("NFA_SEGMENTS")) { if (atoi(e) == 0) return 0; }
     if (a->n_rays > max_rays) return 0;
-    return 2 * a->n_grids - 1 <= 8 ? 8 : 16;
+    int P = 2 * a->n_grids - 1 <= 8 ? 8 : 16;
+    // 32 lanes per ray = 4 per segment slot (parts) while the launch has lanes to spare and the caller's workspace holds the
+    // crossing-time arrays (nfa_traverse_workspace_bytes_for); NFA_SEG_P = 8 | 32 overrides
+    const bool room = a->workspace_bytes >= ws_voxels_offset(a->n_rays) + seg_parts_bytes(a);
+    if (P == 8 && room && a->n_rays <= 4096) P = 32;
+    if (const char *e = getenv("NFA_SEG_P")) { const int v = atoi(e); if (v == 8 && P == 32) P = 8; else if (v == 32 && P == 8 && room) P = 32; }
+    return P;
 }
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
@@ -2305,13 +2411,14 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         const bool lds_occ = gv.lds_compact_cap > 0;
         const unsigned nbs = (unsigned)ceil_div(a->n_rays, plan.blk / P);
         if (plan.seg) {
-#define NFA_LAUNCH_SEG(LDSO, PP, CAP)                                                                                           \
+#define NFA_LAUNCH_SEG(LDSO, PP, CAP, KK)                                                                                       \
     do {                                                                                                                       \
-        if (int rc = allow_lds(traverse_count_segments_kernel<LDSO, PP, CAP>, lds)) return rc;                                   \
-        hipLaunchKernelGGL((traverse_count_segments_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+        if (int rc = allow_lds(traverse_count_segments_kernel<LDSO, PP, CAP, KK>, lds)) return rc;                               \
+        hipLaunchKernelGGL((traverse_count_segments_kernel<LDSO, PP, CAP, KK>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs, seg_xt); \
     } while (0)
-            if (lds_occ) { if (P == 8) NFA_LAUNCH_SEG(true, 8, 32); else NFA_LAUNCH_SEG(true, 16, 32); }
-            else { if (P == 8) NFA_LAUNCH_SEG(false, 8, 32); else NFA_LAUNCH_SEG(false, 16, 32); }
+            float *seg_xt = (float *)((uint8_t *)workspace + ws_voxels_offset(a->n_rays));     // crossing-time arrays (P = 32 only)
+            if (lds_occ) { if (P == 8) NFA_LAUNCH_SEG(true, 8, 32, 1); else if (P == 16) NFA_LAUNCH_SEG(true, 16, 32, 1); else NFA_LAUNCH_SEG(true, 32, 32, 4); }
+            else { if (P == 8) NFA_LAUNCH_SEG(false, 8, 32, 1); else if (P == 16) NFA_LAUNCH_SEG(false, 16, 32, 1); else NFA_LAUNCH_SEG(false, 32, 32, 4); }
 #undef NFA_LAUNCH_SEG
             return check_launch("traverse_count_segments_kernel");
         }

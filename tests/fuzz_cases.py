@@ -209,5 +209,6 @@ def check_api(case):
 
 SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 SEGMENT_FORMS = ("1", "0")
+SEG_P_FORMS = ("8", "32")        # NFA_SEG_P: one lane per level segment / four (parts), cone_angle = 0, up to 4 levels
 CONE_FORMS = ("1", "0")          # NFA_CONE: lane-per-segment walk + serial chain (cone_walk.hpp) / the general lane-per-ray kernel
 CONE_P_FORMS = ("8", "16", "32", "64")      # NFA_CONE_P: lanes per ray of the two-phase kernel (8 only applies up to 4 levels)

@@ -156,7 +156,9 @@ def test_randomised_fuzz_time_boxed():
         elif which == 0:
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000)), "NFA_SPLIT_P", F.SPLIT_P_FORMS)
         elif which == 1:
-            b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 5, 64, 700, 4096)), "NFA_SEGMENTS", F.SEGMENT_FORMS)
+            c = F.fused_levels_case(g, ray_counts=(1, 5, 64, 700, 4096))
+            b, k = F.check_fused(c, "NFA_SEGMENTS", F.SEGMENT_FORMS)
+            b += F.check_fused(c, "NFA_SEG_P", F.SEG_P_FORMS)[0]
         elif which == 2:
             b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_SEGMENTS", F.SEGMENT_FORMS)
         else:

@@ -21,6 +21,8 @@ for case in range(n_cases):
     c = F.fused_levels_case(np.random.default_rng(seed0 * 1000003 + case), cones=cones)
     if c["cone"] == 0.0:
         b, n = F.check_fused(c, "NFA_SEGMENTS", F.SEGMENT_FORMS)
+        b2, _ = F.check_fused(c, "NFA_SEG_P", F.SEG_P_FORMS)
+        b += b2
     else:
         b, n = F.check_fused(c, "NFA_CONE", F.CONE_FORMS)
         b2, _ = F.check_fused(c, "NFA_CONE_P", F.CONE_P_FORMS)
