@@ -266,8 +266,9 @@ int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, co
                            void *stream);
 /* The same with a completion stamp for callers that poll instead of synchronising the stream: n_out is [2] in coherent pinned
  * host memory and the kernel stores `stamp` (non-zero) into n_out[1] right after the count, behind a system-scope fence — the
- * host may read n_out[0] as soon as it sees the stamp, while the compaction itself is still running (inputs of fewer than
- * 2^24 tiles; beyond that the stamp never comes: fall back to a stream synchronisation after a bounded wait). */
+ * host may read n_out[0] as soon as it sees the stamp, while the compaction itself is still running (inputs of up to
+ * 2^18 wave tiles — about 3e8 samples; beyond that the total is written by a separate scan kernel and the stamp never comes:
+ * synchronise the stream instead). */
 int nfa_visibility_compact_stamped(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                                    const float *sigmas, int32_t from_alpha, int64_t n, float early_stop_eps, float alpha_thre,
                                    int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, uint8_t *out_mask,

@@ -133,6 +133,10 @@ py::dict timing_summary() {
 // into pinned host memory, so the readback is a stream wait plus a CPU load.  One slot per (device, stream,
 // host thread): the calls stay re-entrant across threads and streams like the reference's stateless functions.
 // ---------------------------------------------------------------------------------------------------
+// false once a slot had to be allocated without hipHostMallocCoherent: a polling host may then never see a running kernel's
+// store, so wait_stamp synchronises the stream straight away instead of spinning for its 2 ms first
+std::atomic<bool> g_host_ints_coherent{true};
+
 int64_t *host_ints(int device, hipStream_t s) {
     thread_local std::map<std::pair<int, hipStream_t>, int64_t *> slots;
     auto key = std::make_pair(device, s);
@@ -144,6 +148,7 @@ int64_t *host_ints(int device, hipStream_t s) {
         (void)hipGetLastError();
         TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
                     "nerfacc_amd: hipHostMalloc failed");
+        g_host_ints_coherent = false;
     }
     for (int i = 0; i < 8; ++i) p[i] = 0;
     if (slots.size() > 64) slots.clear();      // (slots of dead streams are leaked: 64 B each)
@@ -164,7 +169,7 @@ inline void wait_stamp(const int64_t *slot, int64_t stamp, hipStream_t s) {
     py::gil_scoped_release nogil;
     const volatile int64_t *p = slot;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int64_t spins = 0;; ++spins) {
+    for (int64_t spins = 0; g_host_ints_coherent.load(std::memory_order_relaxed); ++spins) {
         if (*p == stamp) { std::atomic_thread_fence(std::memory_order_acquire); return; }
         if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
