@@ -1939,6 +1939,104 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args
     }
 }
 
+// pass 2, ray-group form (round 3): 16 LANES PER RAY walk the ray's run records in order — no searches.  The sample-parallel
+// form above is bound by its chain of ~14 dependent loads per sample (0.9 TB/s of stores at any size: 666 us for the 38 M
+// samples of 10^6 rays); here a ray costs two round trips (its counts and offsets, then its runs) and every 16 samples one
+// pass of 15 predicated adds: lane k of a group holds the run's lattice point after k steps, the next pass starts from lane
+// 15's end — the same sequential float adds the reference performs, so exact for any cone angle (the sample-parallel form
+// needs the closed form for cone_angle = 0 and j adds per sample otherwise).  Adjacent groups take adjacent rays: their
+// loads coalesce and their stores fill one contiguous stretch of the outputs.
+struct EmitRay {           // what a group of 16 lanes needs of a ray: ONE round trip (every load is independent of the others)
+    int64_t cnt, S, E;
+    int nr;
+    float run_t0;          // lane k: run k of the ray (garbage beyond the ray's runs, never used)
+    int run_first, run_next;
+};
+__device__ __forceinline__ EmitRay emit_ray_load(const nfa_traverse_args &a, const RunStore &rs, int64_t r, int gl) {
+    EmitRay m;
+    const int64_t R = a.n_rays;
+    m.cnt = a.sm_cnts[r];
+    m.nr = rs.n_runs[r];
+    m.S = a.sm_starts[r];
+    m.E = a.iv_vals ? a.iv_starts[r] : 0;
+    m.run_t0 = 0.0f; m.run_first = 0; m.run_next = 0;
+    if (gl < rs.max_runs) {
+        m.run_t0 = rs.t0[(int64_t)gl * R + r];
+        m.run_first = gl > 0 ? rs.first[(int64_t)gl * R + r] : 0;
+        if (gl + 1 < rs.max_runs) m.run_next = rs.first[(int64_t)(gl + 1) * R + r];
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(kBlock) void traverse_emit_rays_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
+                                                                    const int64_t *__restrict__ n_dev)
+{
+    if (n_dev && n_dev[1] > capacity) return;      // speculative launch whose outputs are too small: the caller launches again
+    constexpr int G = 16;
+    const float step_size = a.step_size, cone = a.cone_angle;
+    const int64_t R = a.n_rays;
+    const int lane = lane_id(), gl = lane & (G - 1), gbase = lane & ~(G - 1);
+    const int64_t n_groups = (int64_t)gridDim.x * (kBlock / G);
+    int64_t r = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    if (r >= R) return;
+    EmitRay m = emit_ray_load(a, rs, r, gl);
+    for (; r < R; r += n_groups) {
+        const EmitRay c = m;
+        if (r + n_groups < R) m = emit_ray_load(a, rs, r + n_groups, gl);      // the next ray's round trip overlaps this ray's stores
+        if (c.cnt <= 0) continue;                  // (a masked ray recorded nothing)
+        const int nr = c.nr;
+        if (nr == kRunsOverflow) continue;         // written by the fallback launch
+        const int64_t S = c.S, E = c.E;
+        for (int q0 = 0; q0 < nr; q0 += G) {
+            const int q = q0 + gl;                 // the group's lanes hold 16 runs at once
+            float run_t0 = c.run_t0;
+            int run_first = c.run_first, run_end = q + 1 < nr ? c.run_next : (int)c.cnt;
+            if (q0 > 0 && q < nr) {                // (a ray with more than 16 runs)
+                run_t0 = rs.t0[(int64_t)q * R + r];
+                run_first = rs.first[(int64_t)q * R + r];
+                run_end = q + 1 < nr ? rs.first[(int64_t)(q + 1) * R + r] : (int)c.cnt;
+            }
+            const int nq = nr - q0 < G ? nr - q0 : G;
+            for (int i = 0; i < nq; ++i) {
+                float base = __shfl(run_t0, gbase + i, 64);
+                const int first = __shfl(run_first, gbase + i, 64);
+                const int len = __shfl(run_end, gbase + i, 64) - first;
+                const float dt0 = march_dt(base, cone, step_size);
+                for (int j0 = 0; j0 < len; j0 += G) {
+                    // every lane runs the pass's 16 sequential adds (the only chain from one pass to the next: no shuffle) and
+                    // keeps the value after its own k steps
+                    float t = base, full = base;
+                    if (cone == 0.0f) {
+#pragma unroll
+                        for (int k = 1; k < G; ++k) { full = full + dt0; t = gl >= k ? full : t; }
+                        base = full + dt0;
+                    } else {
+#pragma unroll
+                        for (int k = 1; k < G; ++k) { full = full + march_dt(full, cone, step_size); t = gl >= k ? full : t; }
+                        base = full + march_dt(full, cone, step_size);
+                    }
+                    const float t1 = t + march_dt(t, cone, step_size);
+                    const int j = j0 + gl;
+                    if (j < len) {
+                        const int64_t s = S + first + j;
+                        if (a.sm_vals) a.sm_vals[s] = (t1 + t) * 0.5f;
+                        if (a.sm_ray_indices) a.sm_ray_indices[s] = r;
+                        if (a.sm_is_valid) a.sm_is_valid[s] = 1;
+                        if (a.t_starts) { a.t_starts[s] = t; a.t_ends[s] = t1; }
+                        if (a.iv_vals) {
+                            // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
+                            const int64_t e_right = E + first + j + (q0 + i) + 1;
+                            a.iv_vals[e_right] = t1; a.iv_ray_indices[e_right] = r; a.iv_is_right[e_right] = 1;
+                            a.iv_is_left[e_right - 1] = 1;
+                            if (j == 0) { a.iv_vals[e_right - 1] = t; a.iv_ray_indices[e_right - 1] = r; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // generic exclusive sum of int64 counts (data_spec.hpp:86-106), single workgroup of 1024:
 // rounds of 1024 coalesced elements with a running carry.  Used for the per-ray count arrays
 // of the over-allocated traversal mode and the tile counts of the visibility compaction.
@@ -2045,6 +2143,7 @@ int validate_traverse(const nfa_traverse_args *a) {
 // when known (args.n_nonempty_bricks >= 0, nfa_pack_binaries' header read back once per grid
 // update) so that several workgroups fit per CU; otherwise from the budget.
 constexpr int kLdsBudget = 96 * 1024;
+constexpr int kLdsPerCU = 160 * 1024;
 constexpr int kEvBytes = kEvCap * kBlock * 4 * 2;   // boundary times + lattice indices
 
 GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int budget = kLdsBudget) {
@@ -2267,11 +2366,10 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         // walk does the same job in fewer instructions.  Dense / noisy grids have a boundary every
         // few voxels, so their parts are kept shorter (more lanes per ray).
         if (sparse) {
-            // profiles/r02_split_sweep.md (bench steady state: ~190 voxels and 40 samples per ray): 16 lanes per ray with
-            // 16-entry boundary lists while the launch fits two workgroups per CU (<= 8192 rays), 8 lanes up to ~49 k rays,
-            // lane-per-ray beyond; 4 and 2 lanes per ray never win on a sparse grid
-            if (a->n_rays <= 8192) P = 16;
-            else if (a->n_rays <= 49152) P = 8;
+            // profiles/r02_split_sweep.md, r03_count_pass.md (bench steady state: ~190 voxels and 40 samples per ray): 16 lanes
+            // per ray up to 16 k rays, 8 up to 96 k, lane-per-ray beyond; 4 and 2 lanes per ray never win on a sparse grid
+            if (a->n_rays <= 16384) P = 16;
+            else if (a->n_rays <= 98304) P = 8;
         } else {
             if (a->n_rays <= 8192) P = 16;
             else if (a->n_rays <= 16384) P = 8;
@@ -2281,7 +2379,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
-            if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for LDS-resident grids: they never won)
+            if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for sparse grids: they never won)
         }
     }
     return P;
@@ -2291,7 +2389,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 // sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
 // be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
 // LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
-struct SplitPlan { int P, cap, lds, blk, xt, seg; GridView gv; };
+struct SplitPlan { int P, cap, lds, blk, xt, seg, l2; GridView gv; };
 // several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
 // with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
 // 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off, NFA_SEGMENTS_MAX_RAYS moves the limit
@@ -2318,6 +2416,7 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
 static SplitPlan plan_split(const nfa_traverse_args *a) {
     SplitPlan p;
     p.seg = 0;
+    p.l2 = 0;
     if (const int pc = cone_lanes_per_ray(a)) {
         p.P = pc;
         p.seg = 2;                  // cone_walk.hpp
@@ -2368,6 +2467,21 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
         p.P = count_lanes_per_ray(a, false);
         p.cap = 32;
         p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
+        return p;
+    }
+    // sparse grid, but more rays than one round of LDS-image workgroups holds (> 8192): the image stays in L2 and the
+    // workgroup's LDS is its lists only, 32 KB — five workgroups share a CU instead of one and the walk, bound by its
+    // dependent instructions, overlaps five times as many of them (r03_count_pass.md: 74 -> 49 us at 20 k rays, 142 -> 87 at
+    // 50 k; also staging the 4 KB bitmap of non-empty bricks is 2-3 % slower than leaving everything in L2).
+    // NFA_SPLIT_L2 = 0 | 1 overrides
+    bool l2 = a->n_rays > 8192;
+    if (const char *e = getenv("NFA_SPLIT_L2")) l2 = atoi(e) != 0;
+    if (l2) {
+        p.l2 = 1;
+        p.blk = kBlock;
+        p.xt = 0;
+        p.cap = 16;
+        p.gv = make_view(a, p.cap * kBlock * 8, &p.lds, 0);
     }
     return p;
 }
@@ -2427,7 +2541,10 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \
         hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
     } while (0)
-        if (lds_occ && plan.blk == 512 && plan.xt) {
+        if (plan.l2) {
+            // grid image from L2: 16-entry lists, 32 KB of LDS per workgroup
+            if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 16);
+        } else if (lds_occ && plan.blk == 512 && plan.xt) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ && plan.blk == 512) {
@@ -2444,7 +2561,15 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     }
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     int lds = 0;
-    const GridView gv = make_view(a, kEvBytes, &lds);
+    GridView gv = make_view(a, kEvBytes, &lds);
+    // the image in LDS only while one round of workgroups holds every ray: beyond, its copy per workgroup and the CU's
+    // occupancy (one or two workgroups) cost more than L2 latency does (r03_count_pass.md: 937 -> 632 us at 1 M rays).
+    // NFA_COUNT_L2 = 0 | 1 overrides
+    {
+        bool l2 = gv.lds_compact_cap > 0 && (int64_t)nb > (int64_t)kNumCU * (kLdsPerCU / (lds > 0 ? lds : 1));
+        if (const char *e = getenv("NFA_COUNT_L2")) l2 = atoi(e) != 0;
+        if (l2) gv = make_view(a, kEvBytes, &lds, 0);
+    }
     const bool lds_occ = gv.lds_compact_cap > 0;
 #define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
     do {                                                                                                                    \
@@ -2489,8 +2614,13 @@ NFA_EXPORT int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const vo
 static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint16_t *only_overflow, hipStream_t s)
 {
     int lds = 0;
-    const GridView gv = make_view(a, 0, &lds);       // no boundary lists in the general walk
+    GridView gv = make_view(a, 0, &lds);       // no boundary lists in the general walk
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
+    {   // (image in LDS only while one round of workgroups holds every ray, as in nfa_traverse_count)
+        bool l2 = gv.lds_compact_cap > 0 && (int64_t)nb > (int64_t)kNumCU * (kLdsPerCU / (lds > 0 ? lds : 1));
+        if (const char *e = getenv("NFA_COUNT_L2")) l2 = atoi(e) != 0;
+        if (l2) gv = make_view(a, 0, &lds, 0);
+    }
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
     const bool lds_occ = gv.lds_compact_cap > 0;
 #define NFA_LAUNCH_FILL(EVM, LDSO)                                                                                           \
@@ -2504,6 +2634,18 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     else { if (lds_occ) NFA_LAUNCH_FILL(EV_MANY, true); else NFA_LAUNCH_FILL(EV_MANY, false); }
 #undef NFA_LAUNCH_FILL
     return check_launch("traverse_fill_kernel");
+}
+
+// a lane per sample with searches, or — from 24 k rays — 16 lanes per ray (r03_count_pass.md: below, the batch's longest ray is the
+// ray-group kernel's whole duration: 12.9 vs 7.5 us at 6.5 k rays; 23 vs 25 us at 32 k, 356 vs 655 us at 10^6).
+// NFA_EMIT = rays | samples overrides
+static bool emit_by_rays(int64_t n_rays) {
+    if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r';
+    return n_rays >= 24576;
+}
+static unsigned emit_ray_blocks(int64_t n_rays) {
+    const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;
+    return (unsigned)(nb < cap ? nb : cap);
 }
 
 NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty, int32_t rewrite_counts,
@@ -2522,7 +2664,8 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
-        hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
+        if (emit_by_rays(a->n_rays)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
+        else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         if (int rc = check_launch("traverse_emit_kernel")) return rc;
     }
     if (n_overflow > 0) return launch_fill(a, 1, 0, rs.n_runs, s);
@@ -2538,7 +2681,8 @@ NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const v
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
-    hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    if (emit_by_rays(a->n_rays)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
     return check_launch("traverse_emit_kernel");
 }
 

@@ -142,24 +142,30 @@ def check_fused(case, env_name, env_values):
     live = r_sm["packed_info"][:, 1] > 0         # (the reference leaves the terminate plane of a ray without samples unwritten)
     args = (T(c["o"]), T(c["d"]), T(c["occ"]), T(c["aabbs"]), T(c["near"]), T(c["far"]), c["step"], c["cone"])
     bad = []
-    saved = os.environ.get(env_name)
+    # env_name None: every value is a list of assignments, "NFA_A=1,NFA_B=2"
+    names = [env_name] if env_name else sorted({kv.split("=")[0] for v in env_values for kv in v.split(",") if kv})
+    saved = {k: os.environ.get(k) for k in names}
     try:
         for v in env_values:
-            if v:
+            for k in names:
+                os.environ.pop(k, None)
+            if env_name and v:
                 os.environ[env_name] = v
-            else:
-                os.environ.pop(env_name, None)
+            elif not env_name:
+                for kv in filter(None, v.split(",")):
+                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
             ri, ts, te, pk, term = C.sample_occgrid(*args, with_terminate_planes=True)
             diff = [k for k, same in (("ray_indices", np.array_equal(_n(ri), r_ri)), ("t_starts", np.array_equal(_n(ts), r_ts)),
                                       ("t_ends", np.array_equal(_n(te), r_te)), ("packed_info", np.array_equal(_n(pk), r_sm["packed_info"])),
                                       ("terminate_planes", np.array_equal(_n(term)[live], r_term[live]))) if not same]
             if diff:
-                bad.append(f"{c['desc']} {env_name}={v or 'auto'}: {diff} differ ({len(r_ri)} oracle samples, {ri.shape[0]} here)")
+                bad.append(f"{c['desc']} {env_name or ''}{'=' if env_name else ''}{v or 'auto'}: {diff} differ ({len(r_ri)} oracle samples, {ri.shape[0]} here)")
     finally:
-        if saved is None:
-            os.environ.pop(env_name, None)
-        else:
-            os.environ[env_name] = saved
+        for k, old in saved.items():
+            if old is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old
     return bad, len(r_ri)
 
 
@@ -186,7 +192,24 @@ def api_case(g, ray_counts=(3, 100, 2000, 12000)):
                 desc=f"api levels={levels} res={res} R={R} step={step} cone={cone} kw={ {k: v for k, v in kw.items() if k != 'rays_mask'} }")
 
 
-def check_api(case):
+def check_api(case, emit_forms=("rays", "samples")):
+    """nerfacc_amd.grid.traverse_grids under both emit kernels vs the oracle, every output"""
+    bad, n = [], 0
+    saved = os.environ.get("NFA_EMIT")
+    try:
+        for v in emit_forms:
+            os.environ["NFA_EMIT"] = v
+            b, n = _check_api(case)
+            bad += [f"{line} (NFA_EMIT={v})" for line in b]
+    finally:
+        if saved is None:
+            os.environ.pop("NFA_EMIT", None)
+        else:
+            os.environ["NFA_EMIT"] = saved
+    return bad, n
+
+
+def _check_api(case):
     from nerfacc_amd.grid import traverse_grids
 
     c, kw = case, case["kw"]
@@ -208,6 +231,11 @@ def check_api(case):
 
 
 SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
+# where the grid image is read from (single level, cone_angle = 0): LDS / L2, with 16 and 8 lanes per ray, and the
+# lane-per-ray kernel from LDS / L2
+IMAGE_FORMS = ("NFA_SPLIT_L2=0,NFA_SPLIT_P=16", "NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_L2=0,NFA_SPLIT_P=8", "NFA_SPLIT_L2=1,NFA_SPLIT_P=8",
+               "NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_COUNT_L2=1,NFA_SPLIT_P=1")
+EMIT_FORMS = ("rays", "samples")     # NFA_EMIT: 16 lanes per ray walking its run records / a lane per sample with searches
 SEGMENT_FORMS = ("1", "0")
 SEG_P_FORMS = ("8", "32")        # NFA_SEG_P: one lane per level segment / four (parts), cone_angle = 0, up to 4 levels
 CONE_FORMS = ("1", "0")          # NFA_CONE: lane-per-segment walk + serial chain (cone_walk.hpp) / the general lane-per-ray kernel

@@ -131,7 +131,7 @@ def test_many_transitions_overflow_paths():
 
 
 def test_randomised_fuzz_time_boxed():
-    """A fresh seed from the clock on every run (printed on failure; NFA_FUZZ_SEED replays it), ~18 s of the long campaigns'
+    """A fresh seed from the clock on every run (printed on failure; NFA_FUZZ_SEED replays it), ~24 s of the long campaigns'
     generators (tests/fuzz_cases.py): one-level grids under every lanes-per-ray form of the count pass, several levels under
     both count passes with and without a cone angle, and the reference-API call with per-voxel mode / step limits /
     over-allocation / ray masks — HIP vs oracle, bit for bit."""
@@ -141,13 +141,17 @@ def test_randomised_fuzz_time_boxed():
     import fuzz_cases as F
 
     seed = int(os.environ.get("NFA_FUZZ_SEED", time.time_ns() % (1 << 31)))
-    budget = float(os.environ.get("NFA_FUZZ_SECONDS", 18.0))
+    budget = float(os.environ.get("NFA_FUZZ_SECONDS", 24.0))
     g = np.random.default_rng(seed)
     bad, total, cases = [], 0, 0
     t0 = time.time()
     while time.time() - t0 < budget and not bad:
-        which = cases % 7
-        if which == 6:      # ... under every lanes-per-ray form of the two-phase kernel
+        which = cases % 9
+        if which == 8:      # both emit kernels, with and without a cone angle
+            b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000), cones=(0.0, 0.004, 0.3)), "NFA_EMIT", F.EMIT_FORMS)
+        elif which == 7:      # one level, grid image read from LDS / L2 / L2 + staged bitmap
+            b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000)), None, F.IMAGE_FORMS)
+        elif which == 6:      # ... under every lanes-per-ray form of the two-phase kernel
             b, k = F.check_fused(F.fused_levels_case(g, ray_counts=(1, 64, 700, 2048), cones=(0.004, 0.02, 0.1)), "NFA_CONE_P", F.CONE_P_FORMS)
         elif which == 4:    # (renumbered below)
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 64, 500, 3000), cones=(0.004, 0.05)), "NFA_CONE", F.CONE_FORMS)

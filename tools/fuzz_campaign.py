@@ -20,12 +20,20 @@ for case in range(n_cases):
     bad += len(b); total += n
     for line in b:
         print("MISMATCH", f"case {case}", line, flush=True)
+    b, n = F.check_fused(F.fused_single_case(np.random.default_rng(seed0 * 100003 + case + 31)), None, F.IMAGE_FORMS)
+    bad += len(b); total += n
+    for line in b:
+        print("MISMATCH (image)", f"case {case}", line, flush=True)
+    b, n = F.check_fused(F.fused_single_case(np.random.default_rng(seed0 * 100003 + case + 53), cones=(0.0, 0.0, 0.004, 0.3)), "NFA_EMIT", F.EMIT_FORMS)
+    bad += len(b); total += n
+    for line in b:
+        print("MISMATCH (emit)", f"case {case}", line, flush=True)
     if case % 3 == 0:      # one level with a cone angle: the two-phase kernel with a lane per ray vs the general kernel
         b, n = F.check_fused(F.fused_single_case(np.random.default_rng(seed0 * 100003 + case + 77), cones=(0.004, 0.05, 0.3)), "NFA_CONE", F.CONE_FORMS)
         bad += len(b); total += n
         for line in b:
             print("MISMATCH (cone)", f"case {case}", line, flush=True)
-print(f"{n_cases} cases x 6 lane settings ({total} oracle samples in total), {bad} mismatches, {time.time() - t_begin:.0f} s")
+print(f"{n_cases} cases x (6 lane settings + 6 image placements + 2 emit kernels) ({total} oracle samples in total), {bad} mismatches, {time.time() - t_begin:.0f} s")
 bad2 = tot2 = 0
 t_begin = time.time()
 for case in range(n_cases // 4):

@@ -38,7 +38,8 @@ wall = (time.perf_counter() - t0) / reps
 summ = timer.summary()
 _backend.set_kernel_timer(None)
 print(f"rays {O.shape[0]} candidates {ri.shape[0]} occupied {binaries.float().mean().item():.4f}  "
-      f"count {summ['traverse_count'][1]*1e3:.1f} us  emit {summ['traverse_fill'][1]*1e3:.1f} us  call wall {wall*1e6:.1f} us")
+      f"count {summ['traverse_count'][1]*1e3:.1f} us  emit {summ['traverse_fill'][1]*1e3:.1f} us  call wall {wall*1e6:.1f} us  "
+      f"sums {int(ri.sum())} {float(ts.double().sum()):.9e} {float(te.double().sum()):.9e}")
 if "--check" in sys.argv:
     import oracle
     near = (st["jitter"] * np.float32(step)).astype(np.float32)
