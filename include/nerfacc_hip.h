@@ -331,6 +331,18 @@ int nfa_importance_sampling(const nfa_ray_segments *segments, const float *cdfs,
  * query and absolute positions in key.vals for a flattened one, as in the reference. */
 int nfa_searchsorted(const nfa_ray_segments *query, const nfa_ray_segments *key,
                      int64_t *ids_left, int64_t *ids_right, void *stream);
+/* PropNetEstimator's map from normalised s in [0,1] to ray distance (prop_net.py:215-229, `_transform_stot`):
+ * uniform (lindisp = 0): s t_max + (1 - s) t_min;  lindisp: 1 / (s / t_max + (1 - s) / t_min) — the reference's float
+ * operations in the reference's order, one launch.  s_vals, t_vals: [n]. */
+int nfa_transform_stot(const float *s_vals, int64_t n, float t_min, float t_max, int32_t lindisp, float *t_vals, void *stream);
+/* cdf at the n_samples + 1 edges of a proposal level from its densities, batched layout (prop_net.py:99-112:
+ * render_transmittance_from_density, then 1 - cat([trans, 0])): cdfs[r, j] = 1 - exp(-sum_{i<j} sigma_i (t_{i+1} - t_i)) for
+ * j < n_samples, cdfs[r, n_samples] = 1.  t_edges, cdfs: [n_rays, n_samples + 1]; sigmas, trans (nullable; what the backward
+ * reads): [n_rays, n_samples].  The backward returns d loss / d sigmas from d loss / d cdfs. */
+int nfa_edge_cdfs_fwd(const float *t_edges, const float *sigmas, int64_t n_rays, int64_t n_samples, float *cdfs, float *trans,
+                      void *stream);
+int nfa_edge_cdfs_bwd(const float *t_edges, const float *trans, const float *g_cdfs, int64_t n_rays, int64_t n_samples,
+                      float *g_sigmas, void *stream);
 
 #ifdef __cplusplus
 }

@@ -217,9 +217,6 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
             const bool store_runs = rs.t0 != nullptr;
             const bool fast_chain = near >= 0.0f && cone >= 0.0f && step_size >= 1.0e-30f;     // t >= near; halves of dt are exact
             unsigned long long rem = live_lists;
-#if defined(NFA_CONE_DBG) && NFA_CONE_DBG == 1
-            rem = 0ull;
-#endif
             int last_slot = -1;
             while (rem != 0ull && !dead) {
                 const int sg = __ffsll((long long)rem) - 1;          // the next lane with records: parts of a segment in order, segments in order

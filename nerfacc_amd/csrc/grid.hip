@@ -2223,8 +2223,7 @@ inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
 static int cone_lanes_per_ray(const nfa_traverse_args *a) {
     if (!(a->step_size > 0.0f) || a->cone_angle == 0.0f) return 0;
     if (a->t_sorted || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
-    int64_t max_rays = 32768;       // beyond, a lane per ray fills the chip (and the voxel planes grow with the ray count)
-    if (const char *e = getenv("NFA_CONE_MAX_RAYS")) max_rays = atoll(e);
+    const int64_t max_rays = 32768;       // beyond, a lane per ray fills the chip (and the voxel planes grow with the ray count)
     if (const char *e = getenv("NFA_CONE")) { if (atoi(e) == 0) return 0; }
     if (a->n_rays > max_rays) return 0;
     if (a->workspace_bytes < ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a)) return 0;
@@ -2392,7 +2391,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 struct SplitPlan { int P, cap, lds, blk, xt, seg, l2; GridView gv; };
 // several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
 // with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
-// 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off, NFA_SEGMENTS_MAX_RAYS moves the limit
+// 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off
 // crossing-time arrays of the segment kernel's parts: one (rx + ry + rz + 3)-float array per segment slot, 8 slots per ray
 inline int64_t seg_parts_bytes(const nfa_traverse_args *a) {
     return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / 32) * (kBlock / 4) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 3) * 4 + 256;
@@ -2401,8 +2400,7 @@ static int64_t seg_parts_bytes_fwd(const nfa_traverse_args *a) { return seg_part
 static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     if (!lattice || a->t_sorted || a->n_grids < 2 || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
-    int64_t max_rays = 24576;
-    if (const char *e = getenv("NFA_SEGMENTS_MAX_RAYS")) max_rays = atoll(e);
+    const int64_t max_rays = 24576;
     if (const char *e = getenv("NFA_SEGMENTS")) { if (atoi(e) == 0) return 0; }
     if (a->n_rays > max_rays) return 0;
     int P = 2 * a->n_grids - 1 <= 8 ? 8 : 16;
@@ -2476,6 +2474,7 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     // NFA_SPLIT_L2 = 0 | 1 overrides
     bool l2 = a->n_rays > 8192;
     if (const char *e = getenv("NFA_SPLIT_L2")) l2 = atoi(e) != 0;
+    if (p.P == 8) l2 = true;                       // (no 8-lane instance with the image in LDS any more: it never wins)
     if (l2) {
         p.l2 = 1;
         p.blk = kBlock;
@@ -2507,7 +2506,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         vs.rec = (uint32_t *)((uint8_t *)workspace + ws_voxels_offset(a->n_rays));
         vs.cap = a->res[0] + a->res[1] + a->res[2];
         vs.xt = nullptr;
-        if (P >= 32 && !getenv("NFA_CONE_NO_PARTS"))
+        if (P >= 32)
             vs.xt = (float *)((uint8_t *)vs.rec + ((nbs * (int64_t)(vs.cap + VoxelStore::kSlack) * kBlock * 4 + 255) & ~255ll));
 #define NFA_LAUNCH_CONE(LDSO, PP)                                                                                               \
     do {                                                                                                                       \
@@ -2551,7 +2550,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ) {
-            if (P == 8) NFA_LAUNCH_SPLIT(true, 8, 16); else NFA_LAUNCH_SPLIT(true, 16, 16);
+            NFA_LAUNCH_SPLIT(true, 16, 16);
         } else {
             if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 32); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 32);
             else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 32); else NFA_LAUNCH_SPLIT(false, 16, 32);

@@ -105,10 +105,108 @@ int check_segments(const nfa_ray_segments *s, const char *who) {
     return NFA_OK;
 }
 
+// normalised s in [0, 1] -> ray distance t (prop_net.py:215-229): the reference's torch expressions, operation for operation
+// (no contraction: the Makefile builds with -ffp-contract=off), in one launch instead of five
+//   uniform:  s * t_max + (1 - s) * t_min           lindisp:  1 / (s * (1 / t_max) + (1 - s) * (1 / t_min))
+__global__ __launch_bounds__(kBlock) void transform_stot_kernel(const float *__restrict__ s, int64_t n, float c_max, float c_min,
+                                                                int lindisp, float *__restrict__ t)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float v = s[i];
+        const float r = v * c_max + (1.0f - v) * c_min;
+        t[i] = lindisp ? 1.0f / r : r;
+    }
+}
+
+// cdf at the n + 1 edges of a proposal level from the level's densities (prop_net.py:99-112: render_transmittance_from_density on
+// batched tensors — sigma * (t_end - t_start), exclusive cumsum, exp(-.) — then 1 - cat([trans, 0])): one wave per ray, 64
+// samples per trip, the DPP wave scan of common.hpp with a carry.  The reference spends ~13 elementwise launches + a cumsum on it
+// per level (and as many in backward), each launch-bound at 4096 x 256.  `trans` (optional) is what the backward needs.
+__global__ __launch_bounds__(kBlock) void edge_cdfs_fwd_kernel(const float *__restrict__ t_edges, const float *__restrict__ sigmas,
+                                                               int64_t n_rays, int64_t S, float *__restrict__ cdfs, float *__restrict__ trans)
+{
+    const int lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n_rays; row += (int64_t)gridDim.x * kWavesPerBlock) {
+        const float *t = t_edges + row * (S + 1);
+        const float *sg = sigmas + row * S;
+        float carry = 0.0f;
+        for (int64_t c = 0; c < S; c += 64) {
+            const int64_t j = c + lane;
+            const float x = j < S ? sg[j] * (t[j + 1] - t[j]) : 0.0f;
+            const float incl = wave_seg_scan_fwd<OpSum>(x, lane);
+            float before = lane_prev_f(incl, 0.0f);                  // (no incl - x: x may be inf, the opaque last sample)
+            before = carry + (lane == 0 ? 0.0f : before);
+            carry = carry + readlane_f<63>(incl);
+            if (j < S) {
+                const float T = expf(-before);
+                cdfs[row * (S + 1) + j] = 1.0f - T;
+                if (trans) trans[row * S + j] = T;
+            }
+        }
+        if (lane == 0) cdfs[row * (S + 1) + S] = 1.0f;
+    }
+}
+
+// g_sigma_i = (t_{i+1} - t_i) * sum_{i < j < S} g_cdfs_j T_j   (cdfs_j = 1 - T_j, T_j = exp(-sum_{i<j} sigma_i delta_i); the last edge
+// is the constant 1)
+__global__ __launch_bounds__(kBlock) void edge_cdfs_bwd_kernel(const float *__restrict__ t_edges, const float *__restrict__ trans,
+                                                               const float *__restrict__ g_cdfs, int64_t n_rays, int64_t S,
+                                                               float *__restrict__ g_sigmas)
+{
+    const int lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n_rays; row += (int64_t)gridDim.x * kWavesPerBlock) {
+        const float *t = t_edges + row * (S + 1);
+        float carry = 0.0f;
+        for (int64_t c = ((S - 1) / 64) * 64; c >= 0; c -= 64) {
+            const int64_t j = c + lane;
+            const float y = j < S ? g_cdfs[row * (S + 1) + j] * trans[row * S + j] : 0.0f;
+            const float incl = wave_seg_scan_bwd<OpSum>(y, 63 - lane);          // sum over lanes >= this one
+            float after = lane_next_f(incl, 0.0f);
+            after = (lane == 63 ? 0.0f : after) + carry;
+            carry = carry + readlane_f<0>(incl);
+            if (j < S) g_sigmas[row * S + j] = (t[j + 1] - t[j]) * after;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace nfa
 
 using namespace nfa;
+
+NFA_EXPORT int nfa_edge_cdfs_fwd(const float *t_edges, const float *sigmas, int64_t n_rays, int64_t n_samples, float *cdfs, float *trans,
+                                 void *stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_samples >= 1, "edge_cdfs_fwd: n_rays < 0 or n_samples < 1");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(t_edges && sigmas && cdfs, "edge_cdfs_fwd: NULL pointer");
+    hipLaunchKernelGGL(edge_cdfs_fwd_kernel, dim3(blocks_for(n_rays * kWave)), dim3(kBlock), 0, (hipStream_t)stream, t_edges, sigmas, n_rays,
+                       n_samples, cdfs, trans);
+    return check_launch("edge_cdfs_fwd_kernel");
+}
+
+NFA_EXPORT int nfa_edge_cdfs_bwd(const float *t_edges, const float *trans, const float *g_cdfs, int64_t n_rays, int64_t n_samples,
+                                 float *g_sigmas, void *stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_samples >= 1, "edge_cdfs_bwd: n_rays < 0 or n_samples < 1");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(t_edges && trans && g_cdfs && g_sigmas, "edge_cdfs_bwd: NULL pointer");
+    hipLaunchKernelGGL(edge_cdfs_bwd_kernel, dim3(blocks_for(n_rays * kWave)), dim3(kBlock), 0, (hipStream_t)stream, t_edges, trans, g_cdfs,
+                       n_rays, n_samples, g_sigmas);
+    return check_launch("edge_cdfs_bwd_kernel");
+}
+
+NFA_EXPORT int nfa_transform_stot(const float *s_vals, int64_t n, float t_min, float t_max, int32_t lindisp, float *t_vals, void *stream)
+{
+    NFA_REQUIRE(n >= 0, "transform_stot: n < 0");
+    if (n == 0) return NFA_OK;
+    NFA_REQUIRE(s_vals && t_vals, "transform_stot: NULL pointer");
+    // (the scalars as torch forms them: 1 / t in double, then rounded to float when it meets the float tensor)
+    const float c_max = lindisp ? (float)(1.0 / (double)t_max) : t_max, c_min = lindisp ? (float)(1.0 / (double)t_min) : t_min;
+    hipLaunchKernelGGL(transform_stot_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, s_vals, n, c_max, c_min,
+                       (int)lindisp, t_vals);
+    return check_launch("transform_stot_kernel");
+}
 
 NFA_EXPORT int nfa_importance_sampling(const nfa_ray_segments *segments, const float *cdfs, int64_t n_intervals,
                                        const float *jitter, float *out_edges, float *out_mids, void *stream)

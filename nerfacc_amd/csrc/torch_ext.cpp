@@ -668,6 +668,42 @@ std::vector<Tensor> searchsorted(const RaySegmentsSpec &query, const RaySegments
     return {l, r};
 }
 
+Tensor transform_stot(const Tensor &s_vals, double t_min, double t_max, bool lindisp) {
+    check_input(s_vals, "s_vals", at::kFloat);
+    Tensor t = at::empty_like(s_vals);
+    Guard g(device_of(s_vals));
+    // (the reference's scalars are Python floats: 1 / t is formed in double inside the library call)
+    check_rc(nfa_transform_stot(ptr<float>(s_vals), s_vals.numel(), (float)t_min, (float)t_max, lindisp ? 1 : 0, ptr<float>(t), stream_of(s_vals)));
+    return t;
+}
+
+// (cdfs [R, S + 1], trans [R, S] or undefined)
+std::vector<Tensor> edge_cdfs_fwd(const Tensor &t_edges, const Tensor &sigmas, bool want_trans) {
+    check_input(t_edges, "t_edges", at::kFloat);
+    check_input(sigmas, "sigmas", at::kFloat);
+    TORCH_CHECK(sigmas.dim() == 2 && t_edges.dim() == 2 && t_edges.size(0) == sigmas.size(0) && t_edges.size(1) == sigmas.size(1) + 1 &&
+                sigmas.size(1) >= 1 && t_edges.device() == sigmas.device(), "edge_cdfs: t_edges must be [n_rays, n + 1] and sigmas [n_rays, n]");
+    Tensor cdfs = at::empty_like(t_edges), trans;
+    if (want_trans) trans = at::empty_like(sigmas);
+    Guard g(device_of(sigmas));
+    check_rc(nfa_edge_cdfs_fwd(ptr<float>(t_edges), ptr<float>(sigmas), sigmas.size(0), sigmas.size(1), ptr<float>(cdfs), ptr<float>(trans),
+                               stream_of(sigmas)));
+    return {cdfs, trans};
+}
+
+Tensor edge_cdfs_bwd(const Tensor &t_edges, const Tensor &trans, const Tensor &g_cdfs) {
+    check_input(t_edges, "t_edges", at::kFloat);
+    check_input(trans, "trans", at::kFloat);
+    check_input(g_cdfs, "g_cdfs", at::kFloat);
+    TORCH_CHECK(trans.dim() == 2 && t_edges.dim() == 2 && t_edges.size(0) == trans.size(0) && t_edges.size(1) == trans.size(1) + 1 &&
+                g_cdfs.sizes() == t_edges.sizes(), "edge_cdfs_bwd: shape mismatch");
+    Tensor g_sig = at::empty_like(trans);
+    Guard g(device_of(trans));
+    check_rc(nfa_edge_cdfs_bwd(ptr<float>(t_edges), ptr<float>(trans), ptr<float>(g_cdfs), trans.size(0), trans.size(1), ptr<float>(g_sig),
+                               stream_of(trans)));
+    return g_sig;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // pack / rendering (fused entry points: chains of ATen ops in the reference)
 // ---------------------------------------------------------------------------------------------------
@@ -1067,6 +1103,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("_keyed", &scan_keyed);
     m.def("importance_sampling", &importance_sampling);
     m.def("searchsorted", &searchsorted);
+    m.def("transform_stot", &transform_stot, "s_vals"_a, "t_min"_a, "t_max"_a, "lindisp"_a);
+    m.def("edge_cdfs_fwd", &edge_cdfs_fwd, "t_edges"_a, "sigmas"_a, "want_trans"_a);
+    m.def("edge_cdfs_bwd", &edge_cdfs_bwd, "t_edges"_a, "trans"_a, "g_cdfs"_a);
     m.def("opencv_lens_undistortion", [](py::args, py::kwargs) {
         raise_not_implemented("camera undistortion (camera.cu) is outside the OccGrid hot path and not built"); });
     m.def("opencv_lens_undistortion_fisheye", [](py::args, py::kwargs) {

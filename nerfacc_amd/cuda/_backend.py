@@ -98,6 +98,9 @@ _SIGNATURES = {
     "nfa_rendering_bwd": (ctypes.c_int, [_P] * 10 + [c_int64, c_int64, _P, c_int32] + [_P] * 9),
     "nfa_importance_sampling": (ctypes.c_int, [ctypes.POINTER(_RaySegments), _P, c_int64, _P, _P, _P, _P]),
     "nfa_searchsorted": (ctypes.c_int, [ctypes.POINTER(_RaySegments), ctypes.POINTER(_RaySegments), _P, _P, _P]),
+    "nfa_transform_stot": (ctypes.c_int, [_P, c_int64, c_float, c_float, c_int32, _P, _P]),
+    "nfa_edge_cdfs_fwd": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
+    "nfa_edge_cdfs_bwd": (ctypes.c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -675,6 +678,40 @@ class _CtypesC:
             _check(load_library().nfa_searchsorted(ctypes.byref(q), ctypes.byref(k), _ptr(ids_left), _ptr(ids_right),
                                                    _stream(query.vals)))
         return [ids_left, ids_right]
+
+    @staticmethod
+    def transform_stot(s_vals, t_min: float, t_max: float, lindisp: bool):
+        """prop_net.py:215-229 in one launch (nfa_transform_stot)."""
+        _check_input(s_vals, "s_vals", torch.float32)
+        t = torch.empty_like(s_vals)
+        with _Guard(s_vals):
+            _check(load_library().nfa_transform_stot(_ptr(s_vals), s_vals.numel(), t_min, t_max, int(lindisp), _ptr(t), _stream(s_vals)))
+        return t
+
+    @staticmethod
+    def edge_cdfs_fwd(t_edges, sigmas, want_trans: bool):
+        """(cdfs [R, S + 1], trans [R, S] or None): nfa_edge_cdfs_fwd"""
+        _check_input(t_edges, "t_edges", torch.float32)
+        _check_input(sigmas, "sigmas", torch.float32)
+        if not (sigmas.dim() == 2 and t_edges.dim() == 2 and t_edges.shape[0] == sigmas.shape[0] and t_edges.shape[1] == sigmas.shape[1] + 1
+                and sigmas.shape[1] >= 1):
+            raise RuntimeError("edge_cdfs: t_edges must be [n_rays, n + 1] and sigmas [n_rays, n]")
+        cdfs = torch.empty_like(t_edges)
+        trans = torch.empty_like(sigmas) if want_trans else None
+        with _Guard(sigmas):
+            _check(load_library().nfa_edge_cdfs_fwd(_ptr(t_edges), _ptr(sigmas), sigmas.shape[0], sigmas.shape[1], _ptr(cdfs), _ptr(trans),
+                                                    _stream(sigmas)))
+        return [cdfs, trans]
+
+    @staticmethod
+    def edge_cdfs_bwd(t_edges, trans, g_cdfs):
+        for t, nm in ((t_edges, "t_edges"), (trans, "trans"), (g_cdfs, "g_cdfs")):
+            _check_input(t, nm, torch.float32)
+        g_sig = torch.empty_like(trans)
+        with _Guard(trans):
+            _check(load_library().nfa_edge_cdfs_bwd(_ptr(t_edges), _ptr(trans), _ptr(g_cdfs), trans.shape[0], trans.shape[1], _ptr(g_sig),
+                                                    _stream(trans)))
+        return g_sig
 
     # ---------------------------------------------------------------- camera (out of scope, SURVEY.md 2a)
     @staticmethod

@@ -13,6 +13,7 @@ except ImportError:  # pragma: no cover
 import torch
 from torch import Tensor
 
+from .. import cuda as _C
 from ..data_specs import RayIntervals
 from ..pdf import importance_sampling, searchsorted
 from ..volrend import render_transmittance_from_density
@@ -22,6 +23,34 @@ from .base import AbstractEstimator
 def _edge_cdfs(trans: Tensor) -> Tensor:
     """cdf at the n+1 interval edges from the transmittance at the n interval starts."""
     return 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=-1)
+
+
+class _EdgeCdfs(torch.autograd.Function):
+    """cdfs at a level's n + 1 edges from its densities in one kernel (pdf.hip: edge_cdfs_*): render_transmittance_from_density +
+    `_edge_cdfs` of the reference (prop_net.py:99-112), differentiable in sigmas"""
+
+    @staticmethod
+    def forward(ctx, t_edges, sigmas):
+        t_edges, sigmas = t_edges.contiguous(), sigmas.contiguous()
+        need = ctx.needs_input_grad[1]
+        cdfs, trans = _C.edge_cdfs_fwd(t_edges, sigmas, need)
+        if need:
+            ctx.save_for_backward(t_edges, trans)
+        return cdfs
+
+    @staticmethod
+    def backward(ctx, g_cdfs):
+        t_edges, trans = ctx.saved_tensors
+        return None, _C.edge_cdfs_bwd(t_edges, trans, g_cdfs.contiguous())
+
+
+def _level_cdfs(t_vals: Tensor, sigmas: Tensor) -> Tensor:
+    """cdf at the edges t_vals (n_rays, n + 1) of a proposal level with densities sigmas (n_rays, n)"""
+    if sigmas.is_cuda and sigmas.dtype == torch.float32 and t_vals.dtype == torch.float32 and sigmas.dim() == 2 \
+            and sigmas.shape[-1] >= 1 and not (torch.is_grad_enabled() and t_vals.requires_grad):
+        return _EdgeCdfs.apply(t_vals, sigmas)
+    trans, _ = render_transmittance_from_density(t_vals[..., :-1], t_vals[..., 1:], sigmas)
+    return _edge_cdfs(trans)
 
 
 class PropNetEstimator(AbstractEstimator):
@@ -60,8 +89,7 @@ class PropNetEstimator(AbstractEstimator):
             with torch.set_grad_enabled(requires_grad):
                 sigmas = level_fn(t_starts, t_ends)
                 assert sigmas.shape == t_starts.shape
-                trans, _ = render_transmittance_from_density(t_starts, t_ends, sigmas)
-                cdfs = _edge_cdfs(trans)
+                cdfs = _level_cdfs(t_vals, sigmas)
                 if requires_grad:
                     self.prop_cache.append((intervals, cdfs))
 
@@ -127,6 +155,11 @@ def get_proposal_requires_grad_fn(target: float = 5.0, num_steps: int = 1000) ->
 
 def _transform_stot(transform_type: Literal["uniform", "lindisp"], s_vals: torch.Tensor, t_min, t_max) -> torch.Tensor:
     """Map normalised s in [0,1] to ray distance t, linearly in t ("uniform") or in 1/t ("lindisp")."""
+    if transform_type in ("uniform", "lindisp") and s_vals.is_cuda and s_vals.dtype == torch.float32 \
+            and isinstance(t_min, (int, float)) and isinstance(t_max, (int, float)) \
+            and not (torch.is_grad_enabled() and s_vals.requires_grad):
+        # the same float operations in one launch (nfa_transform_stot) instead of five elementwise ones
+        return _C.transform_stot(s_vals.contiguous(), float(t_min), float(t_max), transform_type == "lindisp")
     if transform_type == "uniform":
         return s_vals * t_max + (1 - s_vals) * t_min
     if transform_type == "lindisp":

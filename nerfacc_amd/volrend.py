@@ -38,6 +38,31 @@ def _needs_torch_composition(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+# Batched inputs (n_rays, n_samples) are the flattened layout with a constant number of samples per ray: on the GPU they take
+# the same fused kernels, keyed by a cached arange(n_rays).repeat_interleave(n_samples) — the reference composes them from
+# ~10 (transmittance) to ~25 (rendering) elementwise launches + torch.cumsum per call (volrend.py:270-278), and as many again
+# in backward; at PropNet's sizes (4096 x 256 / 96 / 48) every one of them is launch-bound.
+_DENSE_KEYS = {}
+
+
+def _dense_keys(rows: int, n: int, device) -> Tensor:
+    key = (rows, n, device)
+    keys = _DENSE_KEYS.get(key)
+    if keys is None:
+        if len(_DENSE_KEYS) >= 16:
+            _DENSE_KEYS.clear()
+        keys = torch.arange(rows, device=device, dtype=torch.int64).repeat_interleave(n)
+        _DENSE_KEYS[key] = keys
+    return keys
+
+
+def _dense_native(ref: Tensor, *others) -> bool:
+    """batched CUDA float32 tensors of one shape (None entries skipped): the fused kernels apply"""
+    if not (ref.is_cuda and ref.dim() >= 2 and ref.numel() > 0 and ref.dtype == torch.float32):
+        return False
+    return all(t is None or (t.shape == ref.shape and t.dtype == torch.float32 and t.is_cuda) for t in others)
+
+
 def _density_composition(t_starts, t_ends, sigmas, packed_info, ray_indices, prefix_trans):
     """volrend.py:266-278 as differentiable ops (keyed / packed exclusive sum from scan.py)"""
     sigmas_dt = sigmas * (t_ends - t_starts)
@@ -149,6 +174,22 @@ def rendering(
         rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
         assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
         assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+        dense = ray_indices is None and _dense_native(sigmas, t_starts, t_ends) and rgbs.is_cuda and rgbs.dtype == torch.float32 \
+            and rgbs.shape[:-1] == sigmas.shape and sigmas.dim() == 2
+        if dense and not _needs_torch_composition(t_starts, t_ends):
+            # batched (n_rays, n_samples): the flattened fused kernel with cached keys (see _dense_keys)
+            R_, S_ = sigmas.shape
+            fused_bkgd = render_bkgd is not None and render_bkgd.numel() == 3 and not render_bkgd.requires_grad
+            from .cuda import _backend
+            render = getattr(_backend._C, "rendering", None) or _Rendering.apply
+            colors, opacities, depths, weights, trans, alphas = render(
+                _dense_keys(R_, S_, sigmas.device), t_starts.reshape(-1), t_ends.reshape(-1), sigmas.reshape(-1), rgbs.reshape(-1, 3), R_,
+                render_bkgd.reshape(3) if fused_bkgd else None, bool(expected_depths))
+            extras = {"weights": weights.reshape(R_, S_), "alphas": alphas.reshape(R_, S_), "trans": trans.reshape(R_, S_),
+                      "sigmas": sigmas, "rgbs": rgbs}
+            if render_bkgd is not None and not fused_bkgd:
+                colors = colors + render_bkgd * (1.0 - opacities)          # volrend.py:161-162
+            return colors, opacities, depths, extras
         if ray_indices is not None and not _needs_torch_composition(t_starts, t_ends):
             assert n_rays is not None, "n_rays must be provided"
             # the kernel blends ONE background colour; anything else the reference's broadcast accepts
@@ -209,6 +250,12 @@ def render_transmittance_from_density(
     """T_i = exp(-sum_{j<i} sigma_j delta_j) and alpha_i = 1 - exp(-sigma_i delta_i)
     (volrend.py:219-278).  Returns (trans, alphas)."""
     if packed_info is None and ray_indices is None:
+        if _dense_native(sigmas, t_starts, t_ends, prefix_trans) and not _needs_torch_composition(t_starts, t_ends, prefix_trans):
+            shape = sigmas.shape
+            keys = _dense_keys(sigmas.numel() // shape[-1], shape[-1], sigmas.device)
+            _, trans, alphas = _WeightFromDensity.apply(keys, t_starts.reshape(-1), t_ends.reshape(-1), sigmas.reshape(-1),
+                                                        None if prefix_trans is None else prefix_trans.reshape(-1))
+            return trans.reshape(shape), alphas.reshape(shape)
         sigmas_dt = sigmas * (t_ends - t_starts)
         alphas = 1.0 - torch.exp(-sigmas_dt)
         trans = torch.exp(-exclusive_sum(sigmas_dt))
@@ -245,6 +292,12 @@ def render_weight_from_density(
         weights: [0.33, 0.37, 0.03, 0.55, 0.04, 0.00, 0.59]
     """
     if packed_info is None and ray_indices is None:
+        if _dense_native(sigmas, t_starts, t_ends, prefix_trans) and not _needs_torch_composition(t_starts, t_ends, prefix_trans):
+            shape = sigmas.shape
+            keys = _dense_keys(sigmas.numel() // shape[-1], shape[-1], sigmas.device)
+            w, trans, alphas = _WeightFromDensity.apply(keys, t_starts.reshape(-1), t_ends.reshape(-1), sigmas.reshape(-1),
+                                                        None if prefix_trans is None else prefix_trans.reshape(-1))
+            return w.reshape(shape), trans.reshape(shape), alphas.reshape(shape)
         trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, prefix_trans=prefix_trans)
         return trans * alphas, trans, alphas
     if _needs_torch_composition(t_starts, t_ends, prefix_trans):

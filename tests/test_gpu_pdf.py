@@ -94,3 +94,51 @@ def test_pdf_loss_and_propnet_sampling():
     assert (te >= ts).all() and (ts[:, 1:] >= ts[:, :-1] - 1e-6).all() and (ts >= 0.2 - 1e-4).all()
     trans = torch.rand(4096, 48, device=DEV).cumsum(-1).neg().exp()
     assert est.compute_loss(trans).ndim == 0
+
+
+def test_transform_stot_is_the_torch_expression_bit_for_bit():
+    """nfa_transform_stot vs prop_net.py:215-229 written with torch ops: the same float operations in the same order"""
+    from nerfacc_amd.estimators.prop_net import _transform_stot
+
+    s = torch.cat([torch.rand(4096, 257, device=DEV), torch.tensor([[0.0, 1.0] + [0.5] * 255], device=DEV)])
+    for t_min, t_max in ((0.2, 1e3), (2.0, 6.0), (0.05, 1e10)):
+        want_u = s * t_max + (1 - s) * t_min
+        want_l = 1 / (s * (1 / t_max) + (1 - s) * (1 / t_min))
+        assert torch.equal(_transform_stot("uniform", s, t_min, t_max), want_u)
+        assert torch.equal(_transform_stot("lindisp", s, t_min, t_max), want_l)
+    ts = _transform_stot("lindisp", s[:, :-1].transpose(0, 1), 0.2, 1e3)      # a non-contiguous view
+    assert torch.equal(ts, 1 / (s[:, :-1].transpose(0, 1) * (1 / 1e3) + (1 - s[:, :-1].transpose(0, 1)) * (1 / 0.2)))
+
+
+@pytest.mark.parametrize("R,S", [(4096, 256), (4096, 96), (33, 48), (5, 1), (3, 700)])
+def test_level_cdfs_kernel_vs_the_reference_composition(R, S):
+    """pdf.hip's edge_cdfs_* (one launch per proposal level) against render_transmittance_from_density + 1 - cat([trans, 0]) written
+    with torch ops (prop_net.py:99-112): values, the gradient with respect to the densities, an opaque last sample (sigma = inf)"""
+    from nerfacc_amd.estimators.prop_net import _edge_cdfs, _level_cdfs
+
+    torch.manual_seed(R + S)
+    t_vals = torch.sort(torch.rand(R, S + 1, device=DEV) * 5 + 0.1, dim=-1)[0]
+    for opaque in (False, True):
+        sig = (torch.rand(R, S, device=DEV) * 4).requires_grad_(True)
+        sig_ref = sig.detach().clone().requires_grad_(True)
+
+        def bk(x):
+            if not opaque:
+                return x
+            x = x.clone()
+            x[..., -1] = torch.inf
+            return x
+
+        cdfs = _level_cdfs(t_vals, bk(sig))
+        x = bk(sig_ref) * (t_vals[:, 1:] - t_vals[:, :-1])
+        trans = torch.exp(-torch.cumsum(torch.cat([torch.zeros_like(x[:, :1]), x[:, :-1]], -1), -1))
+        want = _edge_cdfs(trans)
+        assert cdfs.shape == (R, S + 1) and torch.equal(cdfs[:, -1], torch.ones(R, device=DEV)) and torch.equal(cdfs[:, 0], torch.zeros(R, device=DEV))
+        assert torch.allclose(cdfs, want, rtol=1e-5, atol=2e-6)
+        coef = torch.randn(R, S + 1, device=DEV)
+        (cdfs * coef).sum().backward()
+        (want * coef).sum().backward()
+        assert torch.isfinite(sig.grad).all()
+        assert torch.allclose(sig.grad, sig_ref.grad, rtol=2e-4, atol=2e-5)
+    with torch.no_grad():                                  # no graph: no `trans` kept
+        assert torch.equal(_level_cdfs(t_vals, sig.detach()), _level_cdfs(t_vals, sig).detach())

@@ -294,3 +294,57 @@ def test_visibility_compact_all_prefix_modes(n_rays):
     want = (T >= 1e-2) & (a >= 0.05)
     near = ((T - 1e-2).abs() < 1e-6) | ((a - 0.05).abs() < 1e-6)
     assert torch.equal(mask[~near], want[~near])
+
+
+@pytest.mark.parametrize("shape", [(4096, 48), (300, 257), (7, 1), (2, 3, 50)])
+def test_batched_inputs_take_the_fused_kernels_and_match_the_torch_composition(shape):
+    """(n_rays, n_samples) tensors (PropNetEstimator's layout) go through the flattened fused kernels with cached keys: values and
+    gradients equal the reference's batched composition (volrend.py:270-278: elementwise ops + cumsum) within float tolerance,
+    with an opaque last sample (sigma = inf, examples/utils.py:215) included"""
+    import nerfacc_amd as nerfacc
+
+    torch.manual_seed(sum(shape))
+    edges = torch.sort(torch.rand(*shape[:-1], shape[-1] + 1, device=DEV) * 4 + 0.2, dim=-1)[0]
+    ts, te = edges[..., :-1], edges[..., 1:]                      # views with a row stride of n + 1, as the estimator hands them over
+    for opaque in (False, True):
+        sig = (torch.rand(*shape, device=DEV) * 3).requires_grad_(True)
+        sig2 = sig.detach().clone().requires_grad_(True)
+
+        def with_bkgd(x):
+            if not opaque:
+                return x
+            x = x.clone()
+            x[..., -1] = torch.inf
+            return x
+
+        w, T, a = nerfacc.render_weight_from_density(ts, te, with_bkgd(sig))
+        x = with_bkgd(sig2) * (te - ts)                              # the reference's composition
+        a_ref = 1.0 - torch.exp(-x)
+        T_ref = torch.exp(-torch.cumsum(torch.cat([torch.zeros_like(x[..., :1]), x[..., :-1]], dim=-1), dim=-1))
+        w_ref = T_ref * a_ref
+        assert w.shape == T.shape == a.shape == tuple(shape)
+        for got, want in ((w, w_ref), (T, T_ref), (a, a_ref)):
+            assert torch.allclose(got, want, rtol=2e-5, atol=1e-6)
+        coef = torch.rand(*shape, device=DEV)
+        (w * coef).sum().backward()
+        (w_ref * coef).sum().backward()
+        assert torch.isfinite(sig.grad).all()
+        assert torch.allclose(sig.grad, sig2.grad, rtol=1e-4, atol=1e-5)
+        T2, a2 = nerfacc.render_transmittance_from_density(ts, te, with_bkgd(sig.detach()))
+        assert torch.equal(T2, T) and torch.equal(a2, a)
+    if len(shape) == 2:                                              # rendering(): batched vs the same samples flattened
+        R, S = shape
+        rgb = torch.rand(R, S, 3, device=DEV, requires_grad=True)
+        sig = (torch.rand(R, S, device=DEV) * 3).requires_grad_(True)
+        bk = torch.tensor([0.2, 0.5, 0.9], device=DEV)
+        c, o, d, ex = nerfacc.rendering(ts, te, rgb_sigma_fn=lambda a_, b_, r_: (rgb, sig), render_bkgd=bk)
+        ri = torch.arange(R, device=DEV).repeat_interleave(S)
+        c2, o2, d2, ex2 = nerfacc.rendering(ts.reshape(-1), te.reshape(-1), ray_indices=ri, n_rays=R,
+                                            rgb_sigma_fn=lambda a_, b_, r_: (rgb.reshape(-1, 3), sig.reshape(-1)), render_bkgd=bk)
+        assert c.shape == (R, 3) and o.shape == (R, 1) and d.shape == (R, 1) and ex["weights"].shape == (R, S) and ex["trans"].shape == (R, S)
+        assert torch.equal(c, c2) and torch.equal(o, o2) and torch.equal(d, d2) and torch.equal(ex["weights"].reshape(-1), ex2["weights"])
+        w_ref = nerfacc.render_weight_from_density(ts, te, sig.detach())[0]
+        assert torch.allclose(c, (w_ref[..., None] * rgb.detach()).sum(-2) + bk * (1 - w_ref.sum(-1, keepdim=True)), rtol=1e-4, atol=1e-5)
+        g1 = torch.autograd.grad(c.square().sum(), (rgb, sig))
+        g2 = torch.autograd.grad(c2.square().sum(), (rgb, sig))
+        assert all(torch.equal(x_, y_) for x_, y_ in zip(g1, g2))
