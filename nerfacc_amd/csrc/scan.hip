@@ -109,32 +109,60 @@ __device__ __forceinline__ void ld4_walk(const float *__restrict__ p, int64_t lo
     }
 }
 
+// `rw` rows per wave and outer trip (4 or 16), one per lane, DEALT to the four 16-lane groups as they finish their rows (round 3):
+// with a fixed row per group the wave's trips were those of its longest row — 2.9 trips per four rows of 0..192 elements against
+// the 2.0 a row needs on average; a group that is done now takes the wave's next non-empty row.  rw grows with the input so that
+// small inputs keep one row per group (a wave per four rows: parallelism first) and the launch always has >= 8 k waves.
+// (Also measured: 64 rows per wave — fewer waves than the chip wants at 2^24 elements; the next trip's loads issued one trip
+// ahead — 36 -> 47 us, the kernel is bound by its instructions, not by bytes in flight: profiles/r03_streaming.md.)
 template <class Op, bool INCL>
 __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
     const int64_t *__restrict__ starts, const int64_t *__restrict__ cnts, int64_t n_rows,
     const float *__restrict__ in, const float *__restrict__ mul, const float *__restrict__ div,
-    float *__restrict__ out, int reverse, int normalize)
+    float *__restrict__ out, int reverse, int normalize, int rw)
 {
-    const int lane = lane_id(), sub = lane & 15;
-    const int64_t rows_per_block = kBlock / 16;
-    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4);
-    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
-    // all four rows of a wave iterate together (the DPP / readlane steps are wave-wide): trips = the longest row
-    for (int64_t rbase = row0 - (lane >> 4); rbase < n_rows; rbase += stride) {
-        const int64_t row = rbase + (lane >> 4);
-        const bool row_ok = row < n_rows;
-        const int64_t start = row_ok ? starts[row] : 0, cnt = row_ok ? cnts[row] : 0;
-        int64_t cmax = cnt;
-        cmax = max(cmax, __shfl_xor(cmax, 16, 64));
-        cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t wb = wave * rw; wb < n_rows; wb += n_waves * rw) {
+        // lane l < rw looks at row wb + l; the non-empty rows are packed into the low lanes (ds_permute: a lane SENDS to its rank;
+        // every lane sends — a lane only receives while it is active: the empty rows go behind the non-empty ones, a permutation)
+        const int64_t my_row = wb + lane;
+        const bool mine = lane < rw && my_row < n_rows;
+        const int64_t my_start = mine ? starts[my_row] : 0, my_cnt = mine ? cnts[my_row] : 0;
+        const unsigned long long ne = __ballot(my_cnt > 0);
+        const int n_ne = __popcll(ne);
+        const int dst4 = (my_cnt > 0 ? __popcll(ne & lanes_lt(lane)) : n_ne + __popcll(~ne & lanes_lt(lane))) * 4;
+        const int s_lo = __builtin_amdgcn_ds_permute(dst4, (int)(my_start & 0xffffffffll));
+        const int s_hi = __builtin_amdgcn_ds_permute(dst4, (int)(my_start >> 32));
+        const int c_lo = __builtin_amdgcn_ds_permute(dst4, (int)(my_cnt & 0xffffffffll));
+        const int c_hi = __builtin_amdgcn_ds_permute(dst4, (int)(my_cnt >> 32));
+        int taken = 0;
+        bool busy = false;
+        int64_t start = 0, cnt = 0, c = 0;
         float carry = Op::identity();
-        for (int64_t c = 0; c < cmax; c += 64) {
+        for (;;) {
+            // deal the next rows to the idle groups, in group order
+            const unsigned long long idle_b = __ballot(!busy);
+            const unsigned idle_g = (unsigned)((idle_b & 1ull) | ((idle_b >> 15) & 2ull) | ((idle_b >> 30) & 4ull) | ((idle_b >> 45) & 8ull));
+            const int k = taken + __popc(idle_g & ((1u << grp) - 1u));
+            const int src = (k < n_ne ? k : 0) * 4;
+            const int a_lo = __builtin_amdgcn_ds_bpermute(src, s_lo), a_hi = __builtin_amdgcn_ds_bpermute(src, s_hi);
+            const int b_lo = __builtin_amdgcn_ds_bpermute(src, c_lo), b_hi = __builtin_amdgcn_ds_bpermute(src, c_hi);
+            if (!busy && k < n_ne) {
+                start = ((int64_t)a_hi << 32) | (uint32_t)a_lo;
+                cnt = ((int64_t)b_hi << 32) | (uint32_t)b_lo;
+                c = 0;
+                carry = Op::identity();
+                busy = true;
+            }
+            taken += __popc(idle_g);
+            if (!__ballot(busy)) break;
             const int64_t k0 = c + 4 * sub;                 // this lane's first element of the trip, in walk order
             bool act[4];
             int64_t idx[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                act[e] = k0 + e < cnt;
+                act[e] = busy && k0 + e < cnt;
                 idx[e] = reverse ? (start + cnt - 1 - (k0 + e)) : (start + k0 + e);
             }
             const bool full = act[3];
@@ -174,15 +202,19 @@ __global__ __launch_bounds__(kBlock) void scan_packed_kernel(
                 for (int e = 0; e < 4; ++e)
                     if (act[e]) out[idx[e]] = r[e];
             }
-        }
-        if (normalize) {  // utils_scan.cuh:101-109 / 228-236: divide by the row total
-            const float den = fmaxf(carry, 1e-10f);
-            for (int64_t c = 0; c < cnt; c += 16) {
-                const int64_t k = c + sub;
-                if (k >= cnt) continue;
-                if (!INCL && k == 0) continue;
-                const int64_t i = reverse ? (start + cnt - 1 - k) : (start + k);
-                out[i] = out[i] / den;
+            c += 64;
+            if (busy && c >= cnt) {                         // this group's row is done
+                if (normalize) {  // utils_scan.cuh:101-109 / 228-236: divide by the row total
+                    const float den = fmaxf(carry, 1e-10f);
+                    for (int64_t q = 0; q < cnt; q += 16) {
+                        const int64_t kk = q + sub;
+                        if (kk >= cnt) continue;
+                        if (!INCL && kk == 0) continue;
+                        const int64_t i = reverse ? (start + cnt - 1 - kk) : (start + kk);
+                        out[i] = out[i] / den;
+                    }
+                }
+                busy = false;
             }
         }
     }
@@ -207,9 +239,12 @@ void launch_keyed(const int64_t *keys, const float *in, const float *mul, const 
 template <class Op, bool INCL>
 void launch_packed(const int64_t *starts, const int64_t *cnts, int64_t n_rows, const float *in,
                    const float *mul, const float *div, float *out, int reverse, int normalize, hipStream_t s) {
-    const unsigned nb = blocks_for(n_rows * 16);
+    // rows per wave: 4 (a row per group) until the launch has ~8 k waves of 16; NFA_SCAN_RW = 4 | 16 overrides
+    int rw = n_rows >= 16 * 8192 ? 16 : 4;
+    if (const char *e = getenv("NFA_SCAN_RW")) { const int v = atoi(e); if (v == 4 || v == 16) rw = v; }
+    const unsigned nb = blocks_for(ceil_div(n_rows, rw) * kWave);
     hipLaunchKernelGGL((scan_packed_kernel<Op, INCL>), dim3(nb), dim3(kBlock), 0, s, starts, cnts, n_rows, in, mul, div, out,
-                       reverse, normalize);
+                       reverse, normalize, rw);
 }
 
 }  // namespace
