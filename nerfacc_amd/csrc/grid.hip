@@ -1798,32 +1798,34 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     __shared__ int64_t base[2];
     const int b = blockIdx.x;
     const bool last = b == (int)gridDim.x - 1;
-    int64_t p0 = 0, p1 = 0;
+    // every load of the kernel is requested up front (the host polls for this kernel's stamp: its last block's chain of
+    // dependent round trips is the sampling call's latency — three of them before, one now)
+    const int64_t r = (int64_t)b * kBlock + threadIdx.x;
+    const bool in = r < n_rays;
+    const int64_t c_iv = (iv_cnts && in) ? iv_cnts[r] : 0;
+    const int64_t c_sm = in ? sm_cnts[r] : 0;
+    int64_t p0 = 0, p1 = 0, ov = 0;
     const int64_t before = (int64_t)b * sums_per_block;
     for (int64_t j = threadIdx.x; j < before; j += kBlock) { p0 += block_sums[3 * j]; p1 += block_sums[3 * j + 1]; }
+    if (last)                                     // rays that need the pass-2 re-traversal
+        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
     int64_t t0, t1;
     block_excl_scan_i64(p0, lds, t0);
     block_excl_scan_i64(p1, lds, t1);
     if (threadIdx.x == 0) { base[0] = t0; base[1] = t1; }
     __syncthreads();
-    const int64_t r = (int64_t)b * kBlock + threadIdx.x;
-    const bool in = r < n_rays;
     int64_t tot;
     if (iv_cnts) {
-        const int64_t c = in ? iv_cnts[r] : 0;
-        const int64_t e = block_excl_scan_i64(c, lds, tot);
+        const int64_t e = block_excl_scan_i64(c_iv, lds, tot);
         if (in) iv_starts[r] = base[0] + e;
         if (last && threadIdx.x == 0) { totals[0] = base[0] + tot; totals_dev[0] = base[0] + tot; }
     } else if (last && threadIdx.x == 0) { totals[0] = 0; totals_dev[0] = 0; }
     {
-        const int64_t c = in ? sm_cnts[r] : 0;
-        const int64_t e = block_excl_scan_i64(c, lds, tot);
+        const int64_t e = block_excl_scan_i64(c_sm, lds, tot);
         if (in) sm_starts[r] = base[1] + e;
         if (last && threadIdx.x == 0) { totals[1] = base[1] + tot; totals_dev[1] = base[1] + tot; }
     }
-    if (last) {                                   // rays that need the pass-2 re-traversal
-        int64_t ov = 0;
-        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
+    if (last) {
         int64_t tov;
         block_excl_scan_i64(ov, lds, tov);
         if (threadIdx.x == 0) {
