@@ -2393,7 +2393,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 struct SplitPlan { int P, cap, lds, blk, xt, seg, l2; GridView gv; };
 // several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
 // with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
-// 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k.  NFA_SEGMENTS = 0 switches it off
+// 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k (count pass alone).  NFA_SEGMENTS = 0 switches it off
 // crossing-time arrays of the segment kernel's parts: one (rx + ry + rz + 3)-float array per segment slot, 8 slots per ray
 inline int64_t seg_parts_bytes(const nfa_traverse_args *a) {
     return ceil_div(a->n_rays > 0 ? a->n_rays : 1, kBlock / 32) * (kBlock / 4) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 3) * 4 + 256;
@@ -2402,7 +2402,7 @@ static int64_t seg_parts_bytes_fwd(const nfa_traverse_args *a) { return seg_part
 static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     if (!lattice || a->t_sorted || a->n_grids < 2 || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
-    const int64_t max_rays = 24576;
+    const int64_t max_rays = 40960;     // (r03: with the ray-group emit pass behind it the call is 213 vs 285 us at 32 k rays, 383 vs 312 at 65 k)
     if (const char *e = getenv("NFA_SEGMENTS")) { if (atoi(e) == 0) return 0; }
     if (a->n_rays > max_rays) return 0;
     int P = 2 * a->n_grids - 1 <= 8 ? 8 : 16;
@@ -2637,12 +2637,13 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     return check_launch("traverse_fill_kernel");
 }
 
-// a lane per sample with searches, or — from 24 k rays — 16 lanes per ray (r03_count_pass.md: below, the batch's longest ray is the
-// ray-group kernel's whole duration: 12.9 vs 7.5 us at 6.5 k rays; 23 vs 25 us at 32 k, 356 vs 655 us at 10^6).
-// NFA_EMIT = rays | samples overrides
-static bool emit_by_rays(int64_t n_rays) {
+// a lane per sample with searches, or — from ~10^6 samples — 16 lanes per ray (r03_count_pass.md: below, the batch's longest ray is
+// the ray-group kernel's whole duration: 12.9 vs 7.5 us at 6.5 k rays x 38 samples; 23 vs 25 us at 32 k rays, 356 vs 655 us at 10^6;
+// 4 x 128^3 with 145 samples per ray: equal at 8 k rays, 126 vs 138 us at 16 k).  `n_samples`: the total, or the speculative
+// launch's capacity (the previous call's total).  NFA_EMIT = rays | samples overrides
+static bool emit_by_rays(int64_t n_samples) {
     if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r';
-    return n_rays >= 24576;
+    return n_samples >= 1100000;
 }
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;
@@ -2665,7 +2666,7 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
-        if (emit_by_rays(a->n_rays)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
+        if (emit_by_rays(n_samples)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         if (int rc = check_launch("traverse_emit_kernel")) return rc;
     }
@@ -2682,7 +2683,7 @@ NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const v
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
-    if (emit_by_rays(a->n_rays)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    if (emit_by_rays(capacity)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
     else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
     return check_launch("traverse_emit_kernel");
 }
