@@ -2641,9 +2641,11 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
 // the ray-group kernel's whole duration: 12.9 vs 7.5 us at 6.5 k rays x 38 samples; 23 vs 25 us at 32 k rays, 356 vs 655 us at 10^6;
 // 4 x 128^3 with 145 samples per ray: equal at 8 k rays, 126 vs 138 us at 16 k).  `n_samples`: the total, or the speculative
 // launch's capacity (the previous call's total).  NFA_EMIT = rays | samples overrides
-static bool emit_by_rays(int64_t n_samples) {
+// With a cone angle always by rays: the sample-parallel form re-runs a sample's chain from its run's start (4 x 128^3, cone 0.004:
+// 16.8 vs 26.0 us at 4 k rays, 22.9 vs 77.4 at 16 k).
+static bool emit_by_rays(const nfa_traverse_args *a, int64_t n_samples) {
     if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r';
-    return n_samples >= 1100000;
+    return a->cone_angle != 0.0f || n_samples >= 1100000;
 }
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;
@@ -2666,7 +2668,7 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
-        if (emit_by_rays(n_samples)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
+        if (emit_by_rays(a, n_samples)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
         if (int rc = check_launch("traverse_emit_kernel")) return rc;
     }
@@ -2683,7 +2685,7 @@ NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const v
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
-    if (emit_by_rays(capacity)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    if (emit_by_rays(a, capacity)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
     else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
     return check_launch("traverse_emit_kernel");
 }
