@@ -49,10 +49,11 @@ def _dense_keys(rows: int, n: int, device) -> Tensor:
     key = (rows, n, device)
     keys = _DENSE_KEYS.get(key)
     if keys is None:
-        if len(_DENSE_KEYS) >= 16:
-            _DENSE_KEYS.clear()
         keys = torch.arange(rows, device=device, dtype=torch.int64).repeat_interleave(n)
-        _DENSE_KEYS[key] = keys
+        if rows * n <= (1 << 22):                 # (cache training-size shapes only: 32 MB per entry at most, eight entries)
+            if len(_DENSE_KEYS) >= 8:
+                _DENSE_KEYS.clear()
+            _DENSE_KEYS[key] = keys
     return keys
 
 
