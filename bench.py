@@ -874,13 +874,15 @@ def main():
         }
         # counter-based figures come from a committed rocprofv3 --pmc run of THIS workload (tools/pmc_bench.py); they are
         # attached only when that run's ray count is within 15 % of this run's
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traverse.json")
-        if os.path.exists(pmc_path):
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traverse.json")))      # the latest round's
+        pmc_path = pmc_files[-1] if pmc_files else ""
+        if pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
                 if abs(pmc["rays_per_launch"] - rays_per_launch) <= 0.15 * rays_per_launch:
                     roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r02_pmc_traverse.json (rocprofv3 --pmc, separate passes; %d rays/launch)" % pmc["rays_per_launch"]
+                    roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, separate passes; %d rays/launch)" % (os.path.basename(pmc_path), pmc["rays_per_launch"])
                     if "issue" in pmc:
                         roof["issue"] = pmc["issue"]
             except Exception:      # noqa: BLE001

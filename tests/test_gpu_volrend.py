@@ -348,3 +348,23 @@ def test_batched_inputs_take_the_fused_kernels_and_match_the_torch_composition(s
         g1 = torch.autograd.grad(c.square().sum(), (rgb, sig))
         g2 = torch.autograd.grad(c2.square().sum(), (rgb, sig))
         assert all(torch.equal(x_, y_) for x_, y_ in zip(g1, g2))
+
+
+def test_batched_gpu_inputs_vs_reference_batched_golden(golden):
+    """(n_rays, n_samples) tensors ON THE GPU (fused kernels with cached keys since round 3) against the outputs of the reference's
+    own batched torch path (tests/golden, generated by importing the reference): weights, gradients, rendering()"""
+    import nerfacc_amd as nerfacc
+
+    g = golden
+    ts, te = t(g["v_ts"]), t(g["v_te"])
+    sig = t(g["v_sig"]).requires_grad_(True)
+    w, T, a = nerfacc.render_weight_from_density(ts, te, sig)
+    assert w.shape == ts.shape and w.is_cuda
+    np.testing.assert_allclose(n(w.detach()), g["v_w"], atol=1e-6)
+    (w * t(g["v_gw"]) + T * t(g["v_gT"]) + a * t(g["v_ga"])).sum().backward()
+    np.testing.assert_allclose(n(sig.grad), g["v_gsig"], atol=1e-5, rtol=1e-5)
+    rgb = t(g["r_rgb"])
+    col, opa, dep, ex = nerfacc.rendering(ts, te, rgb_sigma_fn=lambda *_: (rgb, sig.detach()), render_bkgd=t(g["r_bk"]))
+    np.testing.assert_allclose(n(col), g["r_col"], atol=1e-6)
+    np.testing.assert_allclose(n(dep), g["r_dep"], atol=1e-5)
+    assert ex["weights"].shape == ts.shape and ex["trans"].shape == ts.shape
