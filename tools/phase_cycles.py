@@ -42,8 +42,13 @@ if state:
     aabbs = torch.from_numpy(st["aabbs"]).to(dev)
     pool_o, pool_d = torch.from_numpy(st["rays_o"]).to(dev), torch.from_numpy(st["rays_d"]).to(dev)
     step = float(st["render_step"])
-    n = pool_o.shape[0]
     near = torch.from_numpy(st["jitter"]).to(dev) * step
+    for a_ in sys.argv[1:]:
+        if a_.startswith("--rays="):               # tile / truncate the ray batch (lanes-per-ray regimes beyond the bench's 6.5 k)
+            n_ = int(a_.split("=")[1])
+            rep = -(-n_ // pool_o.shape[0])
+            pool_o, pool_d, near = pool_o.repeat(rep, 1)[:n_].contiguous(), pool_d.repeat(rep, 1)[:n_].contiguous(), near.repeat(rep)[:n_].contiguous()
+    n = pool_o.shape[0]
 elif os.environ.get("NFA_PHASE_WORKLOAD") == "m1-random":      # rand > 0.5 grid, 4096 rays
     import numpy as np
     g = np.random.default_rng(42)
