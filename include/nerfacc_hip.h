@@ -343,6 +343,17 @@ int nfa_edge_cdfs_fwd(const float *t_edges, const float *sigmas, int64_t n_rays,
                       void *stream);
 int nfa_edge_cdfs_bwd(const float *t_edges, const float *trans, const float *g_cdfs, int64_t n_rays, int64_t n_samples,
                       float *g_sigmas, void *stream);
+/* Histogram-envelope loss of a proposal level against the final samples, batched layout (prop_net.py:232-256, `_pdf_loss`):
+ * loss[r, i] = clip(w - w_outer, 0)^2 / (w + eps) with w = cdfs_query[r, i + 1] - cdfs_query[r, i] and w_outer the cdf mass of
+ * the key intervals overlapping query interval i (searchsorted of the query edges in the key edges, pdf.cu:245-286).
+ * query_vals, cdfs_query: [n_rays, n_query + 1]; key_vals, cdfs_key: [n_rays, n_key + 1]; loss: [n_rays, n_query].
+ * ids_left, ids_right (int32, indices into the key row) and coef (d loss / d w_outer): [n_rays, n_query], all three or none —
+ * the backward's inputs; it returns d loss / d cdfs_key [n_rays, n_key + 1] (deterministic: no atomics). */
+int nfa_pdf_loss_fwd(const float *query_vals, const float *cdfs_query, const float *key_vals, const float *cdfs_key,
+                     int64_t n_rays, int64_t n_query, int64_t n_key, float eps, float *loss, int32_t *ids_left,
+                     int32_t *ids_right, float *coef, void *stream);
+int nfa_pdf_loss_bwd(const float *g_loss, const int32_t *ids_left, const int32_t *ids_right, const float *coef,
+                     int64_t n_rays, int64_t n_query, int64_t n_key, float *g_cdfs_key, void *stream);
 
 #ifdef __cplusplus
 }

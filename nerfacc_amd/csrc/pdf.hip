@@ -169,10 +169,93 @@ __global__ __launch_bounds__(kBlock) void edge_cdfs_bwd_kernel(const float *__re
     }
 }
 
+// Histogram-envelope loss of one proposal level, batched layout (prop_net.py:232-256, `_pdf_loss`): searchsorted of the query
+// edges in the key edges, w = cdf mass of the query interval, w_outer = mass of the key intervals that overlap it,
+// loss = clip(w - w_outer, 0)^2 / (w + eps) — the reference's float operations in its order, one lane per query interval, one
+// launch instead of searchsorted + ~10 ATen ops (and ~15 in backward).  il / ir (indices into the key row) and
+// coef = d loss / d w_outer are what the backward reads.
+__global__ __launch_bounds__(kBlock) void pdf_loss_fwd_kernel(const float *__restrict__ q, const float *__restrict__ cq,
+                                                              const float *__restrict__ k, const float *__restrict__ ck,
+                                                              int64_t n_rays, int64_t nq, int64_t nk, float eps,
+                                                              float *__restrict__ loss, int32_t *__restrict__ il, int32_t *__restrict__ ir,
+                                                              float *__restrict__ coef)
+{
+    const int64_t total = n_rays * nq;
+    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * kBlock) {
+        const int64_t ray = tid / nq, i = tid - ray * nq;
+        const float *qr = q + ray * (nq + 1), *cqr = cq + ray * (nq + 1);
+        const int64_t base = ray * (nk + 1), last = base + nk;
+        const int64_t pl = upper_bound_f(k, base, last, qr[i]), pr = upper_bound_f(k, base, last, qr[i + 1]);
+        const int64_t l = clamp64(pl - 1, base, last), r = clamp64(pr, base, last);      // searchsorted_kernel's (left, right)
+        const float w = cqr[i + 1] - cqr[i];
+        const float w_outer = ck[r] - ck[l];
+        const float d = w - w_outer;
+        const float c = d < 0.0f ? 0.0f : d;               // torch.clip(min = 0): a NaN stays a NaN
+        const float den = w + eps;
+        loss[tid] = (c * c) / den;
+        if (il) { il[tid] = (int32_t)(l - base); ir[tid] = (int32_t)(r - base); coef[tid] = -2.0f * c / den; }
+    }
+}
+
+// d loss / d cdfs_key: w_outer = ck[ir] - ck[il], so key edge e collects + g coef of the intervals whose right index is e and
+// - g coef of those whose left index is e.  il and ir ascend along a ray (the query edges do): each edge's intervals are one
+// stretch, found by bisection and summed in order — no atomics, the same bits every run.
+__global__ __launch_bounds__(kBlock) void pdf_loss_bwd_kernel(const float *__restrict__ g_loss, const int32_t *__restrict__ il,
+                                                              const int32_t *__restrict__ ir, const float *__restrict__ coef,
+                                                              int64_t n_rays, int64_t nq, int64_t nk, float *__restrict__ g_ck)
+{
+    const int64_t total = n_rays * (nk + 1);
+    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * kBlock) {
+        const int64_t ray = tid / (nk + 1);
+        const int e = (int)(tid - ray * (nk + 1));
+        const int64_t row = ray * nq;
+        auto stretch = [&](const int32_t *__restrict__ ids, int64_t &lo, int64_t &hi) {      // [lo, hi): ids == e
+            int64_t a = 0, b = nq;
+            while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] < e) a = m + 1; else b = m; }
+            lo = a;
+            b = nq;
+            while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] <= e) a = m + 1; else b = m; }
+            hi = a;
+        };
+        int64_t lo, hi;
+        float acc = 0.0f;
+        stretch(ir, lo, hi);
+        for (int64_t i = lo; i < hi; ++i) acc += g_loss[row + i] * coef[row + i];
+        stretch(il, lo, hi);
+        for (int64_t i = lo; i < hi; ++i) acc -= g_loss[row + i] * coef[row + i];
+        g_ck[tid] = acc;
+    }
+}
+
 }  // namespace
 }  // namespace nfa
 
 using namespace nfa;
+
+NFA_EXPORT int nfa_pdf_loss_fwd(const float *query_vals, const float *cdfs_query, const float *key_vals, const float *cdfs_key,
+                                int64_t n_rays, int64_t n_query, int64_t n_key, float eps, float *loss, int32_t *ids_left,
+                                int32_t *ids_right, float *coef, void *stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_query >= 1 && n_key >= 1, "pdf_loss_fwd: n_rays < 0 or an empty level");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(query_vals && cdfs_query && key_vals && cdfs_key && loss, "pdf_loss_fwd: NULL pointer");
+    NFA_REQUIRE((ids_left != nullptr) == (ids_right != nullptr) && (ids_left != nullptr) == (coef != nullptr),
+                "pdf_loss_fwd: ids_left, ids_right and coef must be given together");
+    hipLaunchKernelGGL(pdf_loss_fwd_kernel, dim3(blocks_for(n_rays * n_query)), dim3(kBlock), 0, (hipStream_t)stream, query_vals, cdfs_query,
+                       key_vals, cdfs_key, n_rays, n_query, n_key, eps, loss, ids_left, ids_right, coef);
+    return check_launch("pdf_loss_fwd_kernel");
+}
+
+NFA_EXPORT int nfa_pdf_loss_bwd(const float *g_loss, const int32_t *ids_left, const int32_t *ids_right, const float *coef,
+                                int64_t n_rays, int64_t n_query, int64_t n_key, float *g_cdfs_key, void *stream)
+{
+    NFA_REQUIRE(n_rays >= 0 && n_query >= 1 && n_key >= 1, "pdf_loss_bwd: n_rays < 0 or an empty level");
+    if (n_rays == 0) return NFA_OK;
+    NFA_REQUIRE(g_loss && ids_left && ids_right && coef && g_cdfs_key, "pdf_loss_bwd: NULL pointer");
+    hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(blocks_for(n_rays * (n_key + 1))), dim3(kBlock), 0, (hipStream_t)stream, g_loss, ids_left,
+                       ids_right, coef, n_rays, n_query, n_key, g_cdfs_key);
+    return check_launch("pdf_loss_bwd_kernel");
+}
 
 NFA_EXPORT int nfa_edge_cdfs_fwd(const float *t_edges, const float *sigmas, int64_t n_rays, int64_t n_samples, float *cdfs, float *trans,
                                  void *stream)

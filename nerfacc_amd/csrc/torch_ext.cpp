@@ -704,6 +704,37 @@ Tensor edge_cdfs_bwd(const Tensor &t_edges, const Tensor &trans, const Tensor &g
     return g_sig;
 }
 
+// (loss [R, Nq], ids_left, ids_right (int32), coef) — the last three undefined unless want_grad
+std::vector<Tensor> pdf_loss_fwd(const Tensor &q, const Tensor &cq, const Tensor &k, const Tensor &ck, double eps, bool want_grad) {
+    check_input(q, "query vals", at::kFloat);
+    check_input(cq, "cdfs_query", at::kFloat);
+    check_input(k, "key vals", at::kFloat);
+    check_input(ck, "cdfs_key", at::kFloat);
+    TORCH_CHECK(q.dim() == 2 && k.dim() == 2 && cq.sizes() == q.sizes() && ck.sizes() == k.sizes() && q.size(0) == k.size(0) && q.size(1) >= 2 &&
+                k.size(1) >= 2, "pdf_loss: batched [n_rays, n + 1] edges and cdfs expected");
+    const int64_t R = q.size(0), nq = q.size(1) - 1, nk = k.size(1) - 1;
+    Tensor loss = at::empty({R, nq}, q.options()), il, ir, coef;
+    if (want_grad) { il = at::empty({R, nq}, opts(q, at::kInt)); ir = at::empty_like(il); coef = at::empty_like(loss); }
+    Guard g(device_of(q));
+    check_rc(nfa_pdf_loss_fwd(ptr<float>(q), ptr<float>(cq), ptr<float>(k), ptr<float>(ck), R, nq, nk, (float)eps, ptr<float>(loss),
+                              ptr<int32_t>(il), ptr<int32_t>(ir), ptr<float>(coef), stream_of(q)));
+    return {loss, il, ir, coef};
+}
+
+Tensor pdf_loss_bwd(const Tensor &g_loss, const Tensor &il, const Tensor &ir, const Tensor &coef, int64_t n_key) {
+    check_input(g_loss, "g_loss", at::kFloat);
+    check_input(il, "ids_left", at::kInt);
+    check_input(ir, "ids_right", at::kInt);
+    check_input(coef, "coef", at::kFloat);
+    TORCH_CHECK(g_loss.dim() == 2 && il.sizes() == g_loss.sizes() && ir.sizes() == g_loss.sizes() && coef.sizes() == g_loss.sizes() && n_key >= 1,
+                "pdf_loss_bwd: shape mismatch");
+    Tensor g_ck = at::empty({g_loss.size(0), n_key + 1}, g_loss.options());
+    Guard g(device_of(g_loss));
+    check_rc(nfa_pdf_loss_bwd(ptr<float>(g_loss), ptr<int32_t>(il), ptr<int32_t>(ir), ptr<float>(coef), g_loss.size(0), g_loss.size(1), n_key,
+                              ptr<float>(g_ck), stream_of(g_loss)));
+    return g_ck;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // pack / rendering (fused entry points: chains of ATen ops in the reference)
 // ---------------------------------------------------------------------------------------------------
@@ -1106,6 +1137,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("transform_stot", &transform_stot, "s_vals"_a, "t_min"_a, "t_max"_a, "lindisp"_a);
     m.def("edge_cdfs_fwd", &edge_cdfs_fwd, "t_edges"_a, "sigmas"_a, "want_trans"_a);
     m.def("edge_cdfs_bwd", &edge_cdfs_bwd, "t_edges"_a, "trans"_a, "g_cdfs"_a);
+    m.def("pdf_loss_fwd", &pdf_loss_fwd, "query_vals"_a, "cdfs_query"_a, "key_vals"_a, "cdfs_key"_a, "eps"_a, "want_grad"_a);
+    m.def("pdf_loss_bwd", &pdf_loss_bwd, "g_loss"_a, "ids_left"_a, "ids_right"_a, "coef"_a, "n_key"_a);
     m.def("opencv_lens_undistortion", [](py::args, py::kwargs) {
         raise_not_implemented("camera undistortion (camera.cu) is outside the OccGrid hot path and not built"); });
     m.def("opencv_lens_undistortion_fisheye", [](py::args, py::kwargs) {

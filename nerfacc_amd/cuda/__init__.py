@@ -40,7 +40,7 @@ _FUSED_NAMES = (
     "visibility_compact", "accumulate_along_rays", "accumulate_along_rays_bwd",
     "rendering_fwd", "rendering_bwd",
     "grid_cell_points", "grid_ema_update", "grid_threshold", "grid_mark_invisible", "grid_occupied_counts", "sample_positions",
-    "transform_stot", "edge_cdfs_fwd", "edge_cdfs_bwd",
+    "transform_stot", "edge_cdfs_fwd", "edge_cdfs_bwd", "pdf_loss_fwd", "pdf_loss_bwd",
 )
 
 for _n in _REFERENCE_NAMES + _FUSED_NAMES:

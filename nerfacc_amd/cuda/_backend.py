@@ -101,6 +101,8 @@ _SIGNATURES = {
     "nfa_transform_stot": (ctypes.c_int, [_P, c_int64, c_float, c_float, c_int32, _P, _P]),
     "nfa_edge_cdfs_fwd": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
     "nfa_edge_cdfs_bwd": (ctypes.c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "nfa_pdf_loss_fwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_float, _P, _P, _P, _P, _P]),
+    "nfa_pdf_loss_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -712,6 +714,34 @@ class _CtypesC:
             _check(load_library().nfa_edge_cdfs_bwd(_ptr(t_edges), _ptr(trans), _ptr(g_cdfs), trans.shape[0], trans.shape[1], _ptr(g_sig),
                                                     _stream(trans)))
         return g_sig
+
+    @staticmethod
+    def pdf_loss_fwd(q, cq, k, ck, eps: float, want_grad: bool):
+        """(loss [R, Nq], ids_left, ids_right, coef): nfa_pdf_loss_fwd; the last three None unless want_grad"""
+        for t, nm in ((q, "query vals"), (cq, "cdfs_query"), (k, "key vals"), (ck, "cdfs_key")):
+            _check_input(t, nm, torch.float32)
+        if not (q.dim() == 2 and k.dim() == 2 and cq.shape == q.shape and ck.shape == k.shape and q.shape[0] == k.shape[0]
+                and q.shape[1] >= 2 and k.shape[1] >= 2):
+            raise RuntimeError("pdf_loss: batched [n_rays, n + 1] edges and cdfs expected")
+        R, nq, nk = q.shape[0], q.shape[1] - 1, k.shape[1] - 1
+        loss = torch.empty((R, nq), dtype=torch.float32, device=q.device)
+        il = ir = coef = None
+        if want_grad:
+            il = torch.empty((R, nq), dtype=torch.int32, device=q.device)
+            ir, coef = torch.empty_like(il), torch.empty_like(loss)
+        with _Guard(q):
+            _check(load_library().nfa_pdf_loss_fwd(_ptr(q), _ptr(cq), _ptr(k), _ptr(ck), R, nq, nk, eps, _ptr(loss), _ptr(il), _ptr(ir),
+                                                   _ptr(coef), _stream(q)))
+        return [loss, il, ir, coef]
+
+    @staticmethod
+    def pdf_loss_bwd(g_loss, il, ir, coef, n_key: int):
+        _check_input(g_loss, "g_loss", torch.float32)
+        g_ck = torch.empty((g_loss.shape[0], n_key + 1), dtype=torch.float32, device=g_loss.device)
+        with _Guard(g_loss):
+            _check(load_library().nfa_pdf_loss_bwd(_ptr(g_loss), _ptr(il), _ptr(ir), _ptr(coef), g_loss.shape[0], g_loss.shape[1], n_key,
+                                                   _ptr(g_ck), _stream(g_loss)))
+        return g_ck
 
     # ---------------------------------------------------------------- camera (out of scope, SURVEY.md 2a)
     @staticmethod

@@ -167,10 +167,35 @@ def _transform_stot(transform_type: Literal["uniform", "lindisp"], s_vals: torch
     raise ValueError(f"Unknown transform_type: {transform_type}")
 
 
+class _PdfLossBatched(torch.autograd.Function):
+    """`_pdf_loss` on batched CUDA tensors in one kernel (pdf.hip: pdf_loss_*), differentiable in cdfs_key"""
+
+    @staticmethod
+    def forward(ctx, q_vals, cdfs_query, k_vals, cdfs_key, eps):
+        need = ctx.needs_input_grad[3]
+        loss, il, ir, coef = _C.pdf_loss_fwd(q_vals.contiguous(), cdfs_query.contiguous(), k_vals.contiguous(), cdfs_key.contiguous(),
+                                             float(eps), need)
+        if need:
+            ctx.save_for_backward(il, ir, coef)
+            ctx.n_key = k_vals.shape[-1] - 1
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        il, ir, coef = ctx.saved_tensors
+        return None, None, None, _C.pdf_loss_bwd(g_loss.contiguous(), il, ir, coef, ctx.n_key), None
+
+
 def _pdf_loss(segments_query: RayIntervals, cdfs_query: torch.Tensor, segments_key: RayIntervals,
               cdfs_key: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
     """max(0, w - w_outer)^2 / (w + eps): w = query interval mass, w_outer = mass of the key
     intervals that overlap it (prop_net.py:232-256)."""
+    qv, kv = segments_query.vals, segments_key.vals
+    if qv.dim() == 2 and kv.dim() == 2 and qv.is_cuda and all(t.dtype == torch.float32 for t in (qv, kv, cdfs_query, cdfs_key)) \
+            and cdfs_query.shape == qv.shape and cdfs_key.shape == kv.shape and qv.shape[0] == kv.shape[0] \
+            and qv.shape[1] >= 2 and kv.shape[1] >= 2 \
+            and not (torch.is_grad_enabled() and (cdfs_query.requires_grad or qv.requires_grad or kv.requires_grad)):
+        return _PdfLossBatched.apply(qv, cdfs_query, kv, cdfs_key, eps)
     ids_left, ids_right = searchsorted(segments_key, segments_query)
     if segments_query.vals.dim() > 1:
         w = cdfs_query[..., 1:] - cdfs_query[..., :-1]

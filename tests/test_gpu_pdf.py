@@ -142,3 +142,35 @@ def test_level_cdfs_kernel_vs_the_reference_composition(R, S):
         assert torch.allclose(sig.grad, sig_ref.grad, rtol=2e-4, atol=2e-5)
     with torch.no_grad():                                  # no graph: no `trans` kept
         assert torch.equal(_level_cdfs(t_vals, sig.detach()), _level_cdfs(t_vals, sig).detach())
+
+
+@pytest.mark.parametrize("R,nq,nk", [(4096, 48, 256), (4096, 48, 96), (7, 1, 1), (33, 300, 5), (5, 3, 700)])
+def test_pdf_loss_kernel_vs_the_reference_composition(R, nq, nk):
+    """pdf.hip's pdf_loss_* (one launch forward, one backward, no atomics) against prop_net.py:232-256 written with searchsorted +
+    torch ops: the same loss bits, the gradient with respect to the key cdfs within float tolerance, and run-to-run identical"""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.estimators.prop_net import _pdf_loss
+
+    torch.manual_seed(R + nq + nk)
+    q = torch.sort(torch.rand(R, nq + 1, device=DEV) * 1.2 - 0.1, -1)[0]      # query edges partly outside the key's range
+    k = torch.sort(torch.rand(R, nk + 1, device=DEV), -1)[0]
+    if nq > 2:
+        q[:, 1] = q[:, 2]                                                       # an empty query interval
+    cq = torch.sort(torch.rand(R, nq + 1, device=DEV), -1)[0]
+    ck = torch.sort(torch.rand(R, nk + 1, device=DEV), -1)[0].requires_grad_(True)
+    ck_ref = ck.detach().clone().requires_grad_(True)
+    qi, ki = RayIntervals(vals=q), RayIntervals(vals=k)
+    loss = _pdf_loss(qi, cq, ki, ck)
+    want = _pdf_loss(qi, cq.clone().requires_grad_(True), ki, ck_ref)            # (a query cdf with a gradient: the composition)
+    assert loss.shape == (R, nq) and torch.equal(loss, want.detach())
+    coef = torch.rand(R, nq, device=DEV)
+    (loss * coef).sum().backward()
+    (want * coef).sum().backward()
+    # (an edge that is the right index of one stretch of intervals and the left index of another: two sums of up to nq terms each)
+    assert torch.allclose(ck.grad, ck_ref.grad, rtol=1e-4, atol=2e-7 * nq * float(ck_ref.grad.abs().max()) + 1e-6)
+    g1 = ck.grad.clone()
+    ck.grad = None
+    (_pdf_loss(qi, cq, ki, ck) * coef).sum().backward()
+    assert torch.equal(ck.grad, g1)
+    with torch.no_grad():
+        assert torch.equal(_pdf_loss(qi, cq, ki, ck), loss.detach())
