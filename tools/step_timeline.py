@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 mode = sys.argv[1] if len(sys.argv) > 1 else "api"
 pre = sys.argv[2] if len(sys.argv) > 2 else "1500"
-sys.argv = ["bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-other-mode", "--mode", mode, "--pretrain", pre]
+sys.argv = ["bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-other-mode", "--no-aux", "--windows", "1", "--mode", mode, "--pretrain", pre]
 import bench
 from torch.profiler import ProfilerActivity, profile
 captured = {}
