@@ -2004,33 +2004,68 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_rays_kernel(nfa_traverse
                 const int first = __shfl(run_first, gbase + i, 64);
                 const int len = __shfl(run_end, gbase + i, 64) - first;
                 const float dt0 = march_dt(base, cone, step_size);
-                for (int j0 = 0; j0 < len; j0 += G) {
-                    // every lane runs the pass's 16 sequential adds (the only chain from one pass to the next: no shuffle) and
-                    // keeps the value after its own k steps
+                // A pass of a group covers 64 samples, FOUR CONSECUTIVE ONES PER LANE: every lane runs the pass's sequential adds (the
+                // only chain from one pass to the next: no shuffle) in blocks of 16, keeps the value after its own 4 gl steps and
+                // takes four more steps for its own samples — 63 + 4 adds, 15 selects and four 16-byte stores per 64 samples
+                // (the first form, one sample per lane and 16 per pass, spent 45 instructions per 16: 12.9 -> 7 us on the
+                // bench's longest ray).  Blocks beyond the run's end are skipped (group-uniform).
+                for (int j0 = 0; j0 < len; j0 += 4 * G) {
+                    const int rem = len - j0;
                     float t = base, full = base;
-                    if (cone == 0.0f) {
+                    float sv[5];
+                    auto chain = [&](auto step) {            // (instantiated for the constant step and for the cone's clamp)
 #pragma unroll
-                        for (int k = 1; k < G; ++k) { full = full + dt0; t = gl >= k ? full : t; }
-                        base = full + dt0;
-                    } else {
+                        for (int blk = 0; blk < 4; ++blk) {
+                            if (blk == 0 || 16 * blk < rem) {
 #pragma unroll
-                        for (int k = 1; k < G; ++k) { full = full + march_dt(full, cone, step_size); t = gl >= k ? full : t; }
-                        base = full + march_dt(full, cone, step_size);
+                                for (int l = 4 * blk; l < 4 * blk + 4; ++l) {
+                                    if (l > 0) { full = step(step(step(step(full)))); t = gl >= l ? full : t; }
+                                }
+                            }
+                        }
+                        if (rem > 4 * G) base = step(step(step(step(full))));
+                        sv[0] = t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sv[e + 1] = step(sv[e]);
+                    };
+                    if (cone == 0.0f) chain([&](float x) { return x + dt0; });
+                    else chain([&](float x) { return x + march_dt(x, cone, step_size); });
+                    const int j = j0 + 4 * gl;              // this lane's first sample of the pass
+                    const int nv = rem - 4 * gl;            // its samples that exist (>= 4: all)
+                    if (nv <= 0) continue;
+                    const int64_t s = S + first + j;
+                    if (nv >= 4 && !a.iv_vals) {
+                        typedef float vf4 __attribute__((ext_vector_type(4)));
+                        if (a.t_starts) {
+                            const vf4 v0 = {sv[0], sv[1], sv[2], sv[3]}, v1 = {sv[1], sv[2], sv[3], sv[4]};
+                            __builtin_memcpy(a.t_starts + s, &v0, 16);
+                            __builtin_memcpy(a.t_ends + s, &v1, 16);
+                        }
+                        if (a.sm_vals) {
+                            const vf4 m = {(sv[1] + sv[0]) * 0.5f, (sv[2] + sv[1]) * 0.5f, (sv[3] + sv[2]) * 0.5f, (sv[4] + sv[3]) * 0.5f};
+                            __builtin_memcpy(a.sm_vals + s, &m, 16);
+                        }
+                        if (a.sm_ray_indices) {
+                            const int64_t rr[4] = {r, r, r, r};
+                            __builtin_memcpy(a.sm_ray_indices + s, rr, 32);
+                        }
+                        if (a.sm_is_valid) { const uint32_t ones = 0x01010101u; __builtin_memcpy(a.sm_is_valid + s, &ones, 4); }
+                        continue;
                     }
-                    const float t1 = t + march_dt(t, cone, step_size);
-                    const int j = j0 + gl;
-                    if (j < len) {
-                        const int64_t s = S + first + j;
-                        if (a.sm_vals) a.sm_vals[s] = (t1 + t) * 0.5f;
-                        if (a.sm_ray_indices) a.sm_ray_indices[s] = r;
-                        if (a.sm_is_valid) a.sm_is_valid[s] = 1;
-                        if (a.t_starts) { a.t_starts[s] = t; a.t_ends[s] = t1; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e >= nv) break;
+                        const float t0 = sv[e], t1 = sv[e + 1];
+                        if (a.sm_vals) a.sm_vals[s + e] = (t1 + t0) * 0.5f;
+                        if (a.sm_ray_indices) a.sm_ray_indices[s + e] = r;
+                        if (a.sm_is_valid) a.sm_is_valid[s + e] = 1;
+                        if (a.t_starts) { a.t_starts[s + e] = t0; a.t_ends[s + e] = t1; }
                         if (a.iv_vals) {
                             // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
-                            const int64_t e_right = E + first + j + (q0 + i) + 1;
+                            const int64_t e_right = E + first + j + e + (q0 + i) + 1;
                             a.iv_vals[e_right] = t1; a.iv_ray_indices[e_right] = r; a.iv_is_right[e_right] = 1;
                             a.iv_is_left[e_right - 1] = 1;
-                            if (j == 0) { a.iv_vals[e_right - 1] = t; a.iv_ray_indices[e_right - 1] = r; }
+                            if (j + e == 0) { a.iv_vals[e_right - 1] = t0; a.iv_ray_indices[e_right - 1] = r; }
                         }
                     }
                 }
@@ -2638,14 +2673,14 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
 }
 
 // a lane per sample with searches, or — from ~10^6 samples — 16 lanes per ray (r03_count_pass.md: below, the batch's longest ray is
-// the ray-group kernel's whole duration: 12.9 vs 7.5 us at 6.5 k rays x 38 samples; 23 vs 25 us at 32 k rays, 356 vs 655 us at 10^6;
-// 4 x 128^3 with 145 samples per ray: equal at 8 k rays, 126 vs 138 us at 16 k).  `n_samples`: the total, or the speculative
-// launch's capacity (the previous call's total).  NFA_EMIT = rays | samples overrides
+// the ray-group kernel's whole duration: 10.5 vs 7.5 us at 6.5 k rays x 38 samples; equal at 13 k rays, 18 vs 22 us at 32 k, 331 vs
+// 655 us at 10^6; 4 x 128^3 with 145 samples per ray: 16.5 vs 12.8 us at 4 k rays, 16.6 vs 21.8 at 8 k).  `n_samples`: the total, or
+// the speculative launch's capacity (the previous call's total).  NFA_EMIT = rays | samples overrides
 // With a cone angle always by rays: the sample-parallel form re-runs a sample's chain from its run's start (4 x 128^3, cone 0.004:
-// 16.8 vs 26.0 us at 4 k rays, 22.9 vs 77.4 at 16 k).
+// 14.5 vs 26.0 us at 4 k rays, 20.6 vs 77.4 at 16 k).
 static bool emit_by_rays(const nfa_traverse_args *a, int64_t n_samples) {
     if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r';
-    return a->cone_angle != 0.0f || n_samples >= 1100000;
+    return a->cone_angle != 0.0f || n_samples >= 900000;
 }
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;

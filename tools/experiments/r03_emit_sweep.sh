@@ -1,10 +1,11 @@
-cd /root/repo
-R="python tools/traverse_replay.py profiles/r02_sampling_state.npz 20"
-for n in 1024 4096 6500 13000 32000 65536 160000 300000 1000000; do
-  echo "== $n rays";    $R --rays=$n 2>&1 | tail -1
-  echo "== $n samples"; NFA_EMIT=samples $R --rays=$n 2>&1 | tail -1
-done
-python tools/traverse_replay.py profiles/r02_sampling_state.npz 5 --check | tail -1
-python tools/fuzz_campaign.py 30 902 2>&1 | tail -6
-python tools/fuzz_levels.py 2>&1 | tail -4
-python tools/fuzz_levels.py --cone 2>&1 | tail -4
+cd /root/repo; export TMPDIR=/tmp
+for n in 4096 6500 9000 13000 20000 32000; do for f in rays samples; do
+  D=/tmp/es_${n}_$f; mkdir -p $D
+  NFA_EMIT=$f rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python tools/traverse_replay.py profiles/r02_sampling_state.npz 20 --rays=$n > /dev/null 2>&1
+  echo "== $n $f $(python tools/kernel_summary.py $D | grep -E 'emit' | cut -d'|' -f4)"
+done; done
+for n in 2048 4096 8192; do for f in rays samples; do
+  D=/tmp/esm_${n}_$f; mkdir -p $D
+  NFA_EMIT=$f ML_ONLY_LATTICE=1 ML_NO_CHECK=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python tools/multilevel_bench.py $n > /dev/null 2>&1
+  echo "== levels $n $f $(python tools/kernel_summary.py $D | grep -E 'emit' | cut -d'|' -f4)"
+done; done
