@@ -918,6 +918,65 @@ __device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC>
     }
 }
 
+// The same walk with the boundary list as its only consumer (phase A of the split kernel's L2 forms), written for the
+// instruction count of its loop body: the candidate boundary is stored to the list's NEXT slot at every voxel — harmless when
+// the voxel is no boundary: the slot stays free — and taken with selects; the ray's last run is appended after the loop.
+// Same voxels, same list, same flags as walk_part with the list-appending callback.
+template <bool LDS_OCC, int CAP, int BLK>
+__device__ __forceinline__ void walk_part_list(const GridView &gv, const Occ<LDS_OCC> &occ, BrickCache cache, Dda s, bool live,
+                                               bool have_run, bool run_occ, float run_exit, int major_done, int j_end,
+                                               int m_rank, float seg_hi, float *__restrict__ ev_lane /* &ev_lds[tid] */,
+                                               int &n_ev, unsigned &ev_occ, bool &overflow)
+{
+    bool ended = false;                       // the walk (not just the part) ended: the ray's last run is a boundary too
+    const uint32_t *lc = (const uint32_t *)occ.smem;
+    while (live) {
+        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+        bool oc;
+        if (LDS_OCC) {
+            const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2);
+            if (id != cache.id) {
+                cache.id = id;
+                const uint2 wr = ((const uint2 *)occ.smem)[id >> 5];
+                const uint32_t bit = 1u << (id & 31);
+                const bool has = (wr.x & bit) != 0u;
+                const int k = has ? (int)wr.y + __popc(wr.x & (bit - 1u)) : 0;
+                const uint64_t b = ((const uint64_t *)(lc + 2 * occ.w4))[k];
+                cache.bits = has ? b : 0ull;
+            }
+            oc = (cache.bits >> (((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3))) & 1ull;
+        } else {
+            oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
+        }
+        const bool is_b = have_run && oc != run_occ;
+        const bool room = n_ev < CAP;
+        const int slot = room ? n_ev : CAP - 1;
+        if (room) ev_lane[slot * BLK] = run_exit;
+        overflow = overflow || (is_b && !room);
+        ev_occ |= ((is_b && room && run_occ) ? 1u : 0u) << slot;
+        n_ev += (is_b && room) ? 1 : 0;
+        have_run = true;
+        run_occ = oc;
+        run_exit = t_cell;
+        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        const bool cont = dda_advance(s);
+        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
+        major_done += (cm_after != cm_before) ? 1 : 0;
+        ended = !cont;
+        live = cont && major_done < j_end && !overflow;
+    }
+    if (ended && !overflow) {                 // end of the walk: the ray's last run
+        if (n_ev < CAP) {
+            ev_lane[n_ev * BLK] = run_exit;
+            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+            ++n_ev;
+        } else {
+            overflow = true;
+        }
+    }
+}
+
+
 #ifdef NFA_PHASE_CYCLES
 // build-time instrumentation (tools/phase_cycles.py builds with -DNFA_PHASE_CYCLES): shader-clock
 // stamps between the phases of the split kernel, kept in registers and stored once per wave at the
@@ -1208,6 +1267,10 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     int n_ev = 0;
     unsigned ev_occ = 0;
     bool overflow = false;
+    if (!LDS_OCC) {
+        walk_part_list<LDS_OCC, CAP, BLK>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
+                                          ev_lds + tid, n_ev, ev_occ, overflow);
+    } else
     walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
                        [&](float t_exit, bool o) {
                            if (n_ev == CAP) { overflow = true; return false; }
