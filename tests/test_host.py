@@ -223,3 +223,27 @@ def test_torch_extension_is_the_default_backend_and_has_the_reference_names():
         ext.opencv_lens_undistortion(1, 2)
     with pytest.raises(RuntimeError):                                  # CHECK_INPUT: host tensors are refused
         ext.ray_aabb_intersect(torch.rand(2, 3), torch.rand(2, 3), torch.rand(1, 6), 0.0, 1.0, -1.0)
+
+
+def test_propnet_glue_falls_back_to_torch_on_host_tensors():
+    """the one-launch forms of PropNetEstimator's per-level glue (s -> t map, edge cdfs, histogram loss) apply to device tensors only:
+    on host tensors the same functions run the reference's torch compositions (prop_net.py:99-112, 215-229, 232-256)"""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.estimators.prop_net import _edge_cdfs, _level_cdfs, _pdf_loss, _transform_stot
+
+    torch.manual_seed(0)
+    s = torch.rand(5, 9)
+    assert torch.equal(_transform_stot("lindisp", s, 0.2, 1e3), 1 / (s * (1 / 1e3) + (1 - s) * (1 / 0.2)))
+    assert torch.equal(_transform_stot("uniform", s, 0.2, 1e3), s * 1e3 + (1 - s) * 0.2)
+    t_vals = torch.sort(torch.rand(5, 9) * 4, -1)[0]
+    sig = torch.rand(5, 8, requires_grad=True)
+    cdfs = _level_cdfs(t_vals, sig)
+    x = sig * (t_vals[:, 1:] - t_vals[:, :-1])
+    trans = torch.exp(-torch.cumsum(torch.cat([torch.zeros_like(x[:, :1]), x[:, :-1]], -1), -1))
+    assert torch.allclose(cdfs, _edge_cdfs(trans)) and cdfs.shape == (5, 9) and cdfs.requires_grad
+    cdfs.sum().backward()
+    assert sig.grad is not None and torch.isfinite(sig.grad).all()
+    q, k = RayIntervals(vals=torch.sort(torch.rand(5, 4), -1)[0]), RayIntervals(vals=t_vals / 4)
+    cq = torch.sort(torch.rand(5, 4), -1)[0]
+    with pytest.raises(Exception):          # searchsorted is native: host tensors are refused loudly, not silently emulated
+        _pdf_loss(q, cq, k, cdfs.detach())
