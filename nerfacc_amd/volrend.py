@@ -46,7 +46,8 @@ _DENSE_KEYS = {}
 
 
 def _dense_keys(rows: int, n: int, device) -> Tensor:
-    key = (rows, n, device)
+    # (keyed by the current stream too: a cached tensor is only handed to work queued behind the kernels that filled it)
+    key = (rows, n, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     keys = _DENSE_KEYS.get(key)
     if keys is None:
         keys = torch.arange(rows, device=device, dtype=torch.int64).repeat_interleave(n)
