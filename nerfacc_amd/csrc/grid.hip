@@ -1870,8 +1870,9 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     int64_t p0 = 0, p1 = 0, ov = 0;
     const int64_t before = (int64_t)b * sums_per_block;
     for (int64_t j = threadIdx.x; j < before; j += kBlock) { p0 += block_sums[3 * j]; p1 += block_sums[3 * j + 1]; }
-    if (last)                                     // rays that need the pass-2 re-traversal
-        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) ov += block_sums[3 * j + 2];
+    int64_t ed = 0;
+    if (last)                                     // rays that need the pass-2 re-traversal; the call's edges (also without iv_cnts: the emit
+        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) { ov += block_sums[3 * j + 2]; ed += block_sums[3 * j]; }      // pass reads runs = edges - samples)
     int64_t t0, t1;
     block_excl_scan_i64(p0, lds, t0);
     block_excl_scan_i64(p1, lds, t1);
@@ -1881,17 +1882,18 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     if (iv_cnts) {
         const int64_t e = block_excl_scan_i64(c_iv, lds, tot);
         if (in) iv_starts[r] = base[0] + e;
-        if (last && threadIdx.x == 0) { totals[0] = base[0] + tot; totals_dev[0] = base[0] + tot; }
-    } else if (last && threadIdx.x == 0) { totals[0] = 0; totals_dev[0] = 0; }
+    }
     {
         const int64_t e = block_excl_scan_i64(c_sm, lds, tot);
         if (in) sm_starts[r] = base[1] + e;
         if (last && threadIdx.x == 0) { totals[1] = base[1] + tot; totals_dev[1] = base[1] + tot; }
     }
     if (last) {
-        int64_t tov;
+        int64_t tov, ted;
         block_excl_scan_i64(ov, lds, tov);
+        block_excl_scan_i64(ed, lds, ted);
         if (threadIdx.x == 0) {
+            totals[0] = ted; totals_dev[0] = ted;
             totals[2] = tov; totals_dev[2] = tov; totals_dev[3] = 0;
             // totals[3]: the caller's completion stamp, stored LAST and behind a system-scope fence — a host that polls this word
             // in (coherent) pinned memory may read the three totals as soon as it sees the stamp (nfa_traverse_offsets_stamped)
@@ -1933,14 +1935,8 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
 // stores of ray_indices / t_starts / t_ends (+ interval edges when asked for).
 // n_dev != NULL: speculative launch (before the host knows the total): the total comes from n_dev[1] and a launch whose
 // outputs (sized `n_samples` = the caller's guess) are too small does nothing — the caller launches again with the right size.
-__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t n_samples,
-                                                               const int64_t *__restrict__ n_dev)
+__device__ __forceinline__ void emit_by_samples(const nfa_traverse_args &a, const RunStore &rs, int64_t n_samples)
 {
-    if (n_dev) {
-        const int64_t n = n_dev[1];
-        if (n > n_samples) return;
-        n_samples = n;
-    }
     const float step_size = a.step_size, cone = a.cone_angle;
     const int64_t R = a.n_rays;
     __shared__ int64_t s_span[2];
@@ -2033,10 +2029,8 @@ __device__ __forceinline__ EmitRay emit_ray_load(const nfa_traverse_args &a, con
     return m;
 }
 
-__global__ __launch_bounds__(kBlock) void traverse_emit_rays_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
-                                                                    const int64_t *__restrict__ n_dev)
+__device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, const RunStore &rs)
 {
-    if (n_dev && n_dev[1] > capacity) return;      // speculative launch whose outputs are too small: the caller launches again
     constexpr int G = 16;
     const float step_size = a.step_size, cone = a.cone_angle;
     const int64_t R = a.n_rays;
@@ -2135,6 +2129,25 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_rays_kernel(nfa_traverse
             }
         }
     }
+}
+
+// pass 2: ONE launch, the form chosen ON THE DEVICE from the totals the offsets kernel left in the workspace (the speculative
+// launch runs before the host has seen them).  16 lanes per ray pay per RUN (~25 instructions + a pass per 64 samples), a lane per
+// sample pays ~14 dependent loads per SAMPLE: the ray groups win on long runs and lose on a grid of alternating voxels (the
+// reference's `rand > 0.5` test grid: 271 samples per ray in ~130 runs — 113 vs 77 us at 4 k rays when the choice looked at the
+// sample count alone, profiles/r03_count_pass.md).  runs = edges - samples.  With a cone angle the sample-parallel form re-runs a
+// sample's chain from its run's start, so the ray groups take over at much shorter runs.
+//   hint: 0 = choose, 1 = ray groups, 2 = lane per sample (NFA_EMIT).  speculative: outputs hold `capacity` samples — a launch whose
+//   outputs are too small does nothing, the caller launches again with the right size.
+__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
+                                                               const int64_t *__restrict__ n_dev, int speculative, int hint)
+{
+    const int64_t n_ed = n_dev[0], n_sm = n_dev[1];
+    if (speculative && n_sm > capacity) return;
+    const int64_t runs = n_ed - n_sm > 0 ? n_ed - n_sm : 1;
+    const bool long_runs = a.cone_angle != 0.0f ? n_sm >= 8 * runs : (n_sm >= 900000 && n_sm >= 20 * runs);
+    if (hint == 1 || (hint == 0 && long_runs)) emit_by_ray_groups(a, rs);
+    else emit_by_samples(a, rs, speculative ? n_sm : capacity);
 }
 
 // generic exclusive sum of int64 counts (data_spec.hpp:86-106), single workgroup of 1024:
@@ -2735,15 +2748,10 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     return check_launch("traverse_fill_kernel");
 }
 
-// a lane per sample with searches, or — from ~10^6 samples — 16 lanes per ray (r03_count_pass.md: below, the batch's longest ray is
-// the ray-group kernel's whole duration: 10.5 vs 7.5 us at 6.5 k rays x 38 samples; equal at 13 k rays, 18 vs 22 us at 32 k, 331 vs
-// 655 us at 10^6; 4 x 128^3 with 145 samples per ray: 16.5 vs 12.8 us at 4 k rays, 16.6 vs 21.8 at 8 k).  `n_samples`: the total, or
-// the speculative launch's capacity (the previous call's total).  NFA_EMIT = rays | samples overrides
-// With a cone angle always by rays: the sample-parallel form re-runs a sample's chain from its run's start (4 x 128^3, cone 0.004:
-// 14.5 vs 26.0 us at 4 k rays, 20.6 vs 77.4 at 16 k).
-static bool emit_by_rays(const nfa_traverse_args *a, int64_t n_samples) {
-    if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r';
-    return a->cone_angle != 0.0f || n_samples >= 900000;
+// NFA_EMIT = rays | samples forces a form of the emit pass (traverse_emit_kernel chooses otherwise)
+static int emit_hint() {
+    if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r' ? 1 : 2;
+    return 0;
 }
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;
@@ -2766,8 +2774,9 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     NFA_REQUIRE(n_samples >= 0 && n_overflow >= 0, "traverse_fill: negative totals");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
-        if (emit_by_rays(a, n_samples)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
-        else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, s, *a, rs, n_samples, (const int64_t *)nullptr);
+        const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
+        const unsigned nb_s = blocks_for(n_samples), nb_r = emit_ray_blocks(a->n_rays);
+        hipLaunchKernelGGL(traverse_emit_kernel, dim3(nb_s > nb_r ? nb_s : nb_r), dim3(kBlock), 0, s, *a, rs, n_samples, n_dev, 0, emit_hint());
         if (int rc = check_launch("traverse_emit_kernel")) return rc;
     }
     if (n_overflow > 0) return launch_fill(a, 1, 0, rs.n_runs, s);
@@ -2783,8 +2792,8 @@ NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const v
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
-    if (emit_by_rays(a, capacity)) hipLaunchKernelGGL(traverse_emit_rays_kernel, dim3(emit_ray_blocks(a->n_rays)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
-    else hipLaunchKernelGGL(traverse_emit_kernel, dim3(blocks_for(capacity)), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev);
+    const unsigned nb_s = blocks_for(capacity), nb_r = emit_ray_blocks(a->n_rays);
+    hipLaunchKernelGGL(traverse_emit_kernel, dim3(nb_s > nb_r ? nb_s : nb_r), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev, 1, emit_hint());
     return check_launch("traverse_emit_kernel");
 }
 
