@@ -130,7 +130,7 @@ typedef struct nfa_traverse_args {
      * iv_* describe interval edges (RaySegmentsSpec intervals), sm_* samples. iv pair nullable. */
     int64_t *iv_cnts, *iv_starts; /* [n_rays] */
     int64_t *sm_cnts, *sm_starts; /* [n_rays] */
-    int64_t *totals;            /* [4] = {n_edges, n_samples, n_overflow_rays, 0}; device-visible (pinned host ok) */
+    int64_t *totals;            /* [4] = {n_edges (counted also when no interval outputs are asked for), n_samples, n_overflow_rays, 0}; device-visible (pinned host ok) */
     /* fill outputs, each nullable (grid.cu:219-255) */
     float *iv_vals; int64_t *iv_ray_indices; uint8_t *iv_is_left; uint8_t *iv_is_right; /* [n_edges]; masks pre-zeroed */
     float *sm_vals; int64_t *sm_ray_indices; uint8_t *sm_is_valid;                      /* [n_samples] */
@@ -171,9 +171,10 @@ int nfa_traverse_offsets(const nfa_traverse_args *args, const void *workspace, v
 int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const void *workspace, int64_t stamp, void *stream);
 /* pass 2 (grid.cu:445 / the single over-allocated pass :375): write edges / samples at
  * iv_starts / sm_starts.
- * workspace != NULL: the workspace nfa_traverse_count filled for the SAME args, with
+ * workspace != NULL: the workspace nfa_traverse_count AND nfa_traverse_offsets filled for the SAME args, with
  *   n_samples = totals[1] and n_overflow = totals[2] as read back by the caller; one lane per
- *   output sample (skip_empty / rewrite_counts must be 1 / 0, no rays_mask).
+ *   output sample or 16 lanes per ray, chosen on the device from the totals in the workspace
+ *   (skip_empty / rewrite_counts must be 1 / 0, no rays_mask).
  * workspace == NULL: the grid is traversed again, one lane per ray (n_samples / n_overflow
  *   ignored).  `skip_empty`: skip rays whose stored count is 0 (grid.cu:103-106).
  *   `rewrite_counts`: store the actual per-ray counts back (over-allocated mode, grid.cu:277-280). */
