@@ -797,1030 +797,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
     publish_wave_sums(sink.n_iv, sink.n_sm, ovf, block_sums);
 }
 
-// ---- split walk: P lanes per ray ---------------------------------------------------------
-// With ~10^4 rays per training step a lane-per-ray walk fills only ~200 of the chip's 1024
-// SIMDs, one wave each, and its time is the instruction latency of ONE ray's ~400-voxel walk.
-// Plane crossings of each axis are chains t <- t + delta as well, so the DDA state after the
-// j-th crossing of the ray's major axis has a closed form (lattice.hpp) — the walk can START
-// anywhere.  Each ray is cut into P parts at major-axis crossings; a lane walks one part and
-// lists its occupied<->empty boundaries; lattice positions of boundaries are absolute (counted
-// from the segment start), so every lane resolves its own boundaries independently and the P
-// lanes of a ray are stitched with a P-wide shuffle prefix.  One level, cone_angle == 0,
-// no step limit (the training configuration); everything else uses the kernels above.
-
-// (time, axis) order of plane crossings in the voxel walk: earlier time first, ties z, y, x
-// (the strict '<' chain of utils_grid.cuh:119-141)
-__device__ __forceinline__ bool crossing_precedes(float ta, int rank_a, float tb, int rank_b) {
-    return (ta < tb) || (ta == tb && rank_a < rank_b);
-}
-
-// number of crossings of a chain (first at t0, then +d each) that precede (T, rank_T); also
-// returns the time of the first crossing that does not (the pending tdist of that axis)
-__device__ __forceinline__ int crossings_before(float t0, float d, int rank, float T, int rank_T, int n_max, float &pending) {
-    pending = t0;
-    if (n_max <= 0 || !crossing_precedes(t0, rank, T, rank_T)) return 0;
-    int i = 1;                          // v = time of crossing i
-    float v = t0;
-    const float est = (T - t0) / d;
-    if (est > 8.0f && est < 1.0e7f) {   // jump close, from below; verified
-        int j = (int)est - 2;
-        if (j > n_max) j = n_max;
-        const float vj = nfa_lattice_advance(t0, d, j - 1, nullptr);
-        if (crossing_precedes(vj, rank, T, rank_T)) { i = j; v = vj; }
-    }
-    while (i < n_max) {
-        const float nv = v + d;
-        if (!crossing_precedes(nv, rank, T, rank_T)) { pending = nv; return i; }
-        v = nv;
-        ++i;
-    }
-    pending = v + d;
-    return i;
-}
-
-// serial walk of one ray with the lattice arithmetic done inline at every transition: the
-// fallback of the split kernel for rays with too many transitions per part or a stuck lattice
-template <int EV, bool LDS_OCC>
-__device__ void traverse_ray_lattice_inline(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
-                                            int64_t r, CountSink &sink, float &t_term)
-{
-    const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
-    const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
-    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float near = ray_near(a, r), far = ray_far(a, r);
-    const float dt = march_dt(0.0f, 0.0f, a.step_size);
-    const int G = a.n_grids;
-    Events<EV> ev;
-    ev.init(a, r, o, inv);
-    float t_last = near;
-    bool continuous = false;
-    BrickCache cache;
-    cache.id = -1;
-    cache.bits = 0;
-    for (int i = 0; i + 1 < 2 * G; ++i) {
-        int level;
-        float seg_lo, seg_hi;
-        if (!segment_of(ev, i, G, near, far, level, seg_lo, seg_hi)) continue;
-        int64_t k; bool stuck;
-        if (!continuous) { t_last = nfa_lattice_until(t_last, dt, seg_lo, &k, &stuck); if (stuck) t_last = seg_lo; }
-        Dda s;
-        dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
-        bool have_run = false, run_occ = false, more = true;
-        float run_exit = 0.f;
-        while (more || have_run) {
-            bool oc = false;
-            float t_cell = 0.f;
-            if (more) {
-                t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-                oc = occupied(gv, occ, cache, level, s.cx, s.cy, s.cz);
-            }
-            if (have_run && (!more || oc != run_occ)) {           // close the run that ends at run_exit
-                const float t_new = nfa_lattice_until(t_last, dt, run_exit, &k, &stuck);
-                if (run_occ) { sink.run(t_last, k, continuous); if (k > 0) continuous = true; t_last = t_new; }
-                else { continuous = false; t_last = stuck ? run_exit : t_new; }
-                have_run = false;
-            }
-            if (!more) break;
-            have_run = true;
-            run_occ = oc;
-            run_exit = t_cell;
-            more = dda_advance(s);
-        }
-    }
-    t_term = t_last;
-}
-
-// Voxel walk of one part of a ray (split kernel): `on_boundary(t_exit, run_was_occupied)` is called
-// for every occupied<->empty boundary and for the ray's last run; returning false stops the walk.
-// `major_done` counts crossings of the ray's major axis; the part ends at crossing j_end.
-template <bool LDS_OCC, class F>
-__device__ __forceinline__ void walk_part(const GridView &gv, const Occ<LDS_OCC> &occ, BrickCache cache, Dda s, bool live,
-                                          bool have_run, bool run_occ, float run_exit, int major_done, int j_end,
-                                          int m_rank, float seg_hi, F &&on_boundary)
-{
-    while (live) {
-        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-        const bool oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
-        if (have_run && oc != run_occ) {
-            if (!on_boundary(run_exit, run_occ)) break;
-        }
-        have_run = true;
-        run_occ = oc;
-        run_exit = t_cell;
-        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        const bool cont = dda_advance(s);
-        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        major_done += (cm_after != cm_before) ? 1 : 0;
-        if (!cont) {                                   // end of the walk: the ray's last run
-            on_boundary(run_exit, run_occ);
-            live = false;
-        } else if (major_done >= j_end) live = false;  // next part's seam
-    }
-}
-
-// The same walk with the boundary list as its only consumer (phase A of the split kernel's L2 forms), written for the
-// instruction count of its loop body: the candidate boundary is stored to the list's NEXT slot at every voxel — harmless when
-// the voxel is no boundary: the slot stays free — and taken with selects; the ray's last run is appended after the loop.
-// Same voxels, same list, same flags as walk_part with the list-appending callback.
-template <bool LDS_OCC, int CAP, int BLK>
-__device__ __forceinline__ void walk_part_list(const GridView &gv, const Occ<LDS_OCC> &occ, BrickCache cache, Dda s, bool live,
-                                               bool have_run, bool run_occ, float run_exit, int major_done, int j_end,
-                                               int m_rank, float seg_hi, float *__restrict__ ev_lane /* &ev_lds[tid] */,
-                                               int &n_ev, unsigned &ev_occ, bool &overflow)
-{
-    bool ended = false;                       // the walk (not just the part) ended: the ray's last run is a boundary too
-    const uint32_t *lc = (const uint32_t *)occ.smem;
-    while (live) {
-        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-        bool oc;
-        if (LDS_OCC) {
-            const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2);
-            if (id != cache.id) {
-                cache.id = id;
-                const uint2 wr = ((const uint2 *)occ.smem)[id >> 5];
-                const uint32_t bit = 1u << (id & 31);
-                const bool has = (wr.x & bit) != 0u;
-                const int k = has ? (int)wr.y + __popc(wr.x & (bit - 1u)) : 0;
-                const uint64_t b = ((const uint64_t *)(lc + 2 * occ.w4))[k];
-                cache.bits = has ? b : 0ull;
-            }
-            oc = (cache.bits >> (((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3))) & 1ull;
-        } else {
-            oc = occupied(gv, occ, cache, 0, s.cx, s.cy, s.cz);
-        }
-        const bool is_b = have_run && oc != run_occ;
-        const bool room = n_ev < CAP;
-        const int slot = room ? n_ev : CAP - 1;
-        if (room) ev_lane[slot * BLK] = run_exit;
-        overflow = overflow || (is_b && !room);
-        ev_occ |= ((is_b && room && run_occ) ? 1u : 0u) << slot;
-        n_ev += (is_b && room) ? 1 : 0;
-        have_run = true;
-        run_occ = oc;
-        run_exit = t_cell;
-        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        const bool cont = dda_advance(s);
-        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-        major_done += (cm_after != cm_before) ? 1 : 0;
-        ended = !cont;
-        live = cont && major_done < j_end && !overflow;
-    }
-    if (ended && !overflow) {                 // end of the walk: the ray's last run
-        if (n_ev < CAP) {
-            ev_lane[n_ev * BLK] = run_exit;
-            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
-            ++n_ev;
-        } else {
-            overflow = true;
-        }
-    }
-}
-
-
-#ifdef NFA_PHASE_CYCLES
-// build-time instrumentation (tools/phase_cycles.py builds with -DNFA_PHASE_CYCLES): shader-clock
-// stamps between the phases of the split kernel, kept in registers and stored once per wave at the
-// end (one slot per wave, no atomics); read back with nfa_debug_phase_cycles
-constexpr int kPhaseSlots = 16384;
-__device__ unsigned long long g_phase_cycles[kPhaseSlots][16];
-__device__ unsigned long long g_phase_max_wave = 0, g_phase_hist[16] = {0};     // slowest wave; histogram of wave totals in 16 k-cycle bins
-__device__ unsigned long long g_phase_slow[16] = {0};                           // phase sums over the waves slower than 60 k cycles ([15] = how many)
-#define NFA_PHASE_BEGIN() unsigned long long ph_[16] = {0}; unsigned long long phase_t_ = __builtin_readcyclecounter(); const unsigned long long phase_t0_ = phase_t_
-#define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
-#define NFA_PHASE_END()                                                                        \
-    do {                                                                                      \
-        const int slot_ = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);           \
-        if (lane_id() == 0) {                                                                 \
-            const unsigned long long tot_ = __builtin_readcyclecounter() - phase_t0_;          \
-            atomicMax(&g_phase_max_wave, tot_);                                                \
-            atomicAdd(&g_phase_hist[tot_ >> 14 > 15 ? 15 : tot_ >> 14], 1ull);                 \
-            if (tot_ > 60000ull) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd(&g_phase_slow[i_], ph_[i_]); atomicAdd(&g_phase_slow[15], 1ull); } \
-        }                                                                                     \
-        if (lane_id() == 0 && slot_ < kPhaseSlots) {                                          \
-            ph_[14] = phase_t0_; ph_[15] = 1;                                                  \
-            for (int i_ = 0; i_ < 16; ++i_) g_phase_cycles[slot_][i_] += ph_[i_];              \
-        }                                                                                     \
-    } while (0)
-#else
-#define NFA_PHASE_MARK(i) do {} while (0)
-#define NFA_PHASE_BEGIN() do {} while (0)
-#define NFA_PHASE_END() do {} while (0)
-#endif
-
-// ---- cross-lane moves inside the P adjacent lanes of a ray (P <= 16: one DPP row).  ds_bpermute shuffles go through
-// the LDS crossbar and a lone wave waits for each batch; these stay in the VALU.
-// value of the lane Q below (same row); only meaningful where part >= Q
-template <int Q>
-__device__ __forceinline__ int group_shr_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kDppRowShr + Q, 0xf, 0xf, false); }
-template <int Q>
-__device__ __forceinline__ int64_t group_shr_i64(int64_t v) { return dpp_i64<kDppRowShr + Q>(v); }
-// inclusive prefix sums over the lanes of a group (part = lane index inside the group)
-template <int P>
-__device__ __forceinline__ int group_incl_sum_i32(int v, int part) {
-    if (P > 1) { const int u = group_shr_i32<1>(v); if (part >= 1) v += u; }
-    if (P > 2) { const int u = group_shr_i32<2>(v); if (part >= 2) v += u; }
-    if (P > 4) { const int u = group_shr_i32<4>(v); if (part >= 4) v += u; }
-    if (P > 8) { const int u = group_shr_i32<8>(v); if (part >= 8) v += u; }
-    return v;
-}
-template <int P>
-__device__ __forceinline__ int64_t group_incl_sum_i64(int64_t v, int part) {
-    if (P > 1) { const int64_t u = group_shr_i64<1>(v); if (part >= 1) v += u; }
-    if (P > 2) { const int64_t u = group_shr_i64<2>(v); if (part >= 2) v += u; }
-    if (P > 4) { const int64_t u = group_shr_i64<4>(v); if (part >= 4) v += u; }
-    if (P > 8) { const int64_t u = group_shr_i64<8>(v); if (part >= 8) v += u; }
-    return v;
-}
-// the group's P bits of a wave-wide ballot
-template <int P>
-__device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int group_base) {
-    return (unsigned)((ballot >> group_base) & ((1ull << (P < 32 ? P : 32)) - 1ull));     // (groups wider than 32 lanes only use the low bits: <= 15 segments)
-}
-
-// XT: the plane-crossing times of the ray's three axes are written out in LDS (lanes 1..3 of the ray walk the x / y / z chains
-// with plain adds — exact by construction — n + 1 values each); the walk's end times and every part's seam restart are then
-// reads and two binary searches instead of closed forms (512-thread form only: the arrays need 1.5 KB per ray).
-template <bool LDS_OCC, int P, int CAP, int BLK = kBlock, bool XT = false>
-__global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
-                                                                   int64_t *__restrict__ block_sums, RunStore rs)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    NFA_PHASE_BEGIN();
-    const int tid = threadIdx.x, part = tid % P;
-    const int64_t R = a.n_rays;
-    const int64_t r = (int64_t)blockIdx.x * (BLK / P) + tid / P;
-    const bool ray_ok = r < R;
-    const int64_t rr = ray_ok ? r : 0;
-    // the ray's loads are requested BEFORE the occupancy image is staged: their L2 round trip overlaps the image's
-    const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
-    const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
-    const float near = ray_near(a, rr), far = ray_far(a, rr);
-    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
-    NFA_PHASE_MARK(0);
-    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][BLK] times, then [CAP][BLK] indices
-    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float dt = march_dt(0.0f, 0.0f, a.step_size);
-
-    // the single segment (grid.cu:129-150 with one level)
-    float x0 = 0.f, x1 = 0.f;
-    const bool hit = slab_test(o, inv, a.aabbs, -INFINITY, INFINITY, x0, x1);
-    const float seg_lo = fmaxf(x0, near), seg_hi = fminf(x1, far);
-    const bool live = ray_ok && hit && seg_lo < seg_hi;
-
-    // quantities shared by the P lanes of a ray are computed once and passed around by shuffles
-    const int group_base = lane_id() - part;
-    int64_t k_tmp; bool stuck_any = false, stuck = false;
-    float t_seg = near;
-
-    Dda s;
-    s.tx = s.ty = s.tz = 0.f; s.dx = s.dy = s.dz = 0.f;
-    s.sx = s.sy = s.sz = 0; s.cx = s.cy = s.cz = 0; s.ox = s.oy = s.oz = 0;
-    if (live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs, gv.res);
-    NFA_PHASE_MARK(1);
-
-    // crossings until each axis reaches its overflow index
-    const int nx = s.sx ? (s.ox - s.cx) * s.sx : 1, ny = s.sy ? (s.oy - s.cy) * s.sy : 1, nz = s.sz ? (s.oz - s.cz) * s.sz : 1;
-    float Tx, Ty, Tz;      // time of the last crossing of each axis: when the walk ends
-    // XT layout of a ray: x crossings at [0, rx], y at [rx + 1, rx + ry + 1], z behind them (n + 1 values per axis)
-    const int xt_oy = gv.res[0] + 1, xt_oz = gv.res[0] + gv.res[1] + 2;
-    float *xt_ray = nullptr;
-    if (XT) xt_ray = (float *)(smem + occ.bytes) + 2 * CAP * BLK + (tid / P) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
-    if (XT) {
-        static_assert(!XT || P == 16, "the crossing-time arrays are filled by lanes 1..15 of a ray's group");
-        // ONE closed-form call per ray group: lane 0 jumps the lattice from `near` to the segment start, lanes 1..15 jump to
-        // the first entry of their fifth of the x / y / z chain (5 lanes per axis); then short plain-add loops: lane 0's last
-        // few lattice steps, the others' <= 26 chain entries (exact by construction).
-        const float h = dt * 0.5f;
-        float adv_t = near, adv_d = dt;
-        int64_t adv_j = 0;
-        bool jump = false;
-        int i_lo = 0, i_hi = 0;
-        float *dst = xt_ray;
-        if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
-            const float est = (seg_lo - h - near) / dt;
-            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - nfa_jump_margin(guess); jump = true; }
-        }
-        if (live && part >= 1) {
-            const int ax = (part - 1) / 5, k = (part - 1) % 5;
-            adv_t = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
-            adv_d = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
-            int n = ax == 0 ? nx : (ax == 1 ? ny : nz);
-            const int cap_n = gv.res[ax];
-            n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
-            const int L = (n + 1 + 4) / 5;
-            i_lo = k * L;
-            i_hi = (k + 1) * L < n + 1 ? (k + 1) * L : n + 1;
-            adv_j = i_lo;
-            jump = i_lo > 0 && i_lo < i_hi;
-            dst = xt_ray + (ax == 0 ? 0 : (ax == 1 ? xt_oy : xt_oz));
-        }
-        NFA_PHASE_MARK(9);
-        float adv_v = adv_t;
-        if (jump) adv_v = nfa_lattice_advance(adv_t, adv_d, adv_j, nullptr);
-        NFA_PHASE_MARK(10);
-        if (live && part == 0) {
-            float t = near;
-            if (jump && adv_v + h < seg_lo) t = adv_v;
-            while (t + h < seg_lo) {
-                const float nt = t + dt;
-                if (nt == t) { stuck_any = true; break; }
-                t = nt;
-            }
-            t_seg = t;
-        } else if (live) {
-            float t = adv_v;
-            for (int i = i_lo; i < i_hi; ++i) { dst[i] = t; t = t + adv_d; }
-        }
-        NFA_PHASE_MARK(11);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        t_seg = __shfl(t_seg, group_base, 64);
-        const bool ok3 = live && nx > 0 && ny > 0 && nz > 0 && nx <= gv.res[0] && ny <= gv.res[1] && nz <= gv.res[2];
-        Tx = ok3 ? xt_ray[nx - 1] : 0.0f;
-        Ty = ok3 ? xt_ray[xt_oy + ny - 1] : 0.0f;
-        Tz = ok3 ? xt_ray[xt_oz + nz - 1] : 0.0f;
-    } else if (P >= 4) {
-        // FOUR closed-form jumps per ray — the lattice from `near` to the segment start and the
-        // last crossing of x, y, z — run as ONE call, on lanes 0..3 of the ray's group (a wave pays
-        // for a call once, however many of its lanes are in it).  (Folding the segment-start jump
-        // into phase B instead — every part starting its lattice at `near` — was measured slower:
-        // all parts then pay the many short binades next to zero.)
-        const float h = dt * 0.5f;
-        float adv_t = near, adv_d = dt;
-        int64_t adv_j = 0;
-        bool jump = false;
-        if (live && part == 0 && near + h < seg_lo) {          // nfa_lattice_until's verified under-estimate
-            const float est = (seg_lo - h - near) / dt;
-            if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - nfa_jump_margin(guess); jump = true; }
-        }
-        if (part >= 1 && part <= 3) {
-            adv_t = part == 1 ? s.tx : (part == 2 ? s.ty : s.tz);
-            adv_d = part == 1 ? s.dx : (part == 2 ? s.dy : s.dz);
-            adv_j = (part == 1 ? nx : (part == 2 ? ny : nz)) - 1;
-            jump = live;
-        }
-        float adv_v = adv_t;
-        if (jump) adv_v = nfa_lattice_advance(adv_t, adv_d, adv_j, nullptr);
-        if (live && part == 0) {
-            float t = near;
-            if (jump && adv_v + h < seg_lo) t = adv_v;
-            while (t + h < seg_lo) {
-                const float nt = t + dt;
-                if (nt == t) { stuck_any = true; break; }
-                t = nt;
-            }
-            t_seg = t;
-        }
-        t_seg = __shfl(t_seg, group_base, 64);
-        Tx = __shfl(adv_v, group_base + 1, 64);
-        Ty = __shfl(adv_v, group_base + 2, 64);
-        Tz = __shfl(adv_v, group_base + 3, 64);
-    } else {
-        if (live && part == 0) { t_seg = nfa_lattice_until(near, dt, seg_lo, &k_tmp, &stuck); stuck_any = stuck; }
-        t_seg = __shfl(t_seg, group_base, 64);
-        Tx = nfa_lattice_advance(s.tx, s.dx, nx - 1, nullptr);
-        Ty = nfa_lattice_advance(s.ty, s.dy, ny - 1, nullptr);
-        Tz = nfa_lattice_advance(s.tz, s.dz, nz - 1, nullptr);
-    }
-    int end_rank = 2; float T_end = Tx;                                   // ranks: z 0, y 1, x 2
-    if (crossing_precedes(Ty, 1, T_end, end_rank)) { T_end = Ty; end_rank = 1; }
-    if (crossing_precedes(Tz, 0, T_end, end_rank)) { T_end = Tz; end_rank = 0; }
-    // major axis: most crossings
-    const int m_rank = (nx >= ny && nx >= nz) ? 2 : (ny >= nz ? 1 : 0);
-    const int n_major = m_rank == 2 ? nx : (m_rank == 1 ? ny : nz);
-    const int j_begin = (int)(((int64_t)part * n_major) / P);
-    const int j_end = (part == P - 1) ? 0x7fffffff : (int)(((int64_t)(part + 1) * n_major) / P);
-
-    // index bookkeeping the closed forms rely on; anything odd (a final voxel "behind" the first
-    // one through float error) is left to the serial walk
-    NFA_PHASE_MARK(2);
-    const bool weird = live && (nx <= 0 || ny <= 0 || nz <= 0 || (XT && (nx > gv.res[0] || ny > gv.res[1] || nz > gv.res[2])));
-    // parts whose range is empty do nothing; a part with j_begin == 0 starts at the segment start
-    bool part_live = live && !weird && j_begin < j_end;
-    bool have_run = false, run_occ = false;
-    float run_exit = 0.f;
-    BrickCache cache;
-    cache.id = -1;
-    cache.bits = 0;
-    if (part_live && j_begin > 0) {
-        const float t0m = m_rank == 2 ? s.tx : (m_rank == 1 ? s.ty : s.tz);
-        const float dm = m_rank == 2 ? s.dx : (m_rank == 1 ? s.dy : s.dz);
-        const int xt_om = m_rank == 2 ? 0 : (m_rank == 1 ? xt_oy : xt_oz);
-        const float T_seam = XT ? xt_ray[xt_om + j_begin - 1]
-                                : nfa_lattice_advance(t0m, dm, j_begin - 1, nullptr);    // time of major crossing j_begin
-        if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;
-        else if (XT) {
-            // crossings of the two minor axes that precede the seam: lower bounds in their arrays (both searches in one
-            // loop of 8 rounds: <= 129 entries), the pending crossing is the entry found
-            const bool xm = m_rank == 2, zm = m_rank == 0;
-            const float *A1 = xt_ray + (xm ? xt_oy : 0), *A2 = xt_ray + (zm ? xt_oy : xt_oz);
-            const int r1 = xm ? 1 : 2, r2 = zm ? 1 : 0;
-            const int n1 = xm ? ny : nx, n2 = zm ? ny : nz;
-            int lo1 = 0, hi1 = n1, lo2 = 0, hi2 = n2;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-                const float v1 = A1[m1], v2 = A2[m2];
-                if (lo1 < hi1) { if (crossing_precedes(v1, r1, T_seam, m_rank)) lo1 = m1 + 1; else hi1 = m1; }
-                if (lo2 < hi2) { if (crossing_precedes(v2, r2, T_seam, m_rank)) lo2 = m2 + 1; else hi2 = m2; }
-            }
-            const int c1 = lo1, c2 = lo2;
-            const float pend1 = A1[c1], pend2 = A2[c2];
-            if (!xm) { s.cx += c1 * s.sx; s.tx = pend1; }
-            if (xm) { s.cy += c1 * s.sy; s.ty = pend1; }
-            if (zm) { s.cy += c2 * s.sy; s.ty = pend2; }
-            if (!zm) { s.cz += c2 * s.sz; s.tz = pend2; }
-            int px = s.cx, py = s.cy, pz = s.cz;
-            if (m_rank == 2) { px += (j_begin - 1) * s.sx; s.cx += j_begin * s.sx; s.tx = T_seam + s.dx; }
-            else if (m_rank == 1) { py += (j_begin - 1) * s.sy; s.cy += j_begin * s.sy; s.ty = T_seam + s.dy; }
-            else { pz += (j_begin - 1) * s.sz; s.cz += j_begin * s.sz; s.tz = T_seam + s.dz; }
-            have_run = true;
-            run_occ = occupied(gv, occ, cache, 0, px, py, pz);
-            run_exit = fminf(T_seam, seg_hi);
-        } else {
-            // the two minor axes, picked with selects so that every lane of the wave runs the SAME two
-            // closed-form counts whatever its ray's major axis is (three `if (m_rank != k)` blocks made
-            // a wave with mixed major axes execute all three): minor 1 is x (y for an x-major ray),
-            // minor 2 is z (y for a z-major ray)
-            const bool xm = m_rank == 2, zm = m_rank == 0;
-            float pend1, pend2;
-            const int c1 = crossings_before(xm ? s.ty : s.tx, xm ? s.dy : s.dx, xm ? 1 : 2, T_seam, m_rank, xm ? ny : nx, pend1);
-            const int c2 = crossings_before(zm ? s.ty : s.tz, zm ? s.dy : s.dz, zm ? 1 : 0, T_seam, m_rank, zm ? ny : nz, pend2);
-            if (!xm) { s.cx += c1 * s.sx; s.tx = pend1; }
-            if (xm) { s.cy += c1 * s.sy; s.ty = pend1; }
-            if (zm) { s.cy += c2 * s.sy; s.ty = pend2; }
-            if (!zm) { s.cz += c2 * s.sz; s.tz = pend2; }
-            // the voxel just before the seam: occupancy state the part inherits
-            int px = s.cx, py = s.cy, pz = s.cz;
-            if (m_rank == 2) { px += (j_begin - 1) * s.sx; s.cx += j_begin * s.sx; s.tx = T_seam + s.dx; }
-            else if (m_rank == 1) { py += (j_begin - 1) * s.sy; s.cy += j_begin * s.sy; s.ty = T_seam + s.dy; }
-            else { pz += (j_begin - 1) * s.sz; s.cz += j_begin * s.sz; s.tz = T_seam + s.dz; }
-            have_run = true;
-            run_occ = occupied(gv, occ, cache, 0, px, py, pz);
-            run_exit = fminf(T_seam, seg_hi);
-        }
-    }
-
-    NFA_PHASE_MARK(3);
-    // ---- A: this part's voxels, boundaries only (times into the lane's LDS list)
-    int n_ev = 0;
-    unsigned ev_occ = 0;
-    bool overflow = false;
-    if (!LDS_OCC) {
-        walk_part_list<LDS_OCC, CAP, BLK>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
-                                          ev_lds + tid, n_ev, ev_occ, overflow);
-    } else
-    walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi,
-                       [&](float t_exit, bool o) {
-                           if (n_ev == CAP) { overflow = true; return false; }
-                           ev_lds[n_ev * BLK + tid] = t_exit;
-                           ev_occ |= (o ? 1u : 0u) << n_ev;
-                           ++n_ev;
-                           return true;
-                       });
-    // a part with more boundaries than its list holds puts its whole ray (all P lanes) into
-    // streaming mode: boundaries are resolved as the walk finds them and only aggregates are kept
-    // (S1); the run records are written by walking once more when the ray's prefixes are known (S2)
-    const bool streaming = group_bits<P>(__ballot(overflow), group_base) != 0u;
-
-    NFA_PHASE_MARK(4);
-    // ---- B: absolute lattice position (T_j, K_j = steps from the segment start) of every own
-    // boundary; the lists stay in LDS
-    int32_t *ev_K = (int32_t *)(ev_lds + CAP * BLK);
-    int64_t K_last = 0;
-    float T_last = t_seg;
-    // streaming aggregates: first boundary kept apart (its samples depend on the previous part)
-    int64_t K_first = 0, sm_rest = 0;
-    int fresh_rest = 0;
-    bool occ_first = false;
-    if (!streaming) {
-        int64_t K = 0;
-        float T = t_seg;
-        for (int j = 0; j < n_ev; ++j) {
-            const float bound = ev_lds[j * BLK + tid];
-            T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
-            stuck_any = stuck_any || stuck;
-            K += k_tmp;
-            ev_lds[j * BLK + tid] = T;
-            ev_K[j * BLK + tid] = (int32_t)K;
-        }
-        K_last = K;
-        T_last = T;
-    } else {
-        int64_t K = 0, K_prev = 0;
-        float T = t_seg;
-        n_ev = 0;
-        auto on_boundary = [&](float t_exit, bool o) {
-            int64_t k; bool st;
-            T = nfa_lattice_until(T, dt, t_exit, &k, &st);
-            stuck_any = stuck_any || st;
-            K += k;
-            if (n_ev == 0) { K_first = K; occ_first = o; }
-            else if (o && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; }
-            K_prev = K;
-            ++n_ev;
-            return true;
-        };
-        walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi, on_boundary);
-        K_last = K;
-        T_last = T;
-    }
-    NFA_PHASE_MARK(5);
-    // group-wide decisions (the P lanes of a ray are adjacent lanes of one wave)
-    bool bad = stuck_any || weird || K_last > 0x7fffffffll;
-#ifdef NFA_FORCE_SERIAL                          // test builds: every ray through the serial in-kernel walk
-    bad = true;
-#endif
-    bad = group_bits<P>(__ballot(bad), group_base) != 0u;
-#ifdef NFA_PHASE_CYCLES
-    ph_[12] = __popcll(__ballot(bad && ray_ok && part == 0));          // rays of this wave that take the serial walk
-    ph_[13] = __popcll(__ballot(streaming && ray_ok && part == 0));    // rays in streaming mode
-#endif
-    // boundary before this part's first one: the nearest earlier part that has boundaries
-    const unsigned ev_parts = group_bits<P>(__ballot(n_ev > 0), group_base);     // bit p: part p of this ray has boundaries
-    int64_t K_before = 0;
-    float T_before = t_seg;
-    {
-        const unsigned earlier = ev_parts & ((1u << part) - 1u);
-        const int src = group_base + (earlier ? 31 - __clz(earlier) : part);
-        const int64_t Kq = __shfl(K_last, src, 64);
-        const float Tq = __shfl(T_last, src, 64);
-        if (earlier) { K_before = Kq; T_before = Tq; }
-    }
-    // samples of every occupied run that ends in this part; runs with samples are "fresh"
-    // (each is preceded by an empty run or starts the ray: boundaries alternate)
-    int64_t n_sm = 0;
-    int n_fresh = 0;
-    if (!streaming) {
-        int64_t K_prev = K_before;
-        for (int j = 0; j < n_ev; ++j) {
-            const int64_t K = ev_K[j * BLK + tid];
-            if (((ev_occ >> j) & 1u) && K > K_prev) { n_sm += K - K_prev; ++n_fresh; }
-            K_prev = K;
-        }
-    } else if (n_ev > 0) {
-        n_sm = sm_rest;
-        n_fresh = fresh_rest;
-        if (occ_first && K_first > K_before) { n_sm += K_first - K_before; ++n_fresh; }
-    }
-    // exclusive prefixes of fresh runs and samples over the ray's parts, and ray totals
-    const int fresh_incl = group_incl_sum_i32<P>(n_fresh, part);
-    const int64_t sm_incl = group_incl_sum_i64<P>(n_sm, part);
-    const int fresh_before = fresh_incl - n_fresh;
-    const int64_t sm_before = sm_incl - n_sm;
-    const int fresh_total = __shfl(fresh_incl, group_base + P - 1, 64);
-    const int64_t sm_total = __shfl(sm_incl, group_base + P - 1, 64);
-    const int last_part_with_ev = ev_parts ? 31 - __clz(ev_parts) : -1;
-    const float T_final = __shfl(T_last, group_base + max(last_part_with_ev, 0), 64);
-
-    // run records of this part
-    if (!bad && rs.t0 && n_fresh > 0 && fresh_total <= rs.max_runs) {
-        if (!streaming) {
-            int64_t K_prev = K_before, first = sm_before;
-            float T_prev = T_before;
-            int idx = fresh_before;
-            for (int j = 0; j < n_ev; ++j) {
-                const int64_t K = ev_K[j * BLK + tid];
-                const float T = ev_lds[j * BLK + tid];
-                if (((ev_occ >> j) & 1u) && K > K_prev) {
-                    rs.t0[(int64_t)idx * R + r] = T_prev;
-                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
-                    first += K - K_prev;
-                    ++idx;
-                }
-                K_prev = K;
-                T_prev = T;
-            }
-        } else {                                   // S2: the same walk again, now writing
-            int64_t K = 0, K_prev = K_before, first = sm_before;
-            float T = t_seg, T_prev = T_before;
-            int idx = fresh_before;
-            auto on_boundary = [&](float t_exit, bool o) {
-                int64_t k; bool st;
-                T = nfa_lattice_until(T, dt, t_exit, &k, &st);
-                K += k;
-                if (o && K > K_prev) {
-                    rs.t0[(int64_t)idx * R + r] = T_prev;
-                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
-                    first += K - K_prev;
-                    ++idx;
-                }
-                K_prev = K;
-                T_prev = T;
-                return true;
-            };
-                walk_part<LDS_OCC>(gv, occ, cache, s, part_live, have_run, run_occ, run_exit, j_begin, j_end, m_rank, seg_hi, on_boundary);
-        }
-    }
-    NFA_PHASE_MARK(6);
-    int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
-    if (!bad) {
-        if (ray_ok && part == 0) {
-            const bool ovf = fresh_total > rs.max_runs;
-            if (rs.n_runs) rs.n_runs[r] = (uint16_t)(ovf ? kRunsOverflow : fresh_total);
-            out_iv = sm_total + fresh_total;
-            out_sm = sm_total;
-            out_ovf = ovf ? 1 : 0;
-            if (a.terminate_planes) a.terminate_planes[r] = last_part_with_ev >= 0 ? T_final : t_seg;
-        }
-    } else if (ray_ok && part == 0) {
-        CountSink sink{rs, r, R};
-        float t_term = 0.f;
-        traverse_ray_lattice_inline<EV_ONE, LDS_OCC>(a, gv, occ, r, sink, t_term);
-        out_ovf = sink.finish(true) ? 1 : 0;
-        out_iv = sink.n_iv;
-        out_sm = sink.n_sm;
-        if (a.terminate_planes) a.terminate_planes[r] = t_term;
-    }
-    if (ray_ok && part == 0) {
-        if (a.iv_cnts) a.iv_cnts[r] = out_iv;
-        a.sm_cnts[r] = out_sm;
-    }
-    NFA_PHASE_MARK(7);
-    publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);      // this wave's 64 / P rays
-    NFA_PHASE_MARK(8);
-    NFA_PHASE_END();
-}
-
-// ---- segment walk: several levels, one lane per LEVEL SEGMENT of a ray ---------------------------
-// A ray through G nested grids is a sequence of up to 2 G - 1 segments, each inside one level (grid.cu:129-150).
-// The lane-per-ray walk does them one after the other, every voxel a dependent brick load from L2: its time is
-// one ray's ~250-voxel chain whatever the ray count.  Here the P >= 2 G - 1 adjacent lanes of a ray take ONE
-// segment each and list its occupied<->empty boundaries.  The marching lattice is one chain t <- t + dt from the
-// first live segment's start across all segments (a jump to a later segment's start is the same recurrence), so
-// every lane resolves its own boundaries as absolute positions (T, K) on that chain and the lanes of a ray are
-// stitched in order.  What a segment adds to the single-level stitch: entering a segment while not `continuous`
-// jumps the lattice to its start (grid.cu:157-161) — a virtual empty boundary at seg_lo that only applies in that
-// state; and a first occupied run that continues the previous segment's samples starts no new run record.
-// cone_angle == 0, no step limit, no ray mask; anything odd (stuck lattice, a segment with more than CAP
-// boundaries) goes through the serial walk of the whole ray by the group's first lane.
-// K > 1 (round 3; P = 32 lanes per ray, K = 4 per segment slot, up to 4 levels and 4096 rays): a launch that small has lanes to
-// spare, and a segment's walk — 100-190 voxels at ~1000 cycles each, more than half of this kernel — is cut into K PARTS at
-// crossings of its major axis, as the single-level kernel cuts a ray: three lanes of the slot write the plane-crossing times of
-// the segment's x / y / z chains into scratch (`xt`, plain adds: exact by construction), every part then finds its start state
-// with reads and two binary searches and inherits the occupancy of the voxel before its seam.  A part's boundaries are positions on
-// the ray's ONE chain like a segment's; only the first lane WITH boundaries of a slot applies the jump to the segment's start.
-template <bool LDS_OCC, int P, int CAP, int KP = 1>
-__global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_traverse_args a, GridView gv,
-                                                                         int64_t *__restrict__ block_sums, RunStore rs, float *__restrict__ xt)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    NFA_PHASE_BEGIN();
-    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
-    NFA_PHASE_MARK(0);
-    float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][kBlock] times, then [CAP][kBlock] lattice indices
-    int32_t *ev_K = (int32_t *)(ev_lds + CAP * kBlock);
-    const int tid = threadIdx.x, part = tid % P;
-    const int group_base = lane_id() - part;
-    const int64_t R = a.n_rays;
-    const int64_t r = (int64_t)blockIdx.x * (kBlock / P) + tid / P;
-    const bool ray_ok = r < R;
-    const int64_t rr = ray_ok ? r : 0;
-    const int G = a.n_grids;
-
-    const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
-    const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
-    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    const float near = ray_near(a, rr), far = ray_far(a, rr);
-    const float dt = march_dt(0.0f, 0.0f, a.step_size);
-
-    Events<EV_MANY> ev;
-    ev.init(a, rr, o, inv);
-    int level = 0;
-    float seg_lo = 0.f, seg_hi = 0.f;
-    const int slot = part / KP, sub = part % KP;
-    const bool live = ray_ok && slot + 1 < 2 * G && segment_of(ev, slot, G, near, far, level, seg_lo, seg_hi);
-
-    NFA_PHASE_MARK(1);
-    // the chain starts at the first live segment
-    const unsigned live_parts = group_bits<P>(__ballot(live), group_base);
-    const int first_part = live_parts ? __ffs((int)live_parts) - 1 : 0;
-    const float lo_first = __shfl(seg_lo, group_base + first_part, 64);
-    int64_t k_tmp = 0;
-    bool stuck = false, stuck_any = false;
-    float t_seg = near;
-    if (live_parts) {
-        t_seg = nfa_lattice_until(near, dt, lo_first, &k_tmp, &stuck);
-        stuck_any = stuck;
-    }
-
-    NFA_PHASE_MARK(2);
-    constexpr int kSegBatch = 4;
-    // the segment's voxel walk: on_boundary(t_exit, run_was_occupied) for every occupied<->empty boundary and for the last run;
-    // returning false stops the walk.  kSegBatch voxels per trip: the DDA does not depend on the occupancy, so the steps of a
-    // batch run first, their brick words are requested together (one LDS / L2 latency per batch instead of one per voxel:
-    // 126 k -> 93 k cycles per wave) and the boundaries are found afterwards, in order.
-    // the lane's start state: the segment's first voxel, or (K > 1) the first voxel behind the part's seam
-    Dda s0;
-    s0.tx = s0.ty = s0.tz = 0.f; s0.dx = s0.dy = s0.dz = 0.f;
-    s0.sx = s0.sy = s0.sz = 0; s0.cx = s0.cy = s0.cz = 0; s0.ox = s0.oy = s0.oz = 0;
-    if (live) dda_setup(s0, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
-    bool part_live = live, have_run0 = false, run_occ0 = false;
-    float run_exit0 = 0.f;
-    int major0 = 0, j_end = 0x7fffffff, m_rank = 0;
-    if (KP > 1) {
-        const int nx = s0.sx ? (s0.ox - s0.cx) * s0.sx : 1, ny = s0.sy ? (s0.oy - s0.cy) * s0.sy : 1, nz = s0.sz ? (s0.oz - s0.cz) * s0.sz : 1;
-        const bool regular = live && nx > 0 && ny > 0 && nz > 0 && nx <= gv.res[0] && ny <= gv.res[1] && nz <= gv.res[2];
-        const int oy_ = gv.res[0] + 1, oz_ = gv.res[0] + gv.res[1] + 2;
-        float *const A = xt + ((int64_t)blockIdx.x * (kBlock / KP) + tid / KP) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
-        if (regular && sub < 3) {                          // the chain of axis `sub`: entry i = time of its crossing i
-            float t = sub == 0 ? s0.tx : (sub == 1 ? s0.ty : s0.tz);
-            const float dd = sub == 0 ? s0.dx : (sub == 1 ? s0.dy : s0.dz);
-            const int na = sub == 0 ? nx : (sub == 1 ? ny : nz);
-            float *dst = A + (sub == 0 ? 0 : (sub == 1 ? oy_ : oz_));
-            for (int i = 0; i <= na; ++i) { dst[i] = t; t = t + dd; }
-        }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();                   // (the K lanes of a slot are lanes of one wave)
-        if (regular) {
-            const float Tx = A[nx - 1], Ty = A[oy_ + ny - 1], Tz = A[oz_ + nz - 1];       // the walk ends with the earliest of these
-            int end_rank = 2; float T_end = Tx;                                       // ranks: z 0, y 1, x 2
-            if (crossing_precedes(Ty, 1, T_end, end_rank)) { T_end = Ty; end_rank = 1; }
-            if (crossing_precedes(Tz, 0, T_end, end_rank)) { T_end = Tz; end_rank = 0; }
-            m_rank = (nx >= ny && nx >= nz) ? 2 : (ny >= nz ? 1 : 0);
-            const int n_major = m_rank == 2 ? nx : (m_rank == 1 ? ny : nz);
-            const int j_begin = (int)(((int64_t)sub * n_major) / KP);
-            j_end = (sub == KP - 1) ? 0x7fffffff : (int)(((int64_t)(sub + 1) * n_major) / KP);
-            major0 = j_begin;
-            part_live = j_begin < j_end;
-            if (part_live && j_begin > 0) {
-                const float T_seam = A[(m_rank == 2 ? 0 : (m_rank == 1 ? oy_ : oz_)) + j_begin - 1];   // time of major crossing j_begin
-                if (m_rank != end_rank && !crossing_precedes(T_seam, m_rank, T_end, end_rank)) part_live = false;   // the walk ends before this seam
-                else {
-                    const bool xm = m_rank == 2, zm = m_rank == 0;
-                    const float *A1 = A + (xm ? oy_ : 0), *A2 = A + (zm ? oy_ : oz_);
-                    const int r1 = xm ? 1 : 2, r2 = zm ? 1 : 0;
-                    const int n1 = xm ? ny : nx, n2 = zm ? ny : nz;
-                    int lo1 = 0, hi1 = n1, lo2 = 0, hi2 = n2;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-                        const float v1 = A1[m1], v2 = A2[m2];
-                        if (lo1 < hi1) { if (crossing_precedes(v1, r1, T_seam, m_rank)) lo1 = m1 + 1; else hi1 = m1; }
-                        if (lo2 < hi2) { if (crossing_precedes(v2, r2, T_seam, m_rank)) lo2 = m2 + 1; else hi2 = m2; }
-                    }
-                    const float pend1 = A1[lo1], pend2 = A2[lo2];
-                    if (!xm) { s0.cx += lo1 * s0.sx; s0.tx = pend1; }
-                    if (xm) { s0.cy += lo1 * s0.sy; s0.ty = pend1; }
-                    if (zm) { s0.cy += lo2 * s0.sy; s0.ty = pend2; }
-                    if (!zm) { s0.cz += lo2 * s0.sz; s0.tz = pend2; }
-                    // the voxel just before the seam: the run state the part inherits
-                    int px = s0.cx, py = s0.cy, pz = s0.cz;
-                    if (m_rank == 2) { px += (j_begin - 1) * s0.sx; s0.cx += j_begin * s0.sx; s0.tx = T_seam + s0.dx; }
-                    else if (m_rank == 1) { py += (j_begin - 1) * s0.sy; s0.cy += j_begin * s0.sy; s0.ty = T_seam + s0.dy; }
-                    else { pz += (j_begin - 1) * s0.sz; s0.cz += j_begin * s0.sz; s0.tz = T_seam + s0.dz; }
-                    BrickCache cache;
-                    cache.id = -1;
-                    cache.bits = 0;
-                    have_run0 = true;
-                    run_occ0 = occupied(gv, occ, cache, level, px, py, pz);
-                    run_exit0 = fminf(T_seam, seg_hi);
-                }
-            }
-        } else {
-            part_live = live && sub == 0;                  // odd index bookkeeping: the slot's first lane walks the whole segment
-        }
-    }
-    auto walk = [&](auto &&on_boundary) {
-        Dda s = s0;
-        bool have_run = have_run0, run_occ = run_occ0, stop = false, ended = true;
-        float run_exit = run_exit0;
-        int major_done = major0;
-        const uint32_t *lc = (const uint32_t *)occ.smem;
-        for (bool more = true; more;) {
-            bool valid[kSegBatch];
-            float tc[kSegBatch];
-            int id[kSegBatch], bp[kSegBatch];
-#pragma unroll
-            for (int k = 0; k < kSegBatch; ++k) {
-                valid[k] = more;
-                tc[k] = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
-                id[k] = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + level * gv.bricks_per_grid;
-                bp[k] = ((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3);
-                if (more) {
-                    if (KP > 1) {
-                        const int cm_before = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-                        more = dda_advance(s);
-                        const int cm_after = m_rank == 2 ? s.cx : (m_rank == 1 ? s.cy : s.cz);
-                        major_done += (cm_after != cm_before) ? 1 : 0;
-                        if (more && major_done >= j_end) { more = false; ended = false; }     // the next part's seam: the run stays open
-                    } else {
-                        more = dda_advance(s);
-                    }
-                }
-            }
-            uint64_t bits[kSegBatch];
-            if (LDS_OCC) {
-                uint2 wr[kSegBatch];
-#pragma unroll
-                for (int k = 0; k < kSegBatch; ++k) wr[k] = valid[k] ? ((const uint2 *)occ.smem)[id[k] >> 5] : make_uint2(0u, 0u);
-#pragma unroll
-                for (int k = 0; k < kSegBatch; ++k) {
-                    const uint32_t bit = 1u << (id[k] & 31);
-                    bits[k] = (wr[k].x & bit) ? ((const uint64_t *)(lc + 2 * occ.w4))[(int)wr[k].y + __popc(wr[k].x & (bit - 1u))] : 0ull;
-                }
-            } else if (occ.bytes > 0) {
-                uint32_t w[kSegBatch];
-#pragma unroll
-                for (int k = 0; k < kSegBatch; ++k) w[k] = valid[k] ? lc[id[k] >> 5] : 0u;
-#pragma unroll
-                for (int k = 0; k < kSegBatch; ++k) bits[k] = (w[k] & (1u << (id[k] & 31))) ? gv.bricks[id[k]] : 0ull;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kSegBatch; ++k) bits[k] = valid[k] ? gv.bricks[id[k]] : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < kSegBatch; ++k) {
-                if (valid[k] && !stop) {
-                    const bool oc = (bits[k] >> bp[k]) & 1ull;
-                    if (have_run && oc != run_occ) stop = !on_boundary(run_exit, run_occ);
-                    have_run = true;
-                    run_occ = oc;
-                    run_exit = tc[k];
-                }
-            }
-            if (stop) more = false;
-        }
-        if (!stop && ended) on_boundary(run_exit, run_occ);    // the segment's last run
-    };
-
-    // ---- A: this segment's boundaries into the lane's list; a segment with more than CAP of them is STREAMED: its boundaries
-    // are resolved as a second walk finds them (aggregates only) and its run records written by a third one
-    int n_ev = 0;
-    unsigned ev_occ = 0;
-    bool streaming = false;
-    if (part_live)
-        walk([&](float t_exit, bool oc) {
-            if (n_ev == CAP) { streaming = true; return false; }
-            ev_lds[n_ev * kBlock + tid] = t_exit;
-            ev_occ |= (oc ? 1u : 0u) << n_ev;
-            ++n_ev;
-            return true;
-        });
-
-    NFA_PHASE_MARK(3);
-    // ---- B: positions on the chain: the segment start (the virtual boundary), then the own boundaries
-    float T_lo = t_seg, T_last = t_seg;
-    int64_t K_lo = 0, K_last = 0;
-    int64_t sm_rest = 0;                 // samples / fresh runs of boundaries 1.. (each preceded by an empty boundary of this segment)
-    int fresh_rest = 0;
-    int64_t K_first = 0;
-    bool cont_rest = false, occ_first = false;
-    if (part_live) {
-        T_lo = nfa_lattice_until(t_seg, dt, seg_lo, &K_lo, &stuck);
-        stuck_any = stuck_any || stuck;
-        float T = T_lo;
-        int64_t K = K_lo, K_prev = K_lo;
-        int j = 0;
-        auto resolve = [&](float bound, bool oj) {
-            // A voxel exit BEFORE the segment's start (a ray lying in a bounding plane of a level: its slab test returns an
-            // infinite exit, the level's segment outlasts the box, and the next segment's first voxel lies behind the ray) has
-            // no position relative to this segment's start; where the chain stands then depends on the segments before it.
-            // Such rays take the serial walk (tests/golden/k2_inplane.npz pins them).
-            stuck_any = stuck_any || bound < seg_lo;
-            T = nfa_lattice_until(T, dt, bound, &k_tmp, &stuck);
-            stuck_any = stuck_any || stuck;
-            K += k_tmp;
-            if (j == 0) { K_first = K; occ_first = oj; }
-            else if (oj && K > K_prev) { sm_rest += K - K_prev; ++fresh_rest; cont_rest = true; }
-            else if (!oj) cont_rest = false;
-            K_prev = K;
-            ++j;
-        };
-        if (!streaming) {
-            for (int q = 0; q < n_ev; ++q) {
-                resolve(ev_lds[q * kBlock + tid], (ev_occ >> q) & 1u);
-                ev_lds[q * kBlock + tid] = T;
-                ev_K[q * kBlock + tid] = (int32_t)K;
-            }
-        } else {
-            walk([&](float t_exit, bool oc) { resolve(t_exit, oc); return true; });
-            n_ev = j;
-        }
-        K_last = K;
-        T_last = T;
-    }
-    NFA_PHASE_MARK(4);
-    bool bad = stuck_any || K_last > 0x7fffffffll;
-#ifdef NFA_FORCE_SERIAL
-    bad = true;
-#endif
-    bad = group_bits<P>(__ballot(bad), group_base) != 0u;
-#ifdef NFA_PHASE_CYCLES
-    ph_[12] = __popcll(__ballot(bad && ray_ok && part == 0));          // rays of this wave that take the serial walk
-    ph_[13] = __popcll(__ballot(streaming));                           // streamed segments
-#endif
-
-    // ---- stitch, segment by segment: (position, continuous) before every part
-    const bool has = part_live && n_ev > 0;
-    // the jump to a segment's start (entering it while not continuous) belongs to the first lane WITH boundaries of its slot
-    const unsigned has_lanes = group_bits<P>(__ballot(has), group_base);
-    const unsigned slot_lanes = ((1u << KP) - 1u) << (slot * KP);
-    const bool enters = has && (has_lanes & slot_lanes & ((1u << part) - 1u)) == 0u;
-    int Kpos = 0;
-    float Tpos = t_seg;
-    bool cont = false, any_has = false;
-    int64_t sm_acc = 0;
-    int fresh_acc = 0;
-    int my_K_start = 0, my_fresh_before = 0;
-    float my_T_start = t_seg;
-    bool my_cont_in = false;
-    int64_t my_sm_before = 0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int src = group_base + p;
-        const bool has_p = __shfl((int)has, src, 64) != 0;
-        const int Klo_p = __shfl((int)K_lo, src, 64), Kf_p = __shfl((int)K_first, src, 64), Kl_p = __shfl((int)K_last, src, 64);
-        const float Tlo_p = __shfl(T_lo, src, 64), Tl_p = __shfl(T_last, src, 64);
-        const int flags_p = __shfl((occ_first ? 1 : 0) | (cont_rest ? 2 : 0) | (n_ev >= 2 ? 4 : 0) | (enters ? 8 : 0), src, 64);
-        const int64_t smr_p = __shfl(sm_rest, src, 64);
-        const int frr_p = __shfl(fresh_rest, src, 64);
-        if (part == p) { my_sm_before = sm_acc; my_fresh_before = fresh_acc; my_cont_in = cont; }
-        if (has_p) {
-            int Ks = Kpos;
-            float Ts = Tpos;
-            if ((flags_p & 8) && !cont && Klo_p > Kpos) { Ks = Klo_p; Ts = Tlo_p; }      // entering the segment: jump to its start
-            const bool of = flags_p & 1;
-            const int k1 = of && Kf_p > Ks ? Kf_p - Ks : 0;
-            const bool fresh1 = k1 > 0 && !cont;
-            if (part == p) { my_K_start = Ks; my_T_start = Ts; }
-            sm_acc += k1 + smr_p;
-            fresh_acc += (fresh1 ? 1 : 0) + frr_p;
-            if (of) { if (k1 > 0) cont = true; } else cont = false;
-            if (flags_p & 4) cont = (flags_p & 2) != 0;
-            Kpos = Kl_p;
-            Tpos = Tl_p;
-            any_has = true;
-        }
-    }
-    const int64_t sm_total = sm_acc;
-    const int fresh_total = fresh_acc;
-
-    NFA_PHASE_MARK(5);
-    // run records of this segment
-    if (!bad && rs.t0 && has && fresh_total <= rs.max_runs) {
-        int64_t first = my_sm_before;
-        int64_t K_prev = my_K_start;
-        float T_prev = my_T_start;
-        int idx = my_fresh_before, j = 0;
-        auto record = [&](int64_t K, float T, bool oj) {
-            if (oj && K > K_prev) {
-                if (j > 0 || !my_cont_in) {
-                    rs.t0[(int64_t)idx * R + r] = T_prev;
-                    rs.first[(int64_t)idx * R + r] = (int32_t)first;
-                    ++idx;
-                }
-                first += K - K_prev;
-            }
-            K_prev = K > K_prev ? K : K_prev;
-            T_prev = T;
-            ++j;
-        };
-        if (!streaming) {
-            for (int q = 0; q < n_ev; ++q) record(ev_K[q * kBlock + tid], ev_lds[q * kBlock + tid], (ev_occ >> q) & 1u);
-        } else {
-            float T = T_lo;
-            int64_t K = K_lo;
-            walk([&](float t_exit, bool oc) {
-                int64_t k; bool st;
-                T = nfa_lattice_until(T, dt, t_exit, &k, &st);
-                K += k;
-                record(K, T, oc);
-                return true;
-            });
-        }
-    }
-    NFA_PHASE_MARK(6);
-    int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
-    if (!bad) {
-        if (ray_ok && part == 0) {
-            const bool ovf = fresh_total > rs.max_runs || sm_total > 0x7fffffffll;
-            if (rs.n_runs) rs.n_runs[r] = (uint16_t)(ovf ? kRunsOverflow : fresh_total);
-            out_iv = sm_total + fresh_total;
-            out_sm = sm_total;
-            out_ovf = ovf && sm_total > 0 ? 1 : 0;
-            if (a.terminate_planes) a.terminate_planes[r] = any_has ? Tpos : near;
-        }
-    } else if (ray_ok && part == 0) {
-        CountSink sink{rs, r, R};
-        float t_term = 0.f;
-        traverse_ray_lattice_inline<EV_MANY, LDS_OCC>(a, gv, occ, r, sink, t_term);
-        out_ovf = sink.finish(true) ? 1 : 0;
-        out_iv = sink.n_iv;
-        out_sm = sink.n_sm;
-        if (a.terminate_planes) a.terminate_planes[r] = t_term;
-    }
-    if (ray_ok && part == 0) {
-        if (a.iv_cnts) a.iv_cnts[r] = out_iv;
-        a.sm_cnts[r] = out_sm;
-    }
-    NFA_PHASE_MARK(7);
-    publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);
-    NFA_PHASE_MARK(8);
-    NFA_PHASE_END();
-}
-
+#include "split_walk.hpp"
+#include "segments_walk.hpp"
 #include "cone_walk.hpp"
 
 // block-level exclusive scan of one int64 per thread (256 threads); returns the exclusive
@@ -1930,225 +908,7 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
     }
 }
 
-// pass 2, fast form: ONE LANE PER OUTPUT SAMPLE.  sample s -> ray (binary search in the
-// exclusive offsets) -> run (binary search in the runs' first-sample indices) -> lattice point (closed form) -> coalesced
-// stores of ray_indices / t_starts / t_ends (+ interval edges when asked for).
-// n_dev != NULL: speculative launch (before the host knows the total): the total comes from n_dev[1] and a launch whose
-// outputs (sized `n_samples` = the caller's guess) are too small does nothing — the caller launches again with the right size.
-__device__ __forceinline__ void emit_by_samples(const nfa_traverse_args &a, const RunStore &rs, int64_t n_samples)
-{
-    const float step_size = a.step_size, cone = a.cone_angle;
-    const int64_t R = a.n_rays;
-    __shared__ int64_t s_span[2];
-    for (int64_t s0 = (int64_t)blockIdx.x * kBlock; s0 < n_samples; s0 += (int64_t)gridDim.x * kBlock) {
-        // the workgroup's 256 consecutive samples belong to a narrow range of rays: two lanes
-        // search the whole offset array for the first and the last sample, everyone else only
-        // that range (a dozen rays for NeRF-like rays: 4 dependent loads instead of log2 R)
-        const int64_t s_last = (s0 + kBlock - 1 < n_samples ? s0 + kBlock - 1 : n_samples - 1);
-        if (threadIdx.x < 128) {
-            // waves 0 and 1 look for the ray of the first / last sample with a 64-ary search: every round is ONE memory
-            // round trip for 64 probes (3 rounds for 10^5 rays) instead of the ~log2 R dependent loads of a bisection —
-            // those were this kernel's critical path
-            const int lane = lane_id();
-            const int64_t target = threadIdx.x < 64 ? s0 : s_last;
-            int64_t lo = 0, hi = R;                   // invariant: sm_starts[lo - 1] <= target (or lo == 0), sm_starts[hi] > target (or hi == R)
-            while (hi - lo > 0) {
-                const int64_t span = hi - lo;
-                const int64_t stride = (span + 63) >> 6;
-                const int64_t m = lo + (int64_t)lane * stride;                      // probes lo, lo + stride, ...
-                const bool le = m < hi && a.sm_starts[m] <= target;
-                const unsigned long long b = __ballot(le);                          // a prefix of ones (ascending offsets)
-                const int k = __popcll(b);                                          // probes that are <= target
-                if (k == 0) { hi = lo; break; }
-                const int64_t base = lo + (int64_t)(k - 1) * stride;                // last probe <= target
-                lo = base + 1;
-                const int64_t nh = base + stride;
-                if (nh < hi) hi = nh;
-            }
-            if (lane == 0) s_span[threadIdx.x >> 6] = lo - 1;
-        }
-        __syncthreads();
-        const int64_t r_first = s_span[0], r_last = s_span[1];
-        __syncthreads();
-        const int64_t s = s0 + threadIdx.x;
-        if (s >= n_samples) continue;
-        int64_t lo = r_first, hi = r_last + 1;
-        while (lo < hi) { const int64_t m = lo + ((hi - lo) >> 1); if (a.sm_starts[m] <= s) lo = m + 1; else hi = m; }
-        const int64_t r = lo - 1;
-        const int n_runs = rs.n_runs[r];
-        if (n_runs == kRunsOverflow) continue;        // written by the fallback launch
-        int64_t j = s - a.sm_starts[r];
-        int qlo = 1, qhi = n_runs;                    // last run whose first sample is <= j (run 0 starts at 0)
-        while (qlo < qhi) { const int m = qlo + ((qhi - qlo) >> 1); if ((int64_t)rs.first[(int64_t)m * R + r] <= j) qlo = m + 1; else qhi = m; }
-        const int q = qlo - 1;
-        if (q > 0) j -= rs.first[(int64_t)q * R + r];
-        float t0 = rs.t0[(int64_t)q * R + r];
-        if (cone == 0.0f) t0 = nfa_lattice_advance(t0, march_dt(t0, cone, step_size), j, nullptr);
-        else for (int64_t k = 0; k < j; ++k) t0 = t0 + march_dt(t0, cone, step_size);
-        const float t1 = t0 + march_dt(t0, cone, step_size);
-        if (a.sm_vals) a.sm_vals[s] = (t1 + t0) * 0.5f;
-        if (a.sm_ray_indices) a.sm_ray_indices[s] = r;
-        if (a.sm_is_valid) a.sm_is_valid[s] = 1;
-        if (a.t_starts) { a.t_starts[s] = t0; a.t_ends[s] = t1; }
-        if (a.iv_vals) {
-            // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
-            const int64_t e_right = a.iv_starts[r] + (s - a.sm_starts[r]) + q + 1;
-            a.iv_vals[e_right] = t1; a.iv_ray_indices[e_right] = r; a.iv_is_right[e_right] = 1;
-            a.iv_is_left[e_right - 1] = 1;
-            if (j == 0) { a.iv_vals[e_right - 1] = t0; a.iv_ray_indices[e_right - 1] = r; }
-        }
-    }
-}
-
-// pass 2, ray-group form (round 3): 16 LANES PER RAY walk the ray's run records in order — no searches.  The sample-parallel
-// form above is bound by its chain of ~14 dependent loads per sample (0.9 TB/s of stores at any size: 666 us for the 38 M
-// samples of 10^6 rays); here a ray costs two round trips (its counts and offsets, then its runs) and every 16 samples one
-// pass of 15 predicated adds: lane k of a group holds the run's lattice point after k steps, the next pass starts from lane
-// 15's end — the same sequential float adds the reference performs, so exact for any cone angle (the sample-parallel form
-// needs the closed form for cone_angle = 0 and j adds per sample otherwise).  Adjacent groups take adjacent rays: their
-// loads coalesce and their stores fill one contiguous stretch of the outputs.
-struct EmitRay {           // what a group of 16 lanes needs of a ray: ONE round trip (every load is independent of the others)
-    int64_t cnt, S, E;
-    int nr;
-    float run_t0;          // lane k: run k of the ray (garbage beyond the ray's runs, never used)
-    int run_first, run_next;
-};
-__device__ __forceinline__ EmitRay emit_ray_load(const nfa_traverse_args &a, const RunStore &rs, int64_t r, int gl) {
-    EmitRay m;
-    const int64_t R = a.n_rays;
-    m.cnt = a.sm_cnts[r];
-    m.nr = rs.n_runs[r];
-    m.S = a.sm_starts[r];
-    m.E = a.iv_vals ? a.iv_starts[r] : 0;
-    m.run_t0 = 0.0f; m.run_first = 0; m.run_next = 0;
-    if (gl < rs.max_runs) {
-        m.run_t0 = rs.t0[(int64_t)gl * R + r];
-        m.run_first = gl > 0 ? rs.first[(int64_t)gl * R + r] : 0;
-        if (gl + 1 < rs.max_runs) m.run_next = rs.first[(int64_t)(gl + 1) * R + r];
-    }
-    return m;
-}
-
-__device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, const RunStore &rs)
-{
-    constexpr int G = 16;
-    const float step_size = a.step_size, cone = a.cone_angle;
-    const int64_t R = a.n_rays;
-    const int lane = lane_id(), gl = lane & (G - 1), gbase = lane & ~(G - 1);
-    const int64_t n_groups = (int64_t)gridDim.x * (kBlock / G);
-    int64_t r = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
-    if (r >= R) return;
-    EmitRay m = emit_ray_load(a, rs, r, gl);
-    for (; r < R; r += n_groups) {
-        const EmitRay c = m;
-        if (r + n_groups < R) m = emit_ray_load(a, rs, r + n_groups, gl);      // the next ray's round trip overlaps this ray's stores
-        if (c.cnt <= 0) continue;                  // (a masked ray recorded nothing)
-        const int nr = c.nr;
-        if (nr == kRunsOverflow) continue;         // written by the fallback launch
-        const int64_t S = c.S, E = c.E;
-        for (int q0 = 0; q0 < nr; q0 += G) {
-            const int q = q0 + gl;                 // the group's lanes hold 16 runs at once
-            float run_t0 = c.run_t0;
-            int run_first = c.run_first, run_end = q + 1 < nr ? c.run_next : (int)c.cnt;
-            if (q0 > 0 && q < nr) {                // (a ray with more than 16 runs)
-                run_t0 = rs.t0[(int64_t)q * R + r];
-                run_first = rs.first[(int64_t)q * R + r];
-                run_end = q + 1 < nr ? rs.first[(int64_t)(q + 1) * R + r] : (int)c.cnt;
-            }
-            const int nq = nr - q0 < G ? nr - q0 : G;
-            for (int i = 0; i < nq; ++i) {
-                float base = __shfl(run_t0, gbase + i, 64);
-                const int first = __shfl(run_first, gbase + i, 64);
-                const int len = __shfl(run_end, gbase + i, 64) - first;
-                const float dt0 = march_dt(base, cone, step_size);
-                // A pass of a group covers 64 samples, FOUR CONSECUTIVE ONES PER LANE: every lane runs the pass's sequential adds (the
-                // only chain from one pass to the next: no shuffle) in blocks of 16, keeps the value after its own 4 gl steps and
-                // takes four more steps for its own samples — 63 + 4 adds, 15 selects and four 16-byte stores per 64 samples
-                // (the first form, one sample per lane and 16 per pass, spent 45 instructions per 16: 12.9 -> 7 us on the
-                // bench's longest ray).  Blocks beyond the run's end are skipped (group-uniform).
-                for (int j0 = 0; j0 < len; j0 += 4 * G) {
-                    const int rem = len - j0;
-                    float t = base, full = base;
-                    float sv[5];
-                    auto chain = [&](auto step) {            // (instantiated for the constant step and for the cone's clamp)
-#pragma unroll
-                        for (int blk = 0; blk < 4; ++blk) {
-                            if (blk == 0 || 16 * blk < rem) {
-#pragma unroll
-                                for (int l = 4 * blk; l < 4 * blk + 4; ++l) {
-                                    if (l > 0) { full = step(step(step(step(full)))); t = gl >= l ? full : t; }
-                                }
-                            }
-                        }
-                        if (rem > 4 * G) base = step(step(step(step(full))));
-                        sv[0] = t;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sv[e + 1] = step(sv[e]);
-                    };
-                    if (cone == 0.0f) chain([&](float x) { return x + dt0; });
-                    else chain([&](float x) { return x + march_dt(x, cone, step_size); });
-                    const int j = j0 + 4 * gl;              // this lane's first sample of the pass
-                    const int nv = rem - 4 * gl;            // its samples that exist (>= 4: all)
-                    if (nv <= 0) continue;
-                    const int64_t s = S + first + j;
-                    if (nv >= 4 && !a.iv_vals) {
-                        typedef float vf4 __attribute__((ext_vector_type(4)));
-                        if (a.t_starts) {
-                            const vf4 v0 = {sv[0], sv[1], sv[2], sv[3]}, v1 = {sv[1], sv[2], sv[3], sv[4]};
-                            __builtin_memcpy(a.t_starts + s, &v0, 16);
-                            __builtin_memcpy(a.t_ends + s, &v1, 16);
-                        }
-                        if (a.sm_vals) {
-                            const vf4 m = {(sv[1] + sv[0]) * 0.5f, (sv[2] + sv[1]) * 0.5f, (sv[3] + sv[2]) * 0.5f, (sv[4] + sv[3]) * 0.5f};
-                            __builtin_memcpy(a.sm_vals + s, &m, 16);
-                        }
-                        if (a.sm_ray_indices) {
-                            const int64_t rr[4] = {r, r, r, r};
-                            __builtin_memcpy(a.sm_ray_indices + s, rr, 32);
-                        }
-                        if (a.sm_is_valid) { const uint32_t ones = 0x01010101u; __builtin_memcpy(a.sm_is_valid + s, &ones, 4); }
-                        continue;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (e >= nv) break;
-                        const float t0 = sv[e], t1 = sv[e + 1];
-                        if (a.sm_vals) a.sm_vals[s + e] = (t1 + t0) * 0.5f;
-                        if (a.sm_ray_indices) a.sm_ray_indices[s + e] = r;
-                        if (a.sm_is_valid) a.sm_is_valid[s + e] = 1;
-                        if (a.t_starts) { a.t_starts[s + e] = t0; a.t_ends[s + e] = t1; }
-                        if (a.iv_vals) {
-                            // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
-                            const int64_t e_right = E + first + j + e + (q0 + i) + 1;
-                            a.iv_vals[e_right] = t1; a.iv_ray_indices[e_right] = r; a.iv_is_right[e_right] = 1;
-                            a.iv_is_left[e_right - 1] = 1;
-                            if (j + e == 0) { a.iv_vals[e_right - 1] = t0; a.iv_ray_indices[e_right - 1] = r; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// pass 2: ONE launch, the form chosen ON THE DEVICE from the totals the offsets kernel left in the workspace (the speculative
-// launch runs before the host has seen them).  16 lanes per ray pay per RUN (~25 instructions + a pass per 64 samples), a lane per
-// sample pays ~14 dependent loads per SAMPLE: the ray groups win on long runs and lose on a grid of alternating voxels (the
-// reference's `rand > 0.5` test grid: 271 samples per ray in ~130 runs — 113 vs 77 us at 4 k rays when the choice looked at the
-// sample count alone, profiles/r03_count_pass.md).  runs = edges - samples.  With a cone angle the sample-parallel form re-runs a
-// sample's chain from its run's start, so the ray groups take over at much shorter runs.
-//   hint: 0 = choose, 1 = ray groups, 2 = lane per sample (NFA_EMIT).  speculative: outputs hold `capacity` samples — a launch whose
-//   outputs are too small does nothing, the caller launches again with the right size.
-__global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
-                                                               const int64_t *__restrict__ n_dev, int speculative, int hint)
-{
-    const int64_t n_ed = n_dev[0], n_sm = n_dev[1];
-    if (speculative && n_sm > capacity) return;
-    const int64_t runs = n_ed - n_sm > 0 ? n_ed - n_sm : 1;
-    const bool long_runs = a.cone_angle != 0.0f ? n_sm >= 8 * runs : (n_sm >= 900000 && n_sm >= 20 * runs);
-    if (hint == 1 || (hint == 0 && long_runs)) emit_by_ray_groups(a, rs);
-    else emit_by_samples(a, rs, speculative ? n_sm : capacity);
-}
+#include "emit_pass.hpp"
 
 // generic exclusive sum of int64 counts (data_spec.hpp:86-106), single workgroup of 1024:
 // rounds of 1024 coalesced elements with a running carry.  Used for the per-ray count arrays
