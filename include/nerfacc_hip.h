@@ -45,6 +45,26 @@ const char *nfa_version(void);
 const char *nfa_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
+ * Options: which FORM of a kernel serves a call (lanes per ray, where the grid image lives, the emit form ...).
+ * Every form gives bit-identical results; the defaults ("auto") pick by size and grid kind.  The table is
+ * process-wide, reads and writes are atomic (safe against concurrent calls of any entry point), and the NFA_<NAME>
+ * environment variables seed it exactly once, when the library is loaded: no entry point reads the environment.
+ *   nfa_set_option(name, value)  name: "split_p" or "NFA_SPLIT_P" (case-insensitive); value: the text an environment
+ *                                variable would hold; NULL, "" or "auto" = back to automatic.  Unknown names and
+ *                                values outside the option's set are NFA_ERR_INVALID_ARG and change nothing.
+ *   nfa_get_option               *is_set = 0 while automatic; *value = the forced value (emit: 1 rays, 2 samples)
+ *   nfa_reset_options            every option back to its state at load time
+ *   nfa_option_count / _name / _doc   enumerate the table (names and one-line descriptions)
+ * No reference counterpart (the reference has one form per kernel).
+ * ------------------------------------------------------------------------------------- */
+int nfa_set_option(const char *name, const char *value);
+int nfa_get_option(const char *name, int64_t *value, int32_t *is_set);
+void nfa_reset_options(void);
+int32_t nfa_option_count(void);
+const char *nfa_option_name(int32_t index);
+const char *nfa_option_doc(int32_t index);
+
+/* ---------------------------------------------------------------------------------------
  * Grid: ray/AABB test and multi-level occupancy-grid traversal
  * ------------------------------------------------------------------------------------- */
 
@@ -334,8 +354,9 @@ int nfa_searchsorted(const nfa_ray_segments *query, const nfa_ray_segments *key,
                      int64_t *ids_left, int64_t *ids_right, void *stream);
 /* PropNetEstimator's map from normalised s in [0,1] to ray distance (prop_net.py:215-229, `_transform_stot`):
  * uniform (lindisp = 0): s t_max + (1 - s) t_min;  lindisp: 1 / (s / t_max + (1 - s) / t_min) — the reference's float
- * operations in the reference's order, one launch.  s_vals, t_vals: [n]. */
-int nfa_transform_stot(const float *s_vals, int64_t n, float t_min, float t_max, int32_t lindisp, float *t_vals, void *stream);
+ * operations in the reference's order, one launch.  s_vals, t_vals: [n].  t_min / t_max are doubles, as the Python floats the
+ * reference divides (`1.0 / t` in double, rounded to float once). */
+int nfa_transform_stot(const float *s_vals, int64_t n, double t_min, double t_max, int32_t lindisp, float *t_vals, void *stream);
 /* cdf at the n_samples + 1 edges of a proposal level from its densities, batched layout (prop_net.py:99-112:
  * render_transmittance_from_density, then 1 - cat([trans, 0])): cdfs[r, j] = 1 - exp(-sum_{i<j} sigma_i (t_{i+1} - t_i)) for
  * j < n_samples, cdfs[r, n_samples] = 1.  t_edges, cdfs: [n_rays, n_samples + 1]; sigmas, trans (nullable; what the backward

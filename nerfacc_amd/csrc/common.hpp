@@ -10,6 +10,7 @@
 #include <initializer_list>
 
 #include "../../include/nerfacc_hip.h"
+#include "options.hpp"
 
 #define NFA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -545,18 +546,15 @@ inline TilePlan pick_plan(int64_t n, bool vec_ok = true) {
     // rendering_bwd, which needs 170 VGPRs at 4 and runs 13-15 % faster at 2; at the training size (2.6e5 samples) it is 5-15 %
     // ahead of one per lane back to back, and below ~1e5 samples one per lane wins: profiles/r02_streaming.md)
     p.e = n >= ((int64_t)1 << 17) ? 2 : 1;
-    if (const char *s = getenv("NFA_E")) {               // tuning knobs
-        const int v = atoi(s);
-        if (v == 1 || v == 2 || v == 4) p.e = v;
-    }
+    p.e = (int)opt(OPT_E, p.e);                          // tuning knobs (options.hpp)
     if (!vec_ok) p.e = 1;
     const int64_t ch = 64 * p.e;
     const int64_t target_waves = (int64_t)kNumCU * 4 * 4;
     int64_t t = ceil_div(ceil_div(n, target_waves), ch) * ch;
     if (t < ch) t = ch;                                  // (the one-element-per-lane plan has the smallest tile: workspaces are sized by it)
     if (t > 9 * ch) t = 9 * ch;
-    if (const char *s = getenv("NFA_TILE")) {
-        const int64_t v = atoll(s);
+    {
+        const int64_t v = opt(OPT_TILE, t);
         if (v >= ch && v % ch == 0) t = v;
     }
     p.tile = t;

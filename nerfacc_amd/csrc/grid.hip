@@ -1081,7 +1081,7 @@ inline int cone_lanes_for_levels(int n_grids, int64_t n_rays) {
     int P = 2 * n_grids - 1 <= 8 ? 8 : 16;
     if (n_rays <= 2048) P = 64;
     else if (n_rays <= 8192) P = 32;
-    if (const char *e = getenv("NFA_CONE_P")) { const int v = atoi(e); if ((v == 8 && 2 * n_grids - 1 <= 8) || v == 16 || v == 32 || v == 64) P = v; }
+    { const int v = (int)opt(OPT_CONE_P, 0); if ((v == 8 && 2 * n_grids - 1 <= 8) || v == 16 || v == 32 || v == 64) P = v; }
     return P;
 }
 inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
@@ -1097,7 +1097,7 @@ static int cone_lanes_per_ray(const nfa_traverse_args *a) {
     if (!(a->step_size > 0.0f) || a->cone_angle == 0.0f) return 0;
     if (a->t_sorted || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
     const int64_t max_rays = 32768;       // beyond, a lane per ray fills the chip (and the voxel planes grow with the ray count)
-    if (const char *e = getenv("NFA_CONE")) { if (atoi(e) == 0) return 0; }
+    if (opt(OPT_CONE, 1) == 0) return 0;
     if (a->n_rays > max_rays) return 0;
     if (a->workspace_bytes < ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a)) return 0;
     return cone_lanes_for_levels(a->n_grids, a->n_rays);
@@ -1248,9 +1248,8 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
             else if (a->n_rays <= 36864) P = 4;
             else if (a->n_rays <= 65536) P = 2;
         }
-        if (const char *e = getenv("NFA_SPLIT_P")) {          // tuning knob: 1, 2, 4, 8 or 16
-            const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) P = v;
+        if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
+            P = (int)opt(OPT_SPLIT_P, P);
             if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for sparse grids: they never won)
         }
     }
@@ -1274,14 +1273,14 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     if (!lattice || a->t_sorted || a->n_grids < 2 || a->traverse_steps_limit > 0 || a->rays_mask) return 0;
     const int64_t max_rays = 40960;     // (r03: with the ray-group emit pass behind it the call is 213 vs 285 us at 32 k rays, 383 vs 312 at 65 k)
-    if (const char *e = getenv("NFA_SEGMENTS")) { if (atoi(e) == 0) return 0; }
+    if (opt(OPT_SEGMENTS, 1) == 0) return 0;
     if (a->n_rays > max_rays) return 0;
     int P = 2 * a->n_grids - 1 <= 8 ? 8 : 16;
     // 32 lanes per ray = 4 per segment slot (parts) while the launch has lanes to spare and the caller's workspace holds the
     // crossing-time arrays (nfa_traverse_workspace_bytes_for); NFA_SEG_P = 8 | 32 overrides
     const bool room = a->workspace_bytes >= ws_voxels_offset(a->n_rays) + seg_parts_bytes(a);
     if (P == 8 && room && a->n_rays <= 4096) P = 32;
-    if (const char *e = getenv("NFA_SEG_P")) { const int v = atoi(e); if (v == 8 && P == 32) P = 8; else if (v == 32 && P == 8 && room) P = 32; }
+    { const int v = (int)opt(OPT_SEG_P, 0); if (v == 8 && P == 32) P = 8; else if (v == 32 && P == 8 && room) P = 32; }
     return P;
 }
 static SplitPlan plan_split(const nfa_traverse_args *a) {
@@ -1325,9 +1324,9 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     // image: 37.7 vs 39.6 us at 6.5 k rays; below ~3 k rays the 256-thread form spreads over more CUs and wins);
     // NFA_SPLIT_BLK = 256 | 512 overrides
     if (p.P == 16 && p.cap == 16 && a->n_rays >= 3072) p.blk = 512;
-    if (const char *e = getenv("NFA_SPLIT_BLK")) { const int v = atoi(e); if (v == 256 || (v == 512 && p.P == 16 && p.cap == 16)) p.blk = v; }
+    { const int v = (int)opt(OPT_SPLIT_BLK, 0); if (v == 256 || (v == 512 && p.P == 16 && p.cap == 16)) p.blk = v; }
     // crossing-time arrays (512-thread form only; NFA_SPLIT_XT = 0 switches them off)
-    p.xt = p.blk == 512 && !(getenv("NFA_SPLIT_XT") && atoi(getenv("NFA_SPLIT_XT")) == 0);
+    p.xt = p.blk == 512 && opt(OPT_SPLIT_XT, 1) != 0;
     const int xt_bytes = p.xt ? (p.blk / p.P) * (a->res[0] + a->res[1] + a->res[2] + 3) * 4 : 0;
     // (the 512-thread form is alone on its CU: it may take the whole 160 KB)
     const int budget = p.blk == 512 ? 156 * 1024 : kLdsBudget;
@@ -1346,7 +1345,7 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     // 50 k; also staging the 4 KB bitmap of non-empty bricks is 2-3 % slower than leaving everything in L2).
     // NFA_SPLIT_L2 = 0 | 1 overrides
     bool l2 = a->n_rays > 8192;
-    if (const char *e = getenv("NFA_SPLIT_L2")) l2 = atoi(e) != 0;
+    l2 = opt(OPT_SPLIT_L2, l2) != 0;
     if (p.P == 8) l2 = true;                       // (no 8-lane instance with the image in LDS any more: it never wins)
     if (l2) {
         p.l2 = 1;
@@ -1439,7 +1438,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     // NFA_COUNT_L2 = 0 | 1 overrides
     {
         bool l2 = gv.lds_compact_cap > 0 && (int64_t)nb > (int64_t)kNumCU * (kLdsPerCU / (lds > 0 ? lds : 1));
-        if (const char *e = getenv("NFA_COUNT_L2")) l2 = atoi(e) != 0;
+        l2 = opt(OPT_COUNT_L2, l2) != 0;
         if (l2) gv = make_view(a, kEvBytes, &lds, 0);
     }
     const bool lds_occ = gv.lds_compact_cap > 0;
@@ -1490,7 +1489,7 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
     {   // (image in LDS only while one round of workgroups holds every ray, as in nfa_traverse_count)
         bool l2 = gv.lds_compact_cap > 0 && (int64_t)nb > (int64_t)kNumCU * (kLdsPerCU / (lds > 0 ? lds : 1));
-        if (const char *e = getenv("NFA_COUNT_L2")) l2 = atoi(e) != 0;
+        l2 = opt(OPT_COUNT_L2, l2) != 0;
         if (l2) gv = make_view(a, 0, &lds, 0);
     }
     const int evm = a->t_sorted ? EV_PRE : (a->n_grids == 1 ? EV_ONE : EV_MANY);
@@ -1510,8 +1509,7 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
 
 // NFA_EMIT = rays | samples forces a form of the emit pass (traverse_emit_kernel chooses otherwise)
 static int emit_hint() {
-    if (const char *e = getenv("NFA_EMIT")) return e[0] == 'r' ? 1 : 2;
-    return 0;
+    return (int)opt(OPT_EMIT, 0);
 }
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;

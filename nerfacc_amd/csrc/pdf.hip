@@ -279,13 +279,14 @@ NFA_EXPORT int nfa_edge_cdfs_bwd(const float *t_edges, const float *trans, const
     return check_launch("edge_cdfs_bwd_kernel");
 }
 
-NFA_EXPORT int nfa_transform_stot(const float *s_vals, int64_t n, float t_min, float t_max, int32_t lindisp, float *t_vals, void *stream)
+NFA_EXPORT int nfa_transform_stot(const float *s_vals, int64_t n, double t_min, double t_max, int32_t lindisp, float *t_vals, void *stream)
 {
     NFA_REQUIRE(n >= 0, "transform_stot: n < 0");
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(s_vals && t_vals, "transform_stot: NULL pointer");
-    // (the scalars as torch forms them: 1 / t in double, then rounded to float when it meets the float tensor)
-    const float c_max = lindisp ? (float)(1.0 / (double)t_max) : t_max, c_min = lindisp ? (float)(1.0 / (double)t_min) : t_min;
+    // (the scalars as torch forms them: 1 / t in double FROM THE CALLER'S DOUBLE, rounded to float once, when it meets the float
+    // tensor — a float parameter would round t first and differ by an ulp for ~27 % of scalars: t = 1e-3 gave 999.99994)
+    const float c_max = lindisp ? (float)(1.0 / t_max) : (float)t_max, c_min = lindisp ? (float)(1.0 / t_min) : (float)t_min;
     hipLaunchKernelGGL(transform_stot_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, s_vals, n, c_max, c_min,
                        (int)lindisp, t_vals);
     return check_launch("transform_stot_kernel");

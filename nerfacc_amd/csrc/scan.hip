@@ -241,7 +241,7 @@ void launch_packed(const int64_t *starts, const int64_t *cnts, int64_t n_rows, c
                    const float *mul, const float *div, float *out, int reverse, int normalize, hipStream_t s) {
     // rows per wave: 4 (a row per group) until the launch has ~8 k waves of 16; NFA_SCAN_RW = 4 | 16 overrides
     int rw = n_rows >= 16 * 8192 ? 16 : 4;
-    if (const char *e = getenv("NFA_SCAN_RW")) { const int v = atoi(e); if (v == 4 || v == 16) rw = v; }
+    rw = (int)opt(OPT_SCAN_RW, rw);
     const unsigned nb = blocks_for(ceil_div(n_rows, rw) * kWave);
     hipLaunchKernelGGL((scan_packed_kernel<Op, INCL>), dim3(nb), dim3(kBlock), 0, s, starts, cnts, n_rows, in, mul, div, out,
                        reverse, normalize, rw);

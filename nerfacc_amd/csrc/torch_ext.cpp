@@ -39,6 +39,14 @@ inline void check_rc(int rc) {
     TORCH_CHECK(rc == NFA_OK, "nerfacc_amd: ", nfa_last_error());
 }
 
+// the library's option table (nfa_set_option): 0 = launch the emit pass after the read-back of the totals
+inline bool speculative_emit_allowed() {
+    int64_t v = 1;
+    int32_t is_set = 0;
+    nfa_get_option("speculative_emit", &v, &is_set);
+    return !is_set || v != 0;
+}
+
 inline void check_input(const Tensor &t, const char *name, std::optional<at::ScalarType> dtype = std::nullopt) {
     TORCH_CHECK(t.defined(), name, " is undefined");
     TORCH_CHECK(t.is_cuda(), name, " must be a CUDA/HIP tensor (nerfacc_amd has no CPU kernels)");
@@ -538,7 +546,7 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     // marcher rounds differ by orders of magnitude in size but much less in samples per ray), times this call's ray count.
     thread_local std::map<int, double> last_spr;
     const int dev = rays_o.device().index() * 4 + (rays_mask.has_value() ? 1 : 0) + (traverse_steps_limit > 0 ? 2 : 0);
-    const bool speculate = R > 0 && last_spr.count(dev) && last_spr[dev] > 0.0 && !getenv("NFA_NO_SPECULATIVE_EMIT");
+    const bool speculate = R > 0 && last_spr.count(dev) && last_spr[dev] > 0.0 && speculative_emit_allowed();
     int64_t cap = speculate ? (int64_t)(1.25 * last_spr[dev] * (double)R) + 1024 : 0;
     Tensor ray_indices;
     Rows ts(2, cap, f32);
@@ -673,7 +681,7 @@ Tensor transform_stot(const Tensor &s_vals, double t_min, double t_max, bool lin
     Tensor t = at::empty_like(s_vals);
     Guard g(device_of(s_vals));
     // (the reference's scalars are Python floats: 1 / t is formed in double inside the library call)
-    check_rc(nfa_transform_stot(ptr<float>(s_vals), s_vals.numel(), (float)t_min, (float)t_max, lindisp ? 1 : 0, ptr<float>(t), stream_of(s_vals)));
+    check_rc(nfa_transform_stot(ptr<float>(s_vals), s_vals.numel(), t_min, t_max, lindisp ? 1 : 0, ptr<float>(t), stream_of(s_vals)));
     return t;
 }
 

@@ -29,81 +29,13 @@ LIB_PATH = os.environ.get("NERFACC_AMD_LIB") or os.path.join(_PKG, "libnerfacc_h
 NFA_OP_SUM, NFA_OP_PROD = 0, 1
 
 
-class _TraverseArgs(ctypes.Structure):
-    """struct nfa_traverse_args (include/nerfacc_hip.h)."""
+# struct layouts and prototypes come from include/nerfacc_hip.h itself (_cabi.parse_header): the header is the only
+# place where an entry point's signature is written down
+from ._cabi import HEADER_PATH, parse_header  # noqa: E402
 
-    _fields_ = [
-        ("n_rays", c_int64), ("rays_o", c_void_p), ("rays_d", c_void_p), ("rays_mask", c_void_p),
-        ("n_grids", c_int32), ("res", c_int32 * 3), ("bricks", c_void_p), ("n_nonempty_bricks", c_int64),
-        ("aabbs", c_void_p),
-        ("hits", c_void_p), ("t_sorted", c_void_p), ("t_indices", c_void_p),
-        ("near_planes", c_void_p), ("far_planes", c_void_p),
-        ("step_size", c_float), ("cone_angle", c_float), ("traverse_steps_limit", c_int32),
-        ("iv_cnts", c_void_p), ("iv_starts", c_void_p), ("sm_cnts", c_void_p), ("sm_starts", c_void_p),
-        ("totals", c_void_p),
-        ("iv_vals", c_void_p), ("iv_ray_indices", c_void_p), ("iv_is_left", c_void_p), ("iv_is_right", c_void_p),
-        ("sm_vals", c_void_p), ("sm_ray_indices", c_void_p), ("sm_is_valid", c_void_p),
-        ("t_starts", c_void_p), ("t_ends", c_void_p), ("terminate_planes", c_void_p),
-        ("near_plane", c_float), ("far_plane", c_float), ("t_min", c_void_p), ("t_max", c_void_p),
-        ("jitter", c_void_p), ("jitter_scale", c_float), ("workspace_bytes", c_int64),
-    ]
-
-
-class _RaySegments(ctypes.Structure):
-    """struct nfa_ray_segments (include/nerfacc_hip.h)."""
-
-    _fields_ = [
-        ("vals", c_void_p), ("chunk_starts", c_void_p), ("chunk_cnts", c_void_p), ("ray_indices", c_void_p),
-        ("n_edges", c_int64), ("n_rays", c_int64), ("n_edges_per_ray", c_int64),
-    ]
-
-
-_P = c_void_p
-_SIGNATURES = {
-    # name: (restype, argtypes)
-    "nfa_version": (ctypes.c_char_p, []),
-    "nfa_last_error": (ctypes.c_char_p, []),
-    "nfa_ray_aabb_intersect": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, c_float, c_float, c_float, _P, _P, _P, _P]),
-    "nfa_packed_grid_words": (c_int64, [c_int32] * 4),
-    "nfa_pack_binaries": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "nfa_grid_cell_points": (ctypes.c_int, [_P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
-    "nfa_grid_ema_update": (ctypes.c_int, [_P, _P, c_int64, _P, c_float, _P, _P]),
-    "nfa_grid_mark_invisible": (ctypes.c_int, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int32, c_int32,
-                                               c_float, c_float, c_float, _P]),
-    "nfa_grid_threshold_workspace_bytes": (c_int64, []),
-    "nfa_grid_threshold": (ctypes.c_int, [_P, c_int64, c_float, _P, _P, _P, _P]),
-    "nfa_grid_threshold_packed": (ctypes.c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P]),
-    "nfa_traverse_workspace_bytes": (c_int64, [c_int64]),
-    "nfa_traverse_workspace_bytes_for": (c_int64, [_P]),
-    "nfa_traverse_count": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
-    "nfa_traverse_offsets": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, _P]),
-    "nfa_traverse_offsets_stamped": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), _P, c_int64, _P]),    # (extension only)
-    "nfa_traverse_fill": (ctypes.c_int, [ctypes.POINTER(_TraverseArgs), c_int32, c_int32, _P, c_int64, c_int64, _P]),
-    "nfa_traverse_emit_speculative": (ctypes.c_int, [_P, _P, c_int64, _P]),    # (used by the extension only)
-    "nfa_exclusive_sum_i64": (ctypes.c_int, [_P, c_int64, _P, _P, _P]),
-    "nfa_pack_info": (ctypes.c_int, [_P, c_int64, c_int64, _P, _P]),
-    "nfa_unpack_info": (ctypes.c_int, [_P, _P, c_int64, _P, c_int64, _P]),
-    "nfa_scan_packed": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
-    "nfa_scan_keyed": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
-    "nfa_prod_backward": (ctypes.c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P]),
-    "nfa_render_weight_from_density_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
-    "nfa_render_weight_from_density_bwd": (ctypes.c_int, [_P] * 9 + [c_int64, _P, _P]),
-    "nfa_sample_positions": (ctypes.c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
-    "nfa_visibility_workspace_bytes": (c_int64, [c_int64]),
-    "nfa_visibility_compact": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
-    "nfa_visibility_compact_stamped": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P]),    # (extension only)
-    "nfa_accumulate_along_rays": (ctypes.c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P]),
-    "nfa_accumulate_along_rays_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P]),
-    "nfa_rendering_fwd": (ctypes.c_int, [_P] * 5 + [c_int64, c_int64, _P, c_int32] + [_P] * 7),
-    "nfa_rendering_bwd": (ctypes.c_int, [_P] * 10 + [c_int64, c_int64, _P, c_int32] + [_P] * 9),
-    "nfa_importance_sampling": (ctypes.c_int, [ctypes.POINTER(_RaySegments), _P, c_int64, _P, _P, _P, _P]),
-    "nfa_searchsorted": (ctypes.c_int, [ctypes.POINTER(_RaySegments), ctypes.POINTER(_RaySegments), _P, _P, _P]),
-    "nfa_transform_stot": (ctypes.c_int, [_P, c_int64, c_float, c_float, c_int32, _P, _P]),
-    "nfa_edge_cdfs_fwd": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
-    "nfa_edge_cdfs_bwd": (ctypes.c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
-    "nfa_pdf_loss_fwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_float, _P, _P, _P, _P, _P]),
-    "nfa_pdf_loss_bwd": (ctypes.c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, _P, _P]),
-}
+_STRUCTS, _SIGNATURES = parse_header()
+_TraverseArgs = _STRUCTS["nfa_traverse_args"]
+_RaySegments = _STRUCTS["nfa_ray_segments"]
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

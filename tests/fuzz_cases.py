@@ -142,18 +142,21 @@ def check_fused(case, env_name, env_values):
     live = r_sm["packed_info"][:, 1] > 0         # (the reference leaves the terminate plane of a ray without samples unwritten)
     args = (T(c["o"]), T(c["d"]), T(c["occ"]), T(c["aabbs"]), T(c["near"]), T(c["far"]), c["step"], c["cone"])
     bad = []
-    # env_name None: every value is a list of assignments, "NFA_A=1,NFA_B=2"
+    # env_name None: every value is a list of assignments, "NFA_A=1,NFA_B=2".  (The names are the library's options —
+    # nerfacc_amd.set_option accepts the NFA_ spelling; nothing goes through the environment.)
+    import nerfacc_amd
+
     names = [env_name] if env_name else sorted({kv.split("=")[0] for v in env_values for kv in v.split(",") if kv})
-    saved = {k: os.environ.get(k) for k in names}
+    saved = {k: nerfacc_amd.get_option(k) for k in names}
     try:
         for v in env_values:
             for k in names:
-                os.environ.pop(k, None)
+                nerfacc_amd.set_option(k, None)
             if env_name and v:
-                os.environ[env_name] = v
+                nerfacc_amd.set_option(env_name, v)
             elif not env_name:
                 for kv in filter(None, v.split(",")):
-                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
+                    nerfacc_amd.set_option(kv.split("=")[0], kv.split("=")[1])
             ri, ts, te, pk, term = C.sample_occgrid(*args, with_terminate_planes=True)
             diff = [k for k, same in (("ray_indices", np.array_equal(_n(ri), r_ri)), ("t_starts", np.array_equal(_n(ts), r_ts)),
                                       ("t_ends", np.array_equal(_n(te), r_te)), ("packed_info", np.array_equal(_n(pk), r_sm["packed_info"])),
@@ -162,10 +165,7 @@ def check_fused(case, env_name, env_values):
                 bad.append(f"{c['desc']} {env_name or ''}{'=' if env_name else ''}{v or 'auto'}: {diff} differ ({len(r_ri)} oracle samples, {ri.shape[0]} here)")
     finally:
         for k, old in saved.items():
-            if old is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = old
+            nerfacc_amd.set_option(k, old)
     return bad, len(r_ri)
 
 
@@ -195,17 +195,12 @@ def api_case(g, ray_counts=(3, 100, 2000, 12000)):
 def check_api(case, emit_forms=("rays", "samples")):
     """nerfacc_amd.grid.traverse_grids under both emit kernels vs the oracle, every output"""
     bad, n = [], 0
-    saved = os.environ.get("NFA_EMIT")
-    try:
-        for v in emit_forms:
-            os.environ["NFA_EMIT"] = v
+    import nerfacc_amd
+
+    for v in emit_forms:
+        with nerfacc_amd.options(emit=v):
             b, n = _check_api(case)
-            bad += [f"{line} (NFA_EMIT={v})" for line in b]
-    finally:
-        if saved is None:
-            os.environ.pop("NFA_EMIT", None)
-        else:
-            os.environ["NFA_EMIT"] = saved
+        bad += [f"{line} (emit={v})" for line in b]
     return bad, n
 
 

@@ -130,6 +130,11 @@ def main():
         if not full:
             fixture[f"{name}/cnts/sm_chunk_cnts"] = out["sm_chunk_cnts"].astype(np.int32)
             fixture[f"{name}/cnts/iv_chunk_cnts"] = out["iv_chunk_cnts"].astype(np.int32)
+        if not c["kw"].get("over_allocate"):
+            # what OccGridEstimator.sampling returns from these outputs (the reference's occ_grid.py:174-175):
+            # t_starts = vals[is_left], t_ends = vals[is_right] — digests, for the fused sampling path's test (round 4)
+            fixture[f"{name}/sha/t_starts"] = np.array(K.sha(out["iv_vals"][out["iv_is_left"]]))
+            fixture[f"{name}/sha/t_ends"] = np.array(K.sha(out["iv_vals"][out["iv_is_right"]]))
         print(f"{name:20s} rays {R:6d} samples {n_samples:8d}  off!=fma {d_builds:4d}  oracle!=off {d_orc_off:4d}  oracle!=fma {d_orc_fma:4d}  ({'full' if full else 'digests'})")
 
     # ---- K1 through the reference's own kernel as well (tests/test_grid.py:7-35 generator: seed 42, 1000 rays x 100 boxes) ----

@@ -118,8 +118,13 @@ def _case(name):
         aabbs = np.array([[0, 0, 0, 1, 1, 1]], np.float32)
         binaries = _sphere_grid((128,) * 3, 0.0, 1.0, (0.5,) * 3, 0.3)[None]
         kw = dict(step_size=5e-3 / 3)
-    elif name in ("lego_4k", "lego_70k"):
-        o, d, aabbs, binaries = _lego(rng, 4096 if name == "lego_4k" else 70000)
+    elif name in ("lego_4k", "lego_70k", "lego_12k", "lego_160k"):
+        # ray counts on either side of every ray-count switch of the one-level count pass: 4 k (16 lanes per ray, grid image in
+        # LDS), 12 k (16 lanes, image from L2 — 8 k..16 k rays), 70 k (8 lanes), 160 k (a lane per ray, image from L2)
+        o, d, aabbs, binaries = _lego(rng, {"lego_4k": 4096, "lego_12k": 12288, "lego_70k": 70000, "lego_160k": 160000}[name])
+        kw = dict(step_size=5e-3)
+    elif name == "lego_256":          # configs[4]'s shape: ONE level of 256^3 (the dense brick array is read from L2)
+        o, d, aabbs, binaries = _lego(rng, 4096, res=256)
         kw = dict(step_size=5e-3)
     elif name == "two_level_256":     # C5-sized levels: 2 x 256^3
         o, d, aabbs, b0 = _lego(rng, 2048, res=256)
@@ -179,7 +184,8 @@ def _case(name):
 
 # "ref_test_grid" (tests/test_grid.py:38-68 with torch's CPU generator, seed 42) stores its inputs in the fixture
 GENERATED = ["m1_noise", "m1_sphere", "lego_4k", "lego_70k", "two_level_256", "cone_angle", "cone_angle_levels",
-             "per_voxel", "steps_limit", "over_allocate", "near_far", "non_cubic", "degenerate", "levels4_inside"]
+             "per_voxel", "steps_limit", "over_allocate", "near_far", "non_cubic", "degenerate", "levels4_inside",
+             "lego_256", "lego_12k", "lego_160k"]            # (the last three: round 4)
 ALL = ["ref_test_grid"] + GENERATED
 GPU_RULE = ["in_plane", "in_plane_one_level", "in_plane_four_levels"]     # tests/golden/k2_inplane.npz: the reference built with the GPU's float -> int conversion rule
 FULL_LIMIT = 30000      # cases with fewer samples keep every output array in the fixture; the others digests

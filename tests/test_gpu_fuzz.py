@@ -121,15 +121,15 @@ def test_many_transitions_overflow_paths():
         assert np.array_equal(n(pk), r_pk)
         return len(r_ri)
 
-    try:
-        for p in ("2", "4", "8", "16", "1"):
-            os.environ["NFA_SPLIT_P"] = p
+    import nerfacc_amd
+
+    for p in (2, 4, 8, 16, 1):
+        with nerfacc_amd.options(split_p=p):
             assert fused(o2, d2.astype(np.float32), noise, box, float(np.float32(5e-3 / 3))) > 100000
             assert fused(o, d, g[None], aabbs, 2e-3) > 0
-    finally:
-        os.environ.pop("NFA_SPLIT_P", None)
 
 
+@pytest.mark.randomised
 def test_randomised_fuzz_time_boxed():
     """A fresh seed from the clock on every run (printed on failure; NFA_FUZZ_SEED replays it), ~24 s of the long campaigns'
     generators (tests/fuzz_cases.py): one-level grids under every lanes-per-ray form of the count pass, several levels under

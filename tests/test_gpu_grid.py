@@ -189,7 +189,7 @@ def test_sampling_many_rays_serial_and_split_walks_agree():
 
 
 @pytest.mark.parametrize("levels,res,kind", [(2, 32, "blob"), (4, 32, "blob"), (4, 16, "noise"), (5, 24, "noise"), (8, 8, "blob"), (3, (20, 33, 7), "noise")])
-def test_sampling_multi_level_segment_and_serial_count_passes(monkeypatch, levels, res, kind):
+def test_sampling_multi_level_segment_and_serial_count_passes(force_options, levels, res, kind):
     """several levels, cone_angle = 0: the count pass with one lane per LEVEL SEGMENT of a ray (grid.hip:
     traverse_count_segments_kernel; 8 lanes per ray up to 4 levels, 16 up to 8) and the lane-per-ray one must both give the oracle's
     samples, packed_info and terminate planes bit for bit — rays from inside the first level, from outside everything and
@@ -221,8 +221,8 @@ def test_sampling_multi_level_segment_and_serial_count_passes(monkeypatch, level
     r_ts, r_te = r_iv["vals"][r_iv["is_left"]], r_iv["vals"][r_iv["is_right"]]
     assert r_sm["ray_indices"].shape[0] > 2000
     live = r_sm["packed_info"][:, 1] > 0               # (rays without samples: the reference leaves their terminate plane unwritten)
-    for seg in ("1", "0"):
-        monkeypatch.setenv("NFA_SEGMENTS", seg)
+    for seg in (1, 0):
+        force_options(segments=seg)
         ri, ts, te, pk, term = C.sample_occgrid(t(o), t(d), t(occ), t(aabbs), t(near), t(far), step, 0.0, with_terminate_planes=True)
         assert np.array_equal(n(ri), r_sm["ray_indices"]) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)
         assert np.array_equal(n(pk), r_sm["packed_info"])
@@ -277,7 +277,7 @@ def test_sample_positions_bit_identical_to_the_torch_expression():
     assert nerfacc.sample_positions(o, d, ri[:0], ts[:0], te[:0]).shape == (0, 3)
 
 
-def test_emit_form_chosen_on_the_device_is_near_the_better_one(monkeypatch):
+def test_emit_form_chosen_on_the_device_is_near_the_better_one(force_options):
     """the emit pass picks its form from the call's totals (samples per run, emit_pass.hpp).  Two scenes pull in opposite directions:
     the reference's `rand > 0.5` test grid (tests/test_grid.py: hundreds of two-sample runs per ray — 16 lanes per ray lose by 4x)
     and a blob crossed by 40 k rays (1.5 M samples in long runs — they win).  The automatic choice must stay within 30 % of the
@@ -302,7 +302,7 @@ def test_emit_form_chosen_on_the_device_is_near_the_better_one(monkeypatch):
         near, far = torch.zeros(o.shape[0], device=DEV), torch.full((o.shape[0],), 1e10, device=DEV)
         us, outs = {}, {}
         for form in ("", "rays", "samples"):
-            monkeypatch.setenv("NFA_EMIT", form) if form else monkeypatch.delenv("NFA_EMIT", raising=False)
+            force_options(emit=form or None)
             for _ in range(3):
                 outs[form] = C.sample_occgrid(o, d, occ, aabb, near, far, step, 0.0)
             torch.cuda.synchronize()

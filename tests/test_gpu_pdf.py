@@ -101,7 +101,7 @@ def test_transform_stot_is_the_torch_expression_bit_for_bit():
     from nerfacc_amd.estimators.prop_net import _transform_stot
 
     s = torch.cat([torch.rand(4096, 257, device=DEV), torch.tensor([[0.0, 1.0] + [0.5] * 255], device=DEV)])
-    for t_min, t_max in ((0.2, 1e3), (2.0, 6.0), (0.05, 1e10)):
+    for t_min, t_max in ((0.2, 1e3), (2.0, 6.0), (0.05, 1e10), (1e-3, 0.3), (0.3, 1e-3), (0.7, 3.3)):      # (1e-3, 0.3: float(1/double(t)) != 1/float(t))
         want_u = s * t_max + (1 - s) * t_min
         want_l = 1 / (s * (1 / t_max) + (1 - s) * (1 / t_min))
         assert torch.equal(_transform_stot("uniform", s, t_min, t_max), want_u)

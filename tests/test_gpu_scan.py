@@ -102,11 +102,11 @@ def test_empty_and_cpu_inputs():
         S.inclusive_sum(torch.rand(4), indices=torch.zeros(4, dtype=torch.long))
 
 
-@pytest.mark.parametrize("rw", ["4", "16"])
-def test_packed_scan_rows_dealt_to_groups(monkeypatch, rw):
+@pytest.mark.parametrize("rw", [4, 16])
+def test_packed_scan_rows_dealt_to_groups(force_options, rw):
     """the packed scan deals a wave's rows to its four 16-lane groups as they finish (scan.hip): both group sizes, rows of very
     different lengths and many empty rows, against the oracle — forward, reverse (the backward pass) and normalised"""
-    monkeypatch.setenv("NFA_SCAN_RW", rw)
+    force_options(scan_rw=rw)
     for args in ((9, 3, 1), (700, 150, 2), (5, 3000, 3), (50000, 9, 4), (333, 700, 5)):
         test_ragged_vs_oracle(*args)
     for name in ("inclusive_sum", "exclusive_prod"):

@@ -1,6 +1,6 @@
 """The tiled streaming kernels (common.hpp: walk_rays_fwd / walk_rays_bwd) under every launch plan: 1 / 2 / 4 elements
 per lane, one-chunk and multi-chunk tiles, unaligned views (fall back to one element per lane).  The default plans only
-reach E = 4 at N >= 2^22; the NFA_E / NFA_TILE knobs (read per call) force the others onto the small oracle-checked cases."""
+reach E = 4 at N >= 2^22; the `e` / `tile` options (nerfacc_amd.set_option) force the others onto the small oracle-checked cases."""
 import numpy as np
 import pytest
 import torch
@@ -13,9 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("e,tile", [(1, 64), (1, 192), (2, 128), (2, 384), (4, 256), (4, 768)])
-def test_every_plan_vs_oracle(monkeypatch, e, tile):
-    monkeypatch.setenv("NFA_E", str(e))
-    monkeypatch.setenv("NFA_TILE", str(tile))
+def test_every_plan_vs_oracle(force_options, e, tile):
+    force_options(e=e, tile=tile)
     for args in ((7, 5, 1), (500, 90, 2), (3000, 700, 3), (3, 5000, 4), (20000, 12, 5)):
         test_gpu_volrend.test_ragged_vs_oracle_fwd_bwd(*args)
     for args in ((9, 3, 1), (700, 150, 2), (5, 3000, 3), (20000, 9, 4)):
@@ -27,16 +26,16 @@ def test_every_plan_vs_oracle(monkeypatch, e, tile):
 
 
 @pytest.mark.parametrize("e", [2, 4])
-def test_large_n_properties_vectorised(monkeypatch, e):
-    monkeypatch.setenv("NFA_E", str(e))
+def test_large_n_properties_vectorised(force_options, e):
+    force_options(e=e)
     test_gpu_volrend.test_large_n_properties()
 
 
-def test_unaligned_views_equal_aligned(monkeypatch):
+def test_unaligned_views_equal_aligned(force_options):
     """views whose storage offset is not a multiple of 16 bytes take the one-element plan: same results"""
     from nerfacc_amd import cuda as C
 
-    monkeypatch.setenv("NFA_E", "4")
+    force_options(e=4)
     rng = np.random.default_rng(0)
     ri_, _ = ragged(rng, 4000, 60)
     N = ri_.shape[0]
@@ -64,7 +63,7 @@ def test_unaligned_views_equal_aligned(monkeypatch):
 
 
 @pytest.mark.parametrize("speculative", [True, False])
-def test_sampling_with_and_without_the_speculative_emit(monkeypatch, speculative):
+def test_sampling_with_and_without_the_speculative_emit(force_options, speculative):
     """sample_occgrid launches its emit pass before the read-back of the totals, into outputs sized from the previous call;
     too small a guess must fall back to exactly sized outputs, and both orders must reproduce the reference's sample lists"""
     import os
@@ -72,11 +71,11 @@ def test_sampling_with_and_without_the_speculative_emit(monkeypatch, speculative
     import test_k2_reference as T
 
     if not speculative:
-        monkeypatch.setenv("NFA_NO_SPECULATIVE_EMIT", "1")
+        force_options(speculative_emit=0)
     k2 = dict(np.load(os.path.join(T.GOLD, "k2_reference.npz")))
     # small -> large -> small: the guess is too small for the second case and generous for the third
     for name in ["degenerate", "lego_4k", "lego_70k", "m1_sphere", "near_far", "lego_4k"]:
-        T.test_hip_sampling_reproduces_reference_k2(name, k2)
+        T._sampling_vs_fixture(name, k2)
 
 
 def test_packed_scans_over_arbitrary_row_tables():
@@ -139,8 +138,8 @@ def test_packed_scan_at_scale_equals_keyed():
     assert torch.allclose(p, q, rtol=1e-4, atol=1e-30)
 
 
-@pytest.mark.parametrize("env", [{"NFA_SPLIT_BLK": "512"}, {"NFA_SPLIT_BLK": "512", "NFA_SPLIT_XT": "0"}, {"NFA_SPLIT_BLK": "256"}])
-def test_count_pass_workgroup_forms(monkeypatch, env):
+@pytest.mark.parametrize("env", [{"split_blk": 512}, {"split_blk": 512, "split_xt": 0}, {"split_blk": 256}])
+def test_count_pass_workgroup_forms(force_options, env):
     """the 16-lanes-per-ray count pass runs in 256-thread workgroups (closed-form seam restart), in 512-thread ones, and in
     512-thread ones with the plane-crossing times written out in LDS (default from 3 k rays): every form on the adversarial
     fuzz cases, the degenerate grids, the overflow paths and the reference fixture"""
@@ -150,9 +149,7 @@ def test_count_pass_workgroup_forms(monkeypatch, env):
     import test_gpu_grid as G
     import test_k2_reference as T
 
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    monkeypatch.setenv("NFA_SPLIT_P", "16")
+    force_options(split_p=16, **env)
     for seed in range(6):
         F.test_fuzz_single_level(seed, 700)
     F.test_fuzz_degenerate_grids()
@@ -161,6 +158,6 @@ def test_count_pass_workgroup_forms(monkeypatch, env):
     G.test_traverse_near_far_single_cell()
     k2 = dict(np.load(os.path.join(T.GOLD, "k2_reference.npz")))
     for name in ["m1_sphere", "lego_4k", "near_far", "degenerate"]:
-        T.test_hip_sampling_reproduces_reference_k2(name, k2)
+        T._sampling_vs_fixture(name, k2)
     for name in ["ref_test_grid", "m1_noise", "lego_4k", "non_cubic", "steps_limit"]:
         T.test_hip_reproduces_reference_k2(name, k2)

@@ -32,6 +32,60 @@ def test_library_exports_every_declared_symbol():
     assert lib.nfa_version().decode().startswith("nerfacc_hip ")
 
 
+def test_ctypes_prototypes_are_generated_from_the_header():
+    """the ctypes face reads its argument types and struct layouts from include/nerfacc_hip.h (nerfacc_amd/cuda/_cabi.py):
+    spot-check the parser against prototypes and a struct whose layout is known"""
+    from nerfacc_amd.cuda._cabi import parse_header
+
+    structs, fns = parse_header()
+    args = structs["nfa_traverse_args"]
+    assert ctypes.sizeof(args) == 296 and args.res.offset == 36 and args.res.size == 12 and args.workspace_bytes.offset == 288
+    assert ctypes.sizeof(structs["nfa_ray_segments"]) == 56
+    assert fns["nfa_version"] == (ctypes.c_char_p, [])
+    assert fns["nfa_packed_grid_words"] == (ctypes.c_int64, [ctypes.c_int32] * 4)
+    res, argt = fns["nfa_traverse_fill"]
+    assert res is ctypes.c_int and argt[0]._type_ is args and argt[1:] == [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    assert fns["nfa_transform_stot"][1][2:5] == [ctypes.c_double, ctypes.c_double, ctypes.c_int32]
+    assert fns["nfa_reset_options"] == (None, [])
+
+
+def test_options_table_and_environment_seeding():
+    """nfa_set_option / nfa_get_option (include/nerfacc_hip.h): names with or without the NFA_ prefix, values validated, unknown
+    names refused, `with options(...)` restores; the environment seeds the table ONCE at load (a later setenv changes nothing)"""
+    import subprocess
+    import sys
+
+    import nerfacc_amd as na
+
+    names = na.list_options()
+    assert {"e", "tile", "split_p", "seg_p", "cone_p", "cone", "split_l2", "count_l2", "emit", "scan_rw", "split_blk", "split_xt",
+            "segments", "speculative_emit"} <= set(names) and all(names.values())
+    na.reset_options()
+    try:
+        assert na.get_option("split_p") is None
+        na.set_option("NFA_SPLIT_P", 8)
+        assert na.get_option("split_p") == 8 and na.get_option("Split_P") == 8
+        with na.options(split_p=16, emit="rays"):
+            assert na.get_option("split_p") == 16 and na.get_option("emit") == "rays"
+        assert na.get_option("split_p") == 8 and na.get_option("emit") is None
+        for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1)):
+            if value == "":
+                na.set_option(name, value)          # "" = auto
+                assert na.get_option(name) is None
+                continue
+            with pytest.raises(ValueError):
+                na.set_option(name, value)
+        assert na.get_option("split_p") == 8        # a refused value changes nothing
+    finally:
+        na.reset_options()
+    code = ("import os, nerfacc_amd as na; a = na.get_option('emit'), na.get_option('split_p'), na.get_option('speculative_emit');"
+            "os.environ['NFA_EMIT'] = 'samples'; os.environ['NFA_SCAN_RW'] = '4';"
+            "print(a, na.get_option('emit'), na.get_option('scan_rw'))")
+    env = dict(os.environ, NFA_EMIT="rays", NFA_SPLIT_P="5", NFA_NO_SPECULATIVE_EMIT="1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "('rays', None, 0) rays None", out      # (5 is not a lanes-per-ray value: ignored, as before)
+
+
 def test_argument_validation_happens_before_any_launch():
     # no GPU here: these calls must fail in validation, with a message, not crash
     from nerfacc_amd.cuda._backend import load_library

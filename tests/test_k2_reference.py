@@ -136,11 +136,40 @@ def test_hip_reproduces_reference_k2(name, k2):
     K.check_against_fixture(name, out, k2)
 
 
+# Every kernel FORM that can serve a case, forced through the library's options (nerfacc_amd.set_option), against the reference's
+# own output — not only against the oracle.  {} = the automatic choice.
+_ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}, {"split_p": 8}, {"split_p": 1, "count_l2": 0},
+              {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}]
+_LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}]
+_CONE_ONE = [{}, {"cone": 0}, {"cone": 1, "emit": "rays"}, {"cone": 1, "emit": "samples"}, {"cone": 0, "emit": "rays"}]
+_CONE_LEVELS = _CONE_ONE + [{"cone": 1, "cone_p": p} for p in (8, 16, 32, 64)] + [{"cone_p": 64, "emit": "samples"}]
+SAMPLING_FORMS = {
+    "m1_sphere": _ONE_LEVEL, "m1_noise": _ONE_LEVEL, "lego_4k": _ONE_LEVEL, "lego_12k": _ONE_LEVEL, "lego_256": _ONE_LEVEL,
+    "lego_70k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}],
+    "lego_160k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 0}, {"emit": "rays"}, {"emit": "samples"}],
+    "near_far": _LEVELS, "degenerate": _LEVELS, "two_level_256": _LEVELS, "non_cubic": _LEVELS, "levels4_inside": _LEVELS,
+    "cone_angle": _CONE_ONE, "cone_angle_levels": _CONE_LEVELS,
+}
+_FORM_ID = lambda f: ",".join(f"{k}={v}" for k, v in f.items()) or "auto"
+SAMPLING_PARAMS = [pytest.param(name, form, id=f"{name}-{_FORM_ID(form)}") for name, forms in SAMPLING_FORMS.items() for form in forms]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["m1_sphere", "lego_4k", "lego_70k", "near_far", "degenerate", "two_level_256", "non_cubic", "levels4_inside"])
-def test_hip_sampling_reproduces_reference_k2(name, k2):
+@pytest.mark.parametrize("name,form", SAMPLING_PARAMS)
+def test_hip_sampling_reproduces_reference_k2(name, form, k2):
     """OccGridEstimator.sampling (the fused count/emit kernels, not the general fill kernel) against the same
-    fixture: ray_indices, t_starts = vals[is_left], t_ends = vals[is_right] (occ_grid.py:166-176)"""
+    fixture: ray_indices, t_starts = vals[is_left], t_ends = vals[is_right] (occ_grid.py:166-176) — under every
+    form of the count and emit passes that can serve the case (grid.cu:23-28, 196-216 for the cone-angle ones:
+    the reference's unbounded-scene setting, examples/train_ngp_nerf_occ.py:48-53)"""
+    import torch
+
+    import nerfacc_amd
+
+    with nerfacc_amd.options(**form):
+        _sampling_vs_fixture(name, k2)
+
+
+def _sampling_vs_fixture(name, k2):
     import torch
 
     from gpu_utils import n, t
@@ -167,6 +196,9 @@ def test_hip_sampling_reproduces_reference_k2(name, k2):
     # midpoints of the fixture = (t_start + t_end) * 0.5 with the same rounding (grid.cu:252)
     mids = ((te + ts) * np.float32(0.5)).astype(np.float32)
     assert K.sha(mids) == str(k2[f"{name}/sha/sm_vals"])
+    # and the edges themselves: vals[is_left] / vals[is_right] of the reference's intervals (occ_grid.py:174-175)
+    assert K.sha(ts.astype(np.float32)) == str(k2[f"{name}/sha/t_starts"])
+    assert K.sha(te.astype(np.float32)) == str(k2[f"{name}/sha/t_ends"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -237,13 +269,12 @@ def test_hip_reproduces_reference_inplane(name, k2_inplane):
     K.check_against_fixture(name, K.pack_outputs(as_map(iv, ("is_left", "is_right")), as_map(sm, ("is_valid",)), n(term), None), k2_inplane)
     est = OccGridEstimator(roi_aabb=c["aabbs"][0].tolist(), resolution=list(c["binaries"].shape[1:]), levels=c["binaries"].shape[0]).to("cuda:0")
     est.binaries = t(c["binaries"])
-    for seg in ("1", "0"):
-        os.environ["NFA_SEGMENTS"] = seg
-        try:
+    import nerfacc_amd
+
+    for seg in (1, 0):
+        with nerfacc_amd.options(segments=seg):
             ri, ts, te = est.sampling(t(c["rays_o"]), t(c["rays_d"]), near_plane=0.0, far_plane=float("inf"),
                                       render_step_size=c["kw"]["step_size"])
-        finally:
-            os.environ.pop("NFA_SEGMENTS", None)
         ri, ts, te = n(ri), n(ts), n(te)
         assert K.sha(ri.astype(np.int64)) == str(k2_inplane[f"{name}/sha/sm_ray_indices"])
         assert np.array_equal(np.bincount(ri, minlength=c["rays_o"].shape[0]), k2_inplane[f"{name}/cnts/sm_chunk_cnts"])

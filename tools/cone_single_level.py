@@ -25,7 +25,7 @@ def ms(fn, reps=10):
     return sorted(out)[len(out) // 2]
 res = {}
 for mode in ("1", "0"):
-    os.environ["NFA_CONE"] = mode
+    import nerfacc_amd; nerfacc_amd.set_option("cone", mode)
     f = lambda: C.sample_occgrid(o, d, est.binaries, est.aabbs, near, far, bench.RENDER_STEP, 0.004)
     res[mode] = (ms(f) * 1e3, f())
 a, b = res["1"][1], res["0"][1]
