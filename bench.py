@@ -120,6 +120,38 @@ class DenseGridField(torch.nn.Module):
         return torch.sigmoid(f[:, 1:4]), torch.exp(f[:, :1])
 
 
+class GridMlpField(torch.nn.Module):
+    """`--field grid+mlp`: a dense FEATURE grid (8 channels) decoded by a two-layer MLP — the shape of the reference's NGP
+    field (examples/radiance_fields/ngp.py:79-163: encoding + small MLPs) as far as the gradient exchange is concerned: seven
+    parameter tensors from 4 floats to 8 x res^3, reached by autograd in reverse order.  Not the headline field: it exists so that
+    the multi-GPU path (ExchangeAdam's hooks, chunk order, both exchange modes) is exercised on a multi-tensor graph."""
+
+    def __init__(self, aabb, res=64, feat=8, hidden=32):
+        super().__init__()
+        self.register_buffer("aabb", torch.tensor(aabb, dtype=torch.float32))
+        lo, hi = self.aabb[:3], self.aabb[3:]
+        gen = torch.Generator().manual_seed(7)
+        self.grid = torch.nn.Parameter(0.1 * torch.randn((1, feat, res, res, res), generator=gen))
+        self.l1, self.l2, self.l3 = torch.nn.Linear(feat, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, 4)
+        with torch.no_grad():                       # starts as fog and grey, like the dense-grid student
+            self.l3.weight.mul_(0.1)
+            self.l3.bias.copy_(torch.tensor([math.log(0.5), 0.0, 0.0, 0.0]))
+        self.register_buffer("u_scale", 2.0 / (hi - lo))
+        self.register_buffer("u_shift", -2.0 * lo / (hi - lo) - 1.0)
+
+    def _decode(self, x):
+        u = torch.addcmul(self.u_shift, x, self.u_scale).view(1, 1, 1, -1, 3)
+        f = F.grid_sample(self.grid, u, mode="bilinear", padding_mode="border", align_corners=False).view(self.grid.shape[1], -1).t()
+        return self.l3(torch.relu(self.l2(torch.relu(self.l1(f)))))
+
+    def query_density(self, x):
+        return torch.exp(self._decode(x)[:, :1].clamp(max=8.0))
+
+    def forward(self, x, dirs=None):
+        f = self._decode(x)
+        return torch.sigmoid(f[:, 1:4]), torch.exp(f[:, :1].clamp(max=8.0))
+
+
 def make_ray_pool(n_pool: int, seed: int, device) -> tuple:
     """random pixels of 100 cameras on a radius-4 sphere looking at the origin (OpenGL camera,
     800x800, focal 1111.1)."""
@@ -543,6 +575,12 @@ def main():
     ap.add_argument("--occ-res", type=int, default=GRID_RES,
                     help="occupancy-grid resolution: 128 = configs[1] (default), 256 = the configs[4] grid size")
     ap.add_argument("--grad-chunks", type=int, default=4, help="chunks of the gradient all-reduce (N > 1)")
+    ap.add_argument("--exchange-mode", choices=("allreduce", "rs_ag"), default="allreduce",
+                    help="gradient exchange of ExchangeAdam (N > 1): chunked all-reduce + Adam on every rank, or reduce-scatter -> Adam on the "
+                         "local 1/N -> all-gather of the parameters; the OTHER mode is timed for a few steps as aux.exchange_modes")
+    ap.add_argument("--field", choices=("grid", "grid+mlp"), default="grid",
+                    help="grid = the headline's dense-grid field (one parameter tensor); grid+mlp = feature grid + two-layer MLP (seven "
+                         "tensors: exercises the gradient hooks and the chunk order of the exchange on a multi-tensor graph; dry runs)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="dry run of the N > 1 code path on a single GPU (with --dist-backend gloo): every rank uses cuda:0")
@@ -593,14 +631,20 @@ def main():
 
     torch.manual_seed(42)
     teacher = DenseGridField(AABB, GRID_RES).to(device).eval()          # the analytic scene sampled on a grid
-    field = DenseGridField(AABB, GRID_RES).to(device)
-    with torch.no_grad():                                               # the student starts from fog and grey
-        field.grid[:, :1].fill_(math.log(0.5))
-        field.grid[:, 1:].zero_()
+    if args.field == "grid+mlp":
+        field = GridMlpField(AABB).to(device)
+    else:
+        field = DenseGridField(AABB, GRID_RES).to(device)
+        with torch.no_grad():                                           # the student starts from fog and grey
+            field.grid[:, :1].fill_(math.log(0.5))
+            field.grid[:, 1:].zero_()
     est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
     est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
     if exchanging:
-        optimizer = sharding.ExchangeAdam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=args.grad_chunks)
+        # overlap_backward: this loop obeys its rule (sharding.ExchangeAdam) — the count exchange of a step is STARTED before
+        # backward() and only read after step(); nothing else talks to the process group in between
+        optimizer = sharding.ExchangeAdam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=args.grad_chunks,
+                                          overlap_backward=True, mode=args.exchange_mode)
     else:
         optimizer = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
     loss_scale = 2.0**10
@@ -787,6 +831,24 @@ def main():
     main_run = sorted(windows, key=lambda w: w["elapsed"])[(len(windows) - 1) // 2]      # the median window
     state.pop("proposal", None)
 
+    # the OTHER exchange mode for a few steps (every rank takes part): what the design choice costs on this node
+    exchange_modes = None
+    if exchanging and isinstance(optimizer, sharding.ExchangeAdam) and not args.no_aux:
+        exchange_modes = {args.exchange_mode: {"ms_per_step": main_run["elapsed"] / args.steps * 1e3, "comm_ms_per_step": comm["wait_ms"],
+                                               "comm_window_ms_per_step": comm["window_ms"], "steps": args.steps}}
+        alt = "rs_ag" if args.exchange_mode == "allreduce" else "allreduce"
+        optimizer.set_mode(alt)
+        for _ in range(min(args.warmup, 5)):
+            steps[args.mode]()
+        optimizer.timing = True
+        r = timed_region(steps[args.mode], args.aux_steps, with_timer=False)
+        c = optimizer.comm_stats()
+        optimizer.timing = False
+        exchange_modes[alt] = {"ms_per_step": r["elapsed"] / args.aux_steps * 1e3, "comm_ms_per_step": c["wait_ms"],
+                               "comm_window_ms_per_step": c["window_ms"], "steps": args.aux_steps}
+        optimizer.set_mode(args.exchange_mode)
+        state.pop("proposal", None)
+
     other = None
     if not args.no_other_mode:
         other_mode = "overlap" if args.mode == "api" else "api"
@@ -813,7 +875,7 @@ def main():
         path_prof = profile_steps(step_path_only, min(args.steps, 32))
 
     aux = {}
-    if not args.no_aux and world_size == 1:
+    if not args.no_aux and world_size == 1 and args.field == "grid":
         if args.occ_res != 256:
             # configs[4]'s grid size: the SAME step with a 256^3 occupancy grid built from the trained field
             est256 = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=256, levels=1).to(device)
@@ -908,7 +970,8 @@ def main():
                 "samples_per_ray": main_run["samples"] / max(main_run["rays"], 1),
                 "candidate_samples_per_iter": cand,
                 "occupied_fraction": est.binaries.float().mean().item(),
-                "parallelism": f"rays sharded over {world_size} GPU(s)" + (f", gradient all-reduce in {args.grad_chunks} async chunks overlapped with Adam" if world_size > 1 else ""),
+                "parallelism": f"rays sharded over {world_size} GPU(s)" + (f", gradient exchange ({args.exchange_mode}) in {args.grad_chunks} async chunks overlapped with Adam" if world_size > 1 else ""),
+                "field": args.field,
             },
             "roofline": roof,
         }
@@ -925,6 +988,8 @@ def main():
             po = out["path_only_loop"]
             po["path_us_per_step"] = path_prof["nfa_us_per_step"]
             po["gpu_idle_frac"] = max(0.0, 1.0 - path_prof["busy_us_per_step"] / (po["ms_per_step"] * 1e3))
+        if exchange_modes is not None:
+            aux["exchange_modes"] = exchange_modes
         if aux:
             out["aux"] = aux
         if comm is not None and comm["steps"] > 0:
@@ -940,7 +1005,7 @@ def main():
                 out["path_us_per_step"] = prof["nfa_us_per_step"]
                 out["gpu_idle_frac"] = max(0.0, 1.0 - prof["busy_us_per_step"] / (ms_per_step * 1e3))
                 out["gpu_activity"] = prof
-        if not args.no_cpu_baseline and world_size == 1:
+        if not args.no_cpu_baseline and world_size == 1 and args.field == "grid":
             out["cpu_baseline"] = cpu_baseline(field, est, pool_o, pool_d)
         print(json.dumps(out))
     if exchanging:

@@ -43,6 +43,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
     rank, ws = world()
     if ws == 1:
         return
+    _require_no_open_exchange("allreduce_gradients")
     params = [p for p in params if p.requires_grad]
     if not params:
         return
@@ -73,6 +74,7 @@ def allreduce_counts(n_samples: int, n_rays: int, device) -> Tuple[int, int]:
     rank, ws = world()
     if ws == 1:
         return int(n_samples), int(n_rays)
+    _require_no_open_exchange("allreduce_counts")
     buf = torch.tensor([int(n_samples), int(n_rays)], dtype=torch.int64, device=device)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     s, r = buf.tolist()
@@ -93,6 +95,7 @@ def allreduce_counts_begin(n_samples: int, n_rays: int, device) -> "_PendingCoun
     rank, ws = world()
     if ws == 1:
         return _PendingCounts(None, None, (int(n_samples), int(n_rays)))
+    _require_no_open_exchange("allreduce_counts_begin")
     buf = torch.tensor([int(n_samples), int(n_rays)], dtype=torch.int64, device=device)
     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
     return _PendingCounts(buf, work, None)
@@ -109,42 +112,84 @@ def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
     return s, r
 
 
+# ExchangeAdam instances whose gradient exchange is in flight (first chunk launched from a backward hook, step() not yet
+# run).  While one is, THIS module's other collectives refuse to start: a rank whose backward did not run (no samples)
+# launches the same chunks later, from step(), so any collective issued in between would reach the process group in a
+# different order on different ranks — a hang or a size mismatch.  Collectives the caller issues through
+# torch.distributed directly cannot be checked: the rule is in ExchangeAdam's docstring.
+_OPEN_EXCHANGES: set = set()
+
+
+def _require_no_open_exchange(what: str) -> None:
+    if _OPEN_EXCHANGES:
+        raise RuntimeError(f"nerfacc_amd.sharding.{what}: a gradient exchange started inside backward() is still in flight — no other "
+                           "collective may be issued between backward() and ExchangeAdam.step() (ranks without samples launch the "
+                           "same chunks from step(), so the order of collectives would differ between ranks); call it before "
+                           "backward() or after step(), or build ExchangeAdam with overlap_backward=False")
+
+
 class ExchangeAdam:
     """Adam over ONE flat fp32 parameter buffer with the gradient exchange folded in: the flat gradient is cut
-    into `n_chunks` contiguous chunks, every chunk is all-reduced asynchronously, and the Adam update of chunk k
+    into `n_chunks` contiguous chunks, every chunk is exchanged asynchronously, and the Adam update of chunk k
     runs as soon as chunk k has arrived — while the other chunks are still on the wire.  Same update rule as
     torch.optim.Adam (L2 weight decay added to the gradient, bias correction, eps outside the square root).
 
     `params`: parameters whose storage is packed into the flat buffer (their .data / .grad become views of
     it, so autograd accumulates straight into the exchange buffer: no staging copies).
 
-    **When a chunk's all-reduce starts.**  With `overlap_backward` (default) every parameter carries a
-    post-accumulate-grad hook: a chunk is launched from inside the backward pass as soon as every parameter that
-    overlaps it has its gradient — in a FIXED order, last chunk first (autograd reaches the last parameters of a
-    model first), so that all ranks issue the same sequence of collectives whatever their graphs look like; a
-    chunk that becomes ready out of turn waits for its predecessors.  `step()` launches what is left (ranks whose
-    backward did not run — no samples this step — or parameters the loss did not reach) in the same order.  A
-    field that is ONE tensor (bench.py's voxel grid) gets all its chunks launched by that tensor's hook, i.e. at
+    **mode** — `"allreduce"`: every chunk is all-reduced and every rank runs Adam on the whole chunk (N identical
+    updates).  `"rs_ag"`: every chunk is REDUCE-SCATTERED (each rank receives the sum of its 1/N of the chunk), Adam
+    runs on that 1/N only — the optimizer pass and its moments' traffic shrink N-fold — and the updated 1/N is
+    ALL-GATHERED back into every rank's parameters, chunk k's all-gather overlapping chunk k-1's Adam.  Same bytes
+    on the wire as a ring all-reduce (which is a reduce-scatter followed by an all-gather), same result: every
+    element's sum is formed once and every rank applies the same fp32 update to it.  The moments of a rank are
+    authoritative on its own 1/N only; `state_dict()` gathers them (a collective: call it on every rank).
+
+    **When a chunk's exchange starts.**  Default (`overlap_backward=False`): in `step()`, all chunks at once, in a
+    fixed order.  With `overlap_backward=True` every parameter carries a post-accumulate-grad hook: a chunk is
+    launched from inside the backward pass as soon as every parameter that overlaps it has its gradient — in a
+    FIXED order, last chunk first (autograd reaches the last parameters of a model first), so that all ranks issue
+    the same sequence of collectives whatever their graphs look like; a chunk that becomes ready out of turn waits
+    for its predecessors.  `step()` launches what is left (ranks whose backward did not run — no samples this step —
+    or parameters the loss did not reach) in the same order.  Two rules come with it, both enforced where this module
+    can see the violation:
+      * NO other collective between `backward()` and `step()` on any rank (a rank without samples launches its chunks
+        from `step()`: anything in between would be ordered differently on different ranks).  This module's own
+        collectives (`allreduce_counts[_begin]`, `broadcast_grid`, `allreduce_gradients`) raise while an exchange is
+        in flight; collectives issued through torch.distributed directly are the caller's responsibility.
+      * ONE backward per step: a second backward() would add into a buffer whose exchange is already in flight
+        (silently wrong gradients) — the hook raises.  Accumulate gradients with `overlap_backward=False`.
+    A field that is ONE tensor (bench.py's voxel grid) gets all its chunks launched by that tensor's hook, i.e. at
     the end of its backward kernel: nothing of the backward pass is left to overlap with, only the host time up
-    to `optimizer.step()` and the Adam passes of the earlier chunks.  Use `overlap_backward=False` when gradients
-    are accumulated over several backward passes per step.
+    to `optimizer.step()` and the Adam passes of the earlier chunks.
 
     The exchange runs whenever a process group is initialised — also with one rank (an RCCL all-reduce over a
     world of 1 is a valid collective: the single-GPU smoke test of this path); without a process group it is a
-    plain chunked Adam.
+    plain chunked Adam.  The world size is read at construction (the flat buffers are padded so that every chunk
+    splits evenly over the ranks).
 
     `timing = True` records HIP events around the exchange (`comm_stats()`): `wait_ms` — how long the compute
     stream stood still waiting for chunks (the exposed communication), `window_ms` — first launch to last arrival.
+    `collective_log` (a list, when `record_collectives=True`) receives one `(op, chunk, numel)` tuple per collective
+    issued, in issue order — what the multi-rank tests compare across ranks.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-2, betas=(0.9, 0.999), eps=1e-15,
-                 weight_decay=0.0, n_chunks: int = 4, average: bool = True, overlap_backward: bool = True):
+                 weight_decay=0.0, n_chunks: int = 4, average: bool = True, overlap_backward: bool = False,
+                 mode: str = "allreduce", record_collectives: bool = False):
+        assert mode in ("allreduce", "rs_ag"), mode
+        self.mode = mode
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
         dev = self.params[0].device
+        self.ws = dist.get_world_size() if self._exchanging() else 1
+        self.rank = dist.get_rank() if self._exchanging() else 0
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        unit = 256 * self.ws                                 # every chunk splits evenly over the ranks, shards start 1 KiB aligned
+        padded = -(-total // unit) * unit
+        self.total, self.padded = total, padded
+        self.flat = torch.zeros(padded, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(padded, dtype=torch.float32, device=dev)
         self.offsets: List[int] = []
         off = 0
         for p in self.params:
@@ -158,10 +203,15 @@ class ExchangeAdam:
         self.v = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps, self.weight_decay, self.average = lr, betas, eps, weight_decay, average
         self.t = 0
-        n_chunks = max(1, min(int(n_chunks), total))
-        size = -(-total // n_chunks)
-        size = -(-size // 1024) * 1024                      # chunk starts stay 4 KiB aligned
-        self.bounds = [(a, min(a + size, total)) for a in range(0, total, size)]
+        n_chunks = max(1, min(int(n_chunks), padded // unit))
+        size = -(-padded // n_chunks)
+        size = -(-size // unit) * unit
+        self.bounds = [(a, min(a + size, padded)) for a in range(0, padded, size)]
+        # rs_ag: this rank's 1/N of chunk k is [a + rank * s, a + (rank + 1) * s), s = (b - a) / N; the reduced gradients
+        # of all its shards live back to back in `gshard`
+        self._shard = [((b - a) // self.ws) for a, b in self.bounds]
+        self._gshard_off = [sum(self._shard[:k]) for k in range(len(self.bounds))]
+        self.gshard = torch.zeros(sum(self._shard), dtype=torch.float32, device=dev) if mode == "rs_ag" else None
         self.step_tensor = torch.zeros((), dtype=torch.float32, device=dev)
         self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
         # chunk k is complete when `_need[k]` parameters have reported; parameter i reports to `_chunks_of[i]`
@@ -184,10 +234,12 @@ class ExchangeAdam:
         self.timing = False
         self._events: List = []
         self._first_launch = None
-        self.exchange_bytes = 4 * total
+        self.exchange_bytes = 4 * padded
+        self.collective_log = [] if record_collectives else None
 
     # ---- bookkeeping ----------------------------------------------------------------------------------------------
-    def _exchanging(self) -> bool:
+    @staticmethod
+    def _exchanging() -> bool:
         return dist.is_available() and dist.is_initialized()
 
     def _slot(self, i: int) -> torch.Tensor:
@@ -217,7 +269,13 @@ class ExchangeAdam:
 
     def _make_hook(self, i: int):
         def hook(_param):
-            if self._reported[i] or not self._exchanging():
+            if not self._exchanging():
+                return
+            if self._reported[i]:
+                if any(self._works[k] is not None for k in self._chunks_of[i]):
+                    raise RuntimeError("ExchangeAdam(overlap_backward=True): a second backward() reached a parameter whose gradient "
+                                       "chunk is already being exchanged — its contribution would be lost or double-counted.  Call "
+                                       "step() after every backward(), or accumulate gradients with overlap_backward=False.")
                 return
             if not self._bound(i):
                 self._rebind(i)
@@ -230,12 +288,23 @@ class ExchangeAdam:
         for k in self._chunks_of[i]:
             self._have[k] += 1
 
+    def _log(self, op: str, k: int, numel: int) -> None:
+        if self.collective_log is not None:
+            self.collective_log.append((op, k, int(numel)))
+
     def _launch(self, k: int) -> None:
         a, b = self.bounds[k]
         if self.timing and self._first_launch is None and self.grad.is_cuda:
             self._first_launch = torch.cuda.Event(enable_timing=True)
             self._first_launch.record()
-        self._works[k] = dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
+        if self.mode == "rs_ag":
+            s, g0 = self._shard[k], self._gshard_off[k]
+            self._works[k] = dist.reduce_scatter_tensor(self.gshard[g0:g0 + s], self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
+            self._log("reduce_scatter", k, b - a)
+        else:
+            self._works[k] = dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
+            self._log("all_reduce", k, b - a)
+        _OPEN_EXCHANGES.add(id(self))
 
     def _launch_ready(self) -> None:
         while self._next >= 0 and self._have[self._next] >= self._need[self._next]:
@@ -243,8 +312,7 @@ class ExchangeAdam:
             self._next -= 1
 
     # ---- the step -------------------------------------------------------------------------------------------------
-    def _adam(self, a: int, b: int) -> None:
-        p, g, m, v = self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b]
+    def _adam(self, p, g, m, v) -> None:
         b1, b2 = self.betas
         if self._fused:
             # one launch per chunk; state_steps holds the 1-based number of THIS step (torch's _fused_adam increments
@@ -261,6 +329,11 @@ class ExchangeAdam:
         denom = (v.sqrt() / (bc2**0.5)).add_(self.eps)
         p.addcdiv_(m, denom, value=-self.lr / bc1)
 
+    def _own(self, k: int):
+        """[begin, end) of this rank's 1/N of chunk k in the flat buffers"""
+        a, s = self.bounds[k][0], self._shard[k]
+        return a + self.rank * s, a + (self.rank + 1) * s
+
     def step(self) -> None:
         """finish the exchange (launch the chunks the backward pass did not, in the fixed order) and update every chunk
         as it arrives, in arrival (= launch) order"""
@@ -268,6 +341,7 @@ class ExchangeAdam:
         self.step_tensor += 1
         exchanging = self._exchanging()
         ws = dist.get_world_size() if exchanging else 1
+        assert ws == self.ws, "ExchangeAdam: the world size changed after construction"
         for i in range(len(self.params)):                    # gradients that were produced outside the flat buffer
             if not self._bound(i):
                 assert not self._reported[i], "ExchangeAdam: a gradient was replaced after its chunk had been sent"
@@ -280,6 +354,7 @@ class ExchangeAdam:
             assert self._next < 0
         timed = self.timing and self.grad.is_cuda and exchanging
         waits = []
+        gathers = []
         for k in range(len(self.bounds) - 1, -1, -1):
             a, b = self.bounds[k]
             if exchanging:
@@ -291,9 +366,29 @@ class ExchangeAdam:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     waits.append((e0, e1))
+            if exchanging and self.mode == "rs_ag":
+                s, g0 = self._shard[k], self._gshard_off[k]
+                lo, hi = self._own(k)
+                g = self.gshard[g0:g0 + s]
                 if self.average and ws > 1:
+                    g.div_(ws)
+                self._adam(self.flat[lo:hi], g, self.m[lo:hi], self.v[lo:hi])
+                # in place: the input is this rank's slice of the output (NCCL's in-place all-gather layout)
+                gathers.append(dist.all_gather_into_tensor(self.flat[a:b], self.flat[lo:hi], async_op=True))
+                self._log("all_gather", k, b - a)
+            else:
+                if exchanging and self.average and ws > 1:
                     self.grad[a:b].div_(ws)
-            self._adam(a, b)
+                self._adam(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b])
+        for w in gathers:                                    # parameters are complete before anything reads them
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            w.wait()
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                waits.append((e0, e1))
         if timed:
             self._events.append((self._first_launch, waits))
         self._first_launch = None
@@ -301,11 +396,33 @@ class ExchangeAdam:
         self._have = [0] * len(self.bounds)
         self._reported = [False] * len(self.params)
         self._next = len(self.bounds) - 1
+        _OPEN_EXCHANGES.discard(id(self))
+
+    def set_mode(self, mode: str) -> None:
+        """switch between "allreduce" and "rs_ag" between steps (a COLLECTIVE when leaving rs_ag: the moments are gathered so
+        that every rank holds them whole again).  bench.py times both modes in one run with it."""
+        assert mode in ("allreduce", "rs_ag"), mode
+        assert all(w is None for w in self._works), "ExchangeAdam.set_mode: an exchange is in flight"
+        if mode == self.mode:
+            return
+        if self.mode == "rs_ag":
+            self._gather_moments()
+        elif self.gshard is None:
+            self.gshard = torch.zeros(sum(self._shard), dtype=torch.float32, device=self.flat.device)
+        self.mode = mode
+
+    def close(self) -> None:
+        """remove the gradient hooks (the parameters stay views of the flat buffers)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.overlap_backward = False
+        _OPEN_EXCHANGES.discard(id(self))
 
     def comm_stats(self, reset: bool = True) -> dict:
         """per-step averages over the steps taken with `timing = True` (synchronises the device)"""
         if not self._events:
-            return {"steps": 0, "wait_ms": 0.0, "window_ms": 0.0, "exchange_bytes": self.exchange_bytes}
+            return {"steps": 0, "wait_ms": 0.0, "window_ms": 0.0, "exchange_bytes": self.exchange_bytes, "mode": self.mode}
         torch.cuda.synchronize(self.grad.device)
         wait = window = 0.0
         for first, waits in self._events:
@@ -314,20 +431,34 @@ class ExchangeAdam:
         n = len(self._events)
         if reset:
             self._events = []
-        return {"steps": n, "wait_ms": wait / n, "window_ms": window / n, "exchange_bytes": self.exchange_bytes}
+        return {"steps": n, "wait_ms": wait / n, "window_ms": window / n, "exchange_bytes": self.exchange_bytes, "mode": self.mode}
 
     # ---- checkpointing --------------------------------------------------------------------------------------------
+    def _gather_moments(self) -> None:
+        """rs_ag: a rank's moments are current on its own shards only — make them whole on every rank (collective)"""
+        if self.mode != "rs_ag" or not self._exchanging() or self.ws == 1:
+            return
+        for buf in (self.m, self.v):
+            for k, (a, b) in enumerate(self.bounds):
+                lo, hi = self._own(k)
+                dist.all_gather_into_tensor(buf[a:b], buf[lo:hi].clone())
+
     def state_dict(self) -> dict:
-        return {"flat": self.flat.clone(), "m": self.m.clone(), "v": self.v.clone(), "t": self.t,
+        """parameters, both moments, the step count.  In `rs_ag` mode this is a COLLECTIVE (the moments are gathered):
+        call it on every rank."""
+        self._gather_moments()
+        n = self.total
+        return {"flat": self.flat[:n].clone(), "m": self.m[:n].clone(), "v": self.v[:n].clone(), "t": self.t,
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay},
                 "numels": [p.numel() for p in self.params]}
 
     def load_state_dict(self, state: dict) -> None:
         assert list(state["numels"]) == [p.numel() for p in self.params], "ExchangeAdam: parameter layout differs"
+        n = self.total
         with torch.no_grad():
-            self.flat.copy_(state["flat"])
-            self.m.copy_(state["m"])
-            self.v.copy_(state["v"])
+            self.flat[:n].copy_(state["flat"][:n])
+            self.m[:n].copy_(state["m"][:n])
+            self.v[:n].copy_(state["v"][:n])
         self.t = int(state["t"])
         self.step_tensor.fill_(float(self.t))
         h = state.get("hyper", {})
@@ -340,6 +471,7 @@ def broadcast_grid(estimator, src: int = 0) -> None:
     rank, ws = world()
     if ws == 1:
         return
+    _require_no_open_exchange("broadcast_grid")
     dist.broadcast(estimator.occs, src=src)
     b = estimator.binaries.to(torch.uint8)
     dist.broadcast(b, src=src)

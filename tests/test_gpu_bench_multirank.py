@@ -56,6 +56,7 @@ def test_two_ranks_on_one_device(extra, launch):
     assert "other_loop" in out and out["other_loop"]["ms_per_step"] > 0
     assert len(out["ms_per_step_windows"]) == 2 and out["ms_per_step"] in out["ms_per_step_windows"]
     assert out["exchange_bytes"] == 4 * 4 * 128**3 and out["comm_ms_per_step"] >= 0 and out["comm_window_ms_per_step"] >= 0
+    assert set(out["aux"]["exchange_modes"]) == {"allreduce", "rs_ag"}          # the other exchange mode was stepped too
 
 
 def test_rccl_world_of_one():
@@ -102,3 +103,24 @@ print("ok", st)
     res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                          env=_clean_env())
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_eight_ranks_multi_tensor_field_on_one_device(mode):
+    """the driver's N = 8 command executed once: eight ranks through torch.distributed.run share cuda:0 and
+    exchange through gloo; the field is the feature grid + MLP (seven parameter tensors), so ExchangeAdam's gradient hooks fire in
+    autograd's order on a multi-tensor graph and the chunks leave from inside backward — and the line carries the comm figures of
+    BOTH exchange modes (aux.exchange_modes)."""
+    bench_args = ["--gpus", "8", "--steps", "4", "--warmup", "2", "--windows", "1", "--pretrain", "24", "--pool", "32768", "--aux-steps", "3",
+                  "--dist-backend", "gloo", "--all-ranks-on-device0", "--field", "grid+mlp", "--exchange-mode", mode, "--no-other-mode"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + bench_args
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and math.isfinite(out["value"]) and out["value"] > 0 and out["config"]["field"] == "grid+mlp"
+    modes = out["aux"]["exchange_modes"]
+    assert set(modes) == {"allreduce", "rs_ag"} and all(m["ms_per_step"] > 0 and m["comm_ms_per_step"] >= 0 for m in modes.values())
+    assert out["comm_window_ms_per_step"] > 0

@@ -202,3 +202,145 @@ def test_exchange_adam_survives_detached_grads_and_checkpoints():
         oc.step()
     for x, y in zip(b, c):
         assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the step exchange with a MULTI-TENSOR field on up to 8 ranks — a dense feature grid and a
+# small MLP, seven parameter tensors from 4 to 13 824 elements, one rank without samples on some steps — in both exchange
+# modes (all-reduce / reduce-scatter + sharded Adam + all-gather), launched from step() and from the gradient hooks.
+# Every rank must issue the SAME sequence of collectives, replicas must stay bit-identical, and the result must be
+# torch.optim.Adam on the averaged shard gradients.
+# ---------------------------------------------------------------------------------------------------------------------
+class _GridMlpField(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(11)
+        self.grid = torch.nn.Parameter(0.1 * torch.randn(1, 8, 12, 12, 12, generator=g))
+        self.l1, self.l2, self.l3 = torch.nn.Linear(8, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 4)
+        for lin in (self.l1, self.l2, self.l3):
+            with torch.no_grad():
+                lin.weight.copy_(0.3 * torch.randn(lin.weight.shape, generator=g))
+                lin.bias.copy_(0.1 * torch.randn(lin.bias.shape, generator=g))
+
+    def forward(self, x):
+        f = torch.nn.functional.grid_sample(self.grid, x.view(1, -1, 1, 1, 3), align_corners=True).view(8, -1).t()
+        return self.l3(torch.relu(self.l2(torch.relu(self.l1(f)))))
+
+
+def _field_batch(step):
+    g = torch.Generator().manual_seed(1000 + step)
+    return torch.rand(96, 3, generator=g) * 2 - 1, torch.rand(96, 4, generator=g)
+
+
+def _rank_is_idle(rank, step, world):
+    return world > 1 and rank == world - 1 and step % 3 == 1          # the last rank draws no samples on every third step
+
+
+def _field_worker(rank, world, port, out_dir, mode, overlap, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        field = _GridMlpField()
+        opt = sharding.ExchangeAdam(field.parameters(), lr=5e-3, eps=1e-15, weight_decay=1e-6, n_chunks=4, mode=mode,
+                                    overlap_backward=overlap, record_collectives=True)
+        assert len(opt.params) == 7 and len(opt.bounds) == 4 and all((b - a) % world == 0 for a, b in opt.bounds)
+        for step in range(steps):
+            x, y = _field_batch(step)
+            b, e = sharding.shard_bounds(x.shape[0], rank, world)
+            opt.zero_grad()
+            # the count exchange of the step (train_ngp_nerf_occ.py:187-194) goes BEFORE backward, as bench.py does
+            pend = sharding.allreduce_counts_begin(e - b, e - b, "cpu")
+            if not _rank_is_idle(rank, step, world):
+                torch.nn.functional.smooth_l1_loss(field(x[b:e]), y[b:e]).mul(64.0).backward()
+            opt.step()
+            n_s, n_r = sharding.allreduce_counts_end(pend)
+            assert n_r == x.shape[0]
+        snap = opt.state_dict()                 # (a collective in rs_ag mode: the moments are gathered)
+        torch.save(dict(params=torch.cat([p.detach().flatten() for p in field.parameters()]), log=opt.collective_log,
+                        m=snap["m"], v=snap["v"]), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _field_reference(world, steps):
+    field = _GridMlpField()
+    opt = torch.optim.Adam(field.parameters(), lr=5e-3, eps=1e-15, weight_decay=1e-6)
+    for step in range(steps):
+        x, y = _field_batch(step)
+        total = [torch.zeros_like(p) for p in field.parameters()]
+        for rk in range(world):
+            if _rank_is_idle(rk, step, world):
+                continue
+            b, e = sharding.shard_bounds(x.shape[0], rk, world)
+            field.zero_grad(set_to_none=True)
+            torch.nn.functional.smooth_l1_loss(field(x[b:e]), y[b:e]).mul(64.0).backward()
+            total = [t + (p.grad if p.grad is not None else 0) for t, p in zip(total, field.parameters())]
+        for p, t in zip(field.parameters(), total):
+            p.grad = t / world
+        opt.step()
+    st = opt.state_dict()["state"]
+    return (torch.cat([p.detach().flatten() for p in field.parameters()]),
+            torch.cat([st[i]["exp_avg"].flatten() for i in range(7)]), torch.cat([st[i]["exp_avg_sq"].flatten() for i in range(7)]))
+
+
+@pytest.mark.parametrize("world,mode,overlap", [(8, "allreduce", True), (8, "rs_ag", True), (8, "rs_ag", False), (2, "rs_ag", True),
+                                                (2, "allreduce", False), (3, "rs_ag", True)])
+def test_multi_tensor_field_exchange(tmp_path, world, mode, overlap):
+    steps = 20
+    mp.spawn(_field_worker, args=(world, _free_port(), str(tmp_path), mode, overlap, steps), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    want, want_m, want_v = _field_reference(world, steps)
+    ops = {"allreduce": ["all_reduce"] * 4, "rs_ag": ["reduce_scatter"] * 4 + ["all_gather"] * 4}[mode]
+    assert [op for op, _, _ in ranks[0]["log"][:len(ops)]] == ops
+    assert [k for _, k, _ in ranks[0]["log"][:4]] == [3, 2, 1, 0]                     # the fixed launch order, last chunk first
+    for r in ranks[1:]:
+        assert r["log"] == ranks[0]["log"], "ranks issued different sequences of collectives"
+        assert torch.equal(r["params"], ranks[0]["params"]), "replicas diverged"
+        assert torch.equal(r["m"], ranks[0]["m"]) and torch.equal(r["v"], ranks[0]["v"])
+    assert len(ranks[0]["log"]) == steps * len(ops)
+    assert torch.allclose(ranks[0]["params"], want, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(ranks[0]["m"], want_m, atol=1e-6, rtol=1e-4) and torch.allclose(ranks[0]["v"], want_v, atol=1e-8, rtol=1e-4)
+
+
+def _rules_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        field = _GridMlpField()
+        opt = sharding.ExchangeAdam(field.parameters(), lr=5e-3, n_chunks=4, overlap_backward=True, record_collectives=True)
+        x, y = _field_batch(0)
+        b, e = sharding.shard_bounds(96, rank, world)
+        seen = []
+        torch.nn.functional.smooth_l1_loss(field(x[b:e]), y[b:e]).backward()
+        assert len(opt.collective_log) == 4                  # every chunk went out from inside backward
+        for name, call in (("allreduce_counts", lambda: sharding.allreduce_counts(1, 1, "cpu")),
+                           ("allreduce_counts_begin", lambda: sharding.allreduce_counts_begin(1, 1, "cpu")),
+                           ("allreduce_gradients", lambda: sharding.allreduce_gradients(field.parameters())),
+                           ("broadcast_grid", lambda: sharding.broadcast_grid(None))):
+            try:
+                call()
+                seen.append(name + ": no error")
+            except RuntimeError as err:
+                seen.append(name if "between backward() and ExchangeAdam.step()" in str(err) else f"{name}: {err}")
+        try:                                                   # a second backward before step(): gradient accumulation
+            torch.nn.functional.smooth_l1_loss(field(x[b:e]), y[b:e]).backward()
+            seen.append("second backward: no error")
+        except RuntimeError as err:
+            seen.append("second backward" if "second backward()" in str(err) else f"second backward: {err}")
+        opt.step()
+        assert sharding.allreduce_counts(rank + 1, 1, "cpu") == (3, 2)      # after step() collectives are welcome again
+        torch.save(seen, os.path.join(out_dir, f"rules{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlap_backward_rules_are_enforced(tmp_path):
+    """with overlap_backward the chunks leave from inside backward(); this module's other collectives and
+    a second backward() must raise until step() has run — and overlap_backward is opt-in"""
+    assert sharding.ExchangeAdam([torch.nn.Parameter(torch.zeros(3))]).overlap_backward is False
+    mp.spawn(_rules_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rk in range(2):
+        assert torch.load(tmp_path / f"rules{rk}.pt") == ["allreduce_counts", "allreduce_counts_begin", "allreduce_gradients",
+                                                          "broadcast_grid", "second backward"]
