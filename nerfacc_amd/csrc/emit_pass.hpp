@@ -108,6 +108,11 @@ __device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, c
     const int64_t n_groups = (int64_t)gridDim.x * (kBlock / G);
     int64_t r = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
     if (r >= R) return;
+    // the constant step of cone_angle == 0 as the lattice's integer increment (lattice.hpp): mantissa with the hidden bit, exponent
+    const uint32_t lat_db = nfa_f2u(march_dt(0.0f, 0.0f, step_size));
+    const int lat_ed = (int)((lat_db >> 23) & 0xffu);
+    const uint32_t lat_D = (lat_db & 0x7fffffu) | 0x800000u;
+    const bool lat_ok = lat_ed >= 1 && lat_ed < 255 && (lat_db >> 31) == 0;
     EmitRay m = emit_ray_load(a, rs, r, gl);
     for (; r < R; r += n_groups) {
         const EmitRay c = m;
@@ -140,6 +145,30 @@ __device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, c
                     const int rem = len - j0;
                     float t = base, full = base;
                     float sv[5];
+                    // cone_angle == 0, round 4: the pass's 64 lattice points IN CLOSED FORM when they share base's binade.  Inside a
+                    // binade a step adds the same integer number of ulps c = RN(dt / ulp) to the mantissa (lattice.hpp: exact while
+                    // the sum stays below 2^(e+1) and dt / ulp is not exactly half-way), and while the mantissa does not carry the
+                    // float's BIT PATTERN advances by c too: lane gl's samples are bits(base) + (4 gl + e) c — five integer adds
+                    // instead of the 63-add chain every lane ran before (331 us for the 38 M samples of 10^6 rays, 1.7 TB/s of
+                    // stores, instruction-bound).  A pass that crosses a binade edge (about a dozen between dt and t = 8), a tie or
+                    // an irregular value takes the chain below: the same adds the reference performs.
+                    if (cone == 0.0f) {
+                        const uint32_t tb = nfa_f2u(base);
+                        const int e = (int)((tb >> 23) & 0xffu), sh = e - lat_ed;
+                        const bool ok = lat_ok && (tb >> 31) == 0 && e >= 1 && e < 254 && sh >= 1 && sh <= 24;
+                        const uint32_t shc = ok ? (uint32_t)sh : 1u;
+                        const uint32_t c0 = lat_D >> shc, frac = lat_D & ((1u << shc) - 1u), half = (1u << shc) >> 1;
+                        const uint32_t inc = c0 + (frac > half ? 1u : 0u);
+                        const uint32_t mant = (tb & 0x7fffffu) | 0x800000u;
+                        if (ok && frac != half && mant + 64u * inc < (1u << 24)) {
+                            const uint32_t b0 = tb + (uint32_t)(4 * gl) * inc;
+#pragma unroll
+                            for (int e2 = 0; e2 < 5; ++e2) sv[e2] = nfa_u2f(b0 + (uint32_t)e2 * inc);
+                            base = nfa_u2f(tb + 64u * inc);
+                            goto pass_ready;
+                        }
+                    }
+                    {
                     auto chain = [&](auto step) {            // (instantiated for the constant step and for the cone's clamp)
 #pragma unroll
                         for (int blk = 0; blk < 4; ++blk) {
@@ -157,6 +186,8 @@ __device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, c
                     };
                     if (cone == 0.0f) chain([&](float x) { return x + dt0; });
                     else chain([&](float x) { return x + march_dt(x, cone, step_size); });
+                    }
+                pass_ready:
                     const int j = j0 + 4 * gl;              // this lane's first sample of the pass
                     const int nv = rem - 4 * gl;            // its samples that exist (>= 4: all)
                     if (nv <= 0) continue;
@@ -201,14 +232,312 @@ __device__ __forceinline__ void emit_by_ray_groups(const nfa_traverse_args &a, c
     }
 }
 
+// pass 2, tile form (round 4, cone_angle == 0): A WAVE TAKES A BLOCK OF CONSECUTIVE RAYS AND DEALS ITS RUNS' SAMPLES TO ITS LANES.
+// What the two forms above leave on the table at frame scale (38 M samples of 10^6 rays: 1.65 TB/s of stores, a quarter of what
+// this part writes): the lane-per-sample form pays ~14 dependent loads per sample (two searches in global memory), the ray groups
+// leave most lanes idle — a ray has 38 samples on average and a group's pass holds 64, rays without samples hold a group for
+// nothing, and a wave waits for the longest of its four rays.  Here the unit of work is a block of RB consecutive rays (4 ... 64,
+// by the ray count: enough waves to fill the chip) whose samples are ONE contiguous stretch of the outputs:
+//   1. W = 64 / RB lanes share a ray: lane (ray, w) loads the ray's count, offset, number of runs AND run record w in one round
+//      trip (the records' addresses do not depend on the counts);
+//   2. the block's runs become a SEGMENT LIST in the wave's LDS, ray-major — first sample (relative to the block), lattice start
+//      t0, and, for runs that leave t0's binade, the index j1 of the first lattice point beyond the edge (one division per run, so
+//      that the lanes below almost never need the general closed form).  Every run is cut into QUADS of four consecutive samples
+//      counted from the run's start (the last one partial); quad positions come from a segmented DPP scan inside the ray's lanes,
+//      a scan over the rays, and one LDS pass that adds a ray's base to its entries.  A ray with more than W runs takes more
+//      rounds (a noise grid's 300 runs per ray: 19 rounds of 16 lanes instead of 300 dependent loads of one lane); blocks with
+//      more runs than the list holds are taken in sub-blocks of whole rays;
+//   3. the quads are dealt to the lanes 64 at a time: a lane finds its quad's run by bisection in LDS (at most 65 candidates),
+//      takes its lattice point as bits(t) + j c — exact inside a binade (lattice.hpp; nfa_lattice_advance when the check fails),
+//      three more points the same way, and writes 16-byte vectors (a partial quad: single elements).  A lane never straddles
+//      runs, so there is no per-sample path, and consecutive lanes write consecutive addresses.
+// Rays flagged by the count pass (run records did not fit) become one "skip" segment: the fallback launch writes them.
+constexpr int kSegCap = 512;                // >= kMaxRunsCap: a single ray always fits a sub-block
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    const int lane = lane_id();
+    v += dpp_i32<kDppRowShr + 1>(0, v);
+    v += dpp_i32<kDppRowShr + 2>(0, v);
+    v += dpp_i32<kDppRowShr + 4>(0, v);
+    v += dpp_i32<kDppRowShr + 8>(0, v);
+    int u = dpp_i32<kDppRowBcast15>(0, v); if (lane & 16) v += u;
+    u = dpp_i32<kDppRowBcast31>(0, v); if (lane & 32) v += u;
+    return v;
+}
+__device__ __forceinline__ int readlane_dyn_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int64_t readlane_dyn_i64(int64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// the constant step of cone_angle == 0 as the lattice's integer increment (lattice.hpp)
+struct LatStep {
+    float dt;
+    uint32_t D;       // dt's mantissa with the hidden bit
+    int ed;           // dt's biased exponent
+    bool ok;          // dt is a positive normal number
+    __device__ __forceinline__ explicit LatStep(float d) : dt(d) {
+        const uint32_t db = nfa_f2u(d);
+        ed = (int)((db >> 23) & 0xffu);
+        D = (db & 0x7fffffu) | 0x800000u;
+        ok = ed >= 1 && ed < 255 && (db >> 31) == 0;
+    }
+    // ulps per step in t's binade (0: no closed form here — a tie, t below dt's binade, an irregular value)
+    __device__ __forceinline__ uint32_t inc_at(uint32_t tb) const {
+        const int e = (int)((tb >> 23) & 0xffu), sh = e - ed;
+        const bool reg = ok && (tb >> 31) == 0 && e >= 1 && e < 254 && sh >= 1 && sh <= 24;
+        const uint32_t shc = reg ? (uint32_t)sh : 1u;
+        const uint32_t c0 = D >> shc, frac = D & ((1u << shc) - 1u), half = (1u << shc) >> 1;
+        return (reg && frac != half) ? c0 + (frac > half ? 1u : 0u) : 0u;
+    }
+};
+constexpr int kEmitSegWords = 5;            // qpos, spos, t0, j1, ray (+ 2 words of edge offset with interval outputs)
+constexpr int kEmitRayBaseBytes = 64 * 4;   // per wave, behind the segment list: first quad of every ray of the block
+constexpr int kSegSkip = 64;                // seg_ray flag: the run belongs to a ray the fallback launch writes
+
+// inclusive scan over the lanes of a wave, restarting at every segment head; `dist` = lanes between this lane and its segment's head
+__device__ __forceinline__ int wave_seg_incl_scan_i32(int v, int dist) {
+    const int lane = lane_id();
+    const int rl = lane & 15;
+    const int dr = dist < rl ? dist : rl;
+    int u;
+    u = dpp_i32<kDppRowShr + 1>(0, v); if (dr >= 1) v += u;
+    u = dpp_i32<kDppRowShr + 2>(0, v); if (dr >= 2) v += u;
+    u = dpp_i32<kDppRowShr + 4>(0, v); if (dr >= 4) v += u;
+    u = dpp_i32<kDppRowShr + 8>(0, v); if (dr >= 8) v += u;
+    u = dpp_i32<kDppRowBcast15>(0, v); if ((lane & 16) && dist > rl) v += u;
+    u = dpp_i32<kDppRowBcast31>(0, v); if ((lane & 32) && dist > (lane & 31)) v += u;
+    return v;
+}
+
+template <bool IV>
+__device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const RunStore &rs, int rb_log2, int seg_cap, unsigned char *lds_raw,
+                                              const int64_t *__restrict__ n_dev, int64_t capacity, int speculative)
+{
+    // speculative launch: the true total is requested here and looked at after the first block's loads have been issued — nothing
+    // is stored before the check
+    const int64_t n_total = speculative ? n_dev[1] : 0;
+    bool checked = false;
+    const int lane = lane_id(), wib = (int)(threadIdx.x >> 6);
+    const int64_t R = a.n_rays;
+    const LatStep L(march_dt(0.0f, 0.0f, a.step_size));
+    const float dt = L.dt;
+    const int per_wave = seg_cap * 4 * (kEmitSegWords + (IV ? 2 : 0)) + kEmitRayBaseBytes;
+    int32_t *seg_qpos = (int32_t *)(lds_raw + wib * per_wave);   // first quad of the run (relative to the sub-block)
+    int32_t *seg_spos = seg_qpos + seg_cap;                       // first sample of the run (relative to the sub-block)
+    float *seg_t0 = (float *)(seg_spos + seg_cap);                // lattice point of the run's first sample
+    int32_t *seg_j1 = (int32_t *)(seg_t0 + seg_cap);              // index of the first lattice point past t0's binade (INT_MAX: none in the run)
+    int32_t *seg_ray = seg_j1 + seg_cap;                          // the run's ray (its index in the block; + kSegSkip: not written here)
+    int32_t *ray_base = seg_ray + seg_cap;                        // [64] first quad of every ray
+    int64_t *seg_eoff = (int64_t *)(ray_base + 64);               // (IV only) edge index of a sample = its sample index + this
+    // W = 64 / RB lanes share a ray while the segment list is built: lane (ray_l, w) takes the ray's runs w, w + W, ...
+    const int RB = 1 << rb_log2, wshift = 6 - rb_log2, W = 1 << wshift;
+    const int ray_l = lane >> wshift, w = lane & (W - 1);
+    const bool head = w == 0;
+    const int64_t n_rb = (R + RB - 1) >> rb_log2;
+    for (int64_t blk = (int64_t)blockIdx.x * kWavesPerBlock + wib; blk < n_rb; blk += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t r0 = blk << rb_log2, r = r0 + ray_l;
+        const bool own = r < R;
+        int64_t S = 0, cnt = 0, E = 0;
+        int nr = 0;
+        float t0_q = 0.0f, t0_q2 = 0.0f;
+        int32_t first_q = 0, next_q = 0, first_q2 = 0, next_q2 = 0;
+        if (own) {
+            // ONE round trip: the ray's counts and its first 2 W run records (their addresses do not depend on the counts)
+            cnt = a.sm_cnts[r]; S = a.sm_starts[r]; nr = rs.n_runs[r];
+            if (IV) E = a.iv_starts[r];
+            if (w < rs.max_runs) { t0_q = rs.t0[(int64_t)w * R + r]; if (w > 0) first_q = rs.first[(int64_t)w * R + r]; }
+            if (w + 1 < rs.max_runs) next_q = rs.first[(int64_t)(w + 1) * R + r];
+            if (W + w < rs.max_runs) { t0_q2 = rs.t0[(int64_t)(W + w) * R + r]; first_q2 = rs.first[(int64_t)(W + w) * R + r]; }
+            if (W + w + 1 < rs.max_runs) next_q2 = rs.first[(int64_t)(W + w + 1) * R + r];
+        }
+        if (!checked) {
+            if (n_total > capacity) return;                         // outputs too small: the caller launches again after its read-back
+            checked = true;
+        }
+        if (cnt < 0) cnt = 0;
+        const bool skip = nr == kRunsOverflow;
+        const int nseg = cnt > 0 ? (skip ? 1 : nr) : 0;
+        const int P = wave_incl_scan_i32(head ? nseg : 0);          // inclusive prefix of the rays' segment counts (the same in a ray's W lanes)
+        if (readlane_dyn_i32(P, 63) == 0) continue;                 // a block of rays without samples
+        // rays beyond the last one inherit its end (monotone ends for the sub-block search below)
+        const int n_own = (int)((R - r0) < RB ? (R - r0) : RB);
+        int64_t End = S + cnt;
+        {
+            const int64_t last_end = readlane_dyn_i64(End, (n_own << wshift) - 1);
+            if (ray_l >= n_own) { S = last_end; End = last_end; }
+        }
+        int a_ray = 0, seg_off = 0;
+        while (a_ray < n_own) {
+            const int64_t S_a = readlane_dyn_i64(S, a_ray << wshift);
+            // the sub-block: rays [a_ray, b_ray) — as many whole rays as the segment list holds (and 2^31 samples at most)
+            const bool fits = ray_l >= a_ray && ray_l < n_own && (P - seg_off) <= seg_cap && (End - S_a) < (1ll << 31);
+            const unsigned long long fm = __ballot(fits) >> (a_ray << wshift);
+            int n_take = (fm == ~0ull ? 64 : __ffsll((long long)~fm) - 1) >> wshift;     // leading run of ones, in rays
+            if (n_take < 1) n_take = 1;                              // (one ray's runs always fit; one ray of >= 2^31 samples: below)
+            const int b_ray = a_ray + n_take;
+            const bool in_sub = ray_l >= a_ray && ray_l < b_ray;
+            const int my_base = P - nseg - seg_off;
+            const int n_sub = readlane_dyn_i32(P, (b_ray << wshift) - 1) - seg_off;
+            const int64_t sub_end = readlane_dyn_i64(End, (b_ray << wshift) - 1);
+            const bool too_long = sub_end - S_a >= (1ll << 31);      // (one ray of >= 2^31 samples: flagged by the count pass, the fallback launch writes it)
+            // the segment list, quad positions counted from the RAY's first quad; a round takes W runs of every ray
+            int carry = 0;                                           // quads of the ray's earlier rounds
+            for (int round = 0;; ++round) {
+                const int q = (round << wshift) + w;
+                const bool valid = in_sub && q < nseg;
+                if (__ballot(valid) == 0ull) break;
+                // the records of this round were requested a round ago (round 0 and 1: with the ray's counts); request the next round's
+                if (round >= 1) {
+                    t0_q = t0_q2; first_q = first_q2; next_q = next_q2;
+                    const int qn = q + W;
+                    if (in_sub && qn < nseg) {
+                        t0_q2 = rs.t0[(int64_t)qn * R + r];
+                        first_q2 = rs.first[(int64_t)qn * R + r];
+                        next_q2 = qn + 1 < nseg ? rs.first[(int64_t)(qn + 1) * R + r] : 0;
+                    }
+                }
+                const int32_t first = (skip || q == 0) ? 0 : first_q;
+                const int32_t next = (skip || q + 1 >= nseg) ? (int32_t)cnt : next_q;
+                const int len = valid ? next - first : 0;
+                const int quads = (len + 3) >> 2;
+                const int incl = wave_seg_incl_scan_i32(quads, w);
+                if (valid) {
+                    const int k = my_base + q;
+                    seg_qpos[k] = carry + incl - quads;
+                    seg_spos[k] = (int32_t)(S - S_a) + first;
+                    seg_t0[k] = t0_q;
+                    seg_ray[k] = ray_l + ((skip || too_long) ? kSegSkip : 0);
+                    // index of the first lattice point past t0's binade: the steps that stay inside, plus the one that crosses
+                    const uint32_t tb = nfa_f2u(t0_q);
+                    const uint32_t inc = L.inc_at(tb);
+                    int32_t j1 = 0x7fffffff;
+                    if (inc != 0u) {
+                        const uint32_t x = (1u << 24) - 1u - ((tb & 0x7fffffu) | 0x800000u);
+                        uint32_t n_in = (uint32_t)((float)x / (float)inc);         // both < 2^24: exact operands, the correctly
+                        n_in -= ((uint64_t)n_in * inc > x) ? 1u : 0u;              // rounded quotient truncates to floor or floor + 1
+                        n_in += ((uint64_t)(n_in + 1u) * inc <= x) ? 1u : 0u;
+                        if ((int)n_in + 1 < len) j1 = (int32_t)n_in + 1;
+                    }
+                    seg_j1[k] = j1;
+                    if (IV) seg_eoff[k] = E - S + q + 1;
+                }
+                carry += __shfl(incl, lane | (W - 1), 64);           // the round's quads of this ray (its last lane holds the sum)
+            }
+            // the ray's first quad = exclusive prefix of the rays' quad counts; every entry then moves by its ray's base
+            const int QP = wave_incl_scan_i32(head && in_sub ? carry : 0);
+            const int n_quads = too_long ? 0 : readlane_dyn_i32(QP, 63);
+            const int span = (int)(sub_end - S_a);
+            if (head && in_sub) ray_base[ray_l] = QP - carry;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = lane; k < n_sub; k += 64) seg_qpos[k] += ray_base[seg_ray[k] & 63];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int seg_lo = 0;                                          // wave-uniform: the run of the chunk's first quad
+            for (int qc = 0; qc < n_quads; qc += 64) {
+                const int slot = qc + lane;
+                int seg = seg_lo;
+                if (slot < n_quads) {
+                    int lo = seg_lo, hi = seg_lo + 65 < n_sub ? seg_lo + 65 : n_sub;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_qpos[mid] <= slot) lo = mid; else hi = mid; }
+                    seg = lo;
+                    const int ray_s = seg_ray[seg];
+                    if (ray_s < kSegSkip) {
+                        const int sp = seg_spos[seg];
+                        const int j = 4 * (slot - seg_qpos[seg]);                   // the quad's first sample within its run
+                        const int len = (seg + 1 < n_sub ? seg_spos[seg + 1] : span) - sp;
+                        const int nv = len - j < 4 ? len - j : 4;                   // samples of this quad (>= 1)
+                        const int j1 = seg_j1[seg];
+                        float tbase = seg_t0[seg];
+                        uint32_t tb = nfa_f2u(tbase);
+                        uint32_t inc = L.inc_at(tb);
+                        int jj = j;
+                        if (j >= j1) {                                              // past t0's binade: restart from the first point beyond
+                            tbase = nfa_u2f(tb + (uint32_t)(j1 - 1) * inc) + dt;    // (j1 was formed with this inc: exact inside the binade, one real add)
+                            tb = nfa_f2u(tbase);
+                            inc = L.inc_at(tb);
+                            jj = j - j1;
+                        }
+                        float sv[5];
+                        const uint64_t top = (uint64_t)((tb & 0x7fffffu) | 0x800000u) + (uint64_t)(uint32_t)(jj + 4) * inc;
+                        if (inc != 0u && top < (1ull << 24)) {
+                            const uint32_t b0 = tb + (uint32_t)jj * inc;
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) sv[k] = nfa_u2f(b0 + (uint32_t)k * inc);
+                        } else {                                                    // (a quad on a binade edge, a second edge in one run)
+                            sv[0] = nfa_lattice_advance(tbase, dt, (int64_t)jj, nullptr);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sv[k + 1] = sv[k] + dt;
+                        }
+                        const int64_t s = S_a + sp + j, rr = r0 + ray_s;
+                        if (!IV && nv == 4) {
+                            typedef float vf4 __attribute__((ext_vector_type(4)));
+                            if (a.t_starts) {
+                                const vf4 v0 = {sv[0], sv[1], sv[2], sv[3]}, v1 = {sv[1], sv[2], sv[3], sv[4]};
+                                __builtin_memcpy(a.t_starts + s, &v0, 16);
+                                __builtin_memcpy(a.t_ends + s, &v1, 16);
+                            }
+                            if (a.sm_vals) {
+                                const vf4 m = {(sv[1] + sv[0]) * 0.5f, (sv[2] + sv[1]) * 0.5f, (sv[3] + sv[2]) * 0.5f, (sv[4] + sv[3]) * 0.5f};
+                                __builtin_memcpy(a.sm_vals + s, &m, 16);
+                            }
+                            if (a.sm_ray_indices) {
+                                const int64_t rv[4] = {rr, rr, rr, rr};
+                                __builtin_memcpy(a.sm_ray_indices + s, rv, 32);
+                            }
+                            if (a.sm_is_valid) { const uint32_t ones = 0x01010101u; __builtin_memcpy(a.sm_is_valid + s, &ones, 4); }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (e >= nv) break;
+                                const float ta = sv[e], tb2 = sv[e + 1];
+                                if (a.sm_vals) a.sm_vals[s + e] = (tb2 + ta) * 0.5f;
+                                if (a.sm_ray_indices) a.sm_ray_indices[s + e] = rr;
+                                if (a.sm_is_valid) a.sm_is_valid[s + e] = 1;
+                                if (a.t_starts) { a.t_starts[s + e] = ta; a.t_ends[s + e] = tb2; }
+                                if (IV && a.iv_vals) {
+                                    // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
+                                    const int64_t e_right = s + e + seg_eoff[seg];
+                                    a.iv_vals[e_right] = tb2; a.iv_ray_indices[e_right] = rr; a.iv_is_right[e_right] = 1;
+                                    a.iv_is_left[e_right - 1] = 1;
+                                    if (j + e == 0) { a.iv_vals[e_right - 1] = ta; a.iv_ray_indices[e_right - 1] = rr; }
+                                }
+                            }
+                        }
+                    }
+                }
+                seg_lo = readlane_dyn_i32(seg, 63);                  // (lane 63 idle = the last chunk)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                          // the list is rewritten by the next sub-block
+            seg_off = readlane_dyn_i32(P, (b_ray << wshift) - 1);
+            a_ray = b_ray;
+        }
+    }
+}
+
+// the tile form's own kernel: the host launches it for every cone_angle == 0 call (`emit` option: auto or tiles)
+template <bool IV>
+__global__ __launch_bounds__(kBlock) void traverse_emit_tiles_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
+                                                                     const int64_t *__restrict__ n_dev, int speculative, int rb_log2, int seg_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
+    emit_by_tiles<IV>(a, rs, rb_log2, seg_cap, emit_lds, n_dev, capacity, speculative);
+}
+
 // pass 2: ONE launch, the form chosen ON THE DEVICE from the totals the offsets kernel left in the workspace (the speculative
 // launch runs before the host has seen them).  16 lanes per ray pay per RUN (~25 instructions + a pass per 64 samples), a lane per
 // sample pays ~14 dependent loads per SAMPLE: the ray groups win on long runs and lose on a grid of alternating voxels (the
 // reference's `rand > 0.5` test grid: 271 samples per ray in ~130 runs — 113 vs 77 us at 4 k rays when the choice looked at the
 // sample count alone, profiles/r03_count_pass.md).  runs = edges - samples.  With a cone angle the sample-parallel form re-runs a
 // sample's chain from its run's start, so the ray groups take over at much shorter runs.
-//   hint: 0 = choose, 1 = ray groups, 2 = lane per sample (NFA_EMIT).  speculative: outputs hold `capacity` samples — a launch whose
-//   outputs are too small does nothing, the caller launches again with the right size.
+//   hint: 0 = choose, 1 = ray groups, 2 = lane per sample (the `emit` option; tiles: traverse_emit_tiles_kernel, cone_angle == 0 only).
+//   speculative: outputs hold `capacity` samples — a launch whose outputs are too small does nothing, the caller launches again
+//   with the right size.
 __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
                                                                const int64_t *__restrict__ n_dev, int speculative, int hint)
 {
@@ -216,7 +545,6 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args
     if (speculative && n_sm > capacity) return;
     const int64_t runs = n_ed - n_sm > 0 ? n_ed - n_sm : 1;
     const bool long_runs = a.cone_angle != 0.0f ? n_sm >= 8 * runs : (n_sm >= 900000 && n_sm >= 20 * runs);
-    if (hint == 1 || (hint == 0 && long_runs)) emit_by_ray_groups(a, rs);
+    if (hint == 1 || (hint != 2 && long_runs)) emit_by_ray_groups(a, rs);
     else emit_by_samples(a, rs, speculative ? n_sm : capacity);
 }
-

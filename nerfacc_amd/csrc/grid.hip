@@ -1228,6 +1228,11 @@ NFA_EXPORT int64_t nfa_traverse_workspace_bytes_for(const nfa_traverse_args *a) 
 // lanes per ray of the count pass for this call (1 = lane-per-ray kernels).  `sparse`: the full
 // occupancy image fits in LDS (few non-empty bricks: a blob-like grid, few occupied<->empty
 // boundaries per ray).
+// half of the bricks or more hold an occupied voxel (the reference's rand > 0.5 test grid: all of them), or nothing is known
+static bool grid_is_noisy(const nfa_traverse_args *a) {
+    const int64_t n_bricks = (int64_t)a->n_grids * ceil_div(a->res[0], 4) * ceil_div(a->res[1], 4) * ceil_div(a->res[2], 4);
+    return a->n_nonempty_bricks < 0 || 2 * a->n_nonempty_bricks >= n_bricks;
+}
 static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     const bool split = lattice && !a->t_sorted && a->n_grids == 1 && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
@@ -1243,10 +1248,21 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
             if (a->n_rays <= 16384) P = 16;
             else if (a->n_rays <= 98304) P = 8;
         } else {
-            if (a->n_rays <= 8192) P = 16;
-            else if (a->n_rays <= 16384) P = 8;
-            else if (a->n_rays <= 36864) P = 4;
-            else if (a->n_rays <= 65536) P = 2;
+            // Grids read from L2 (256^3, or dense at 128^3).  Round 4, six scenes x six ray counts x two resolutions
+            // (tools/experiments/r04_count_grid.py, profiles/r04_count_pass.md).  With the share of non-empty bricks known (the
+            // caller read it back with the packed grid's header) plan_split gives every grid that is not noise-like 16-entry
+            // boundary lists — five workgroups per CU instead of two — and then 16 lanes per ray are the best or within 1.22x of it
+            // up to 48 k rays on every scene (46 vs 66 us at 12 k rays of the 256^3 lego, 124 vs 192 at 48 k), 8 up to 96 k; a
+            // noise grid keeps 32-entry lists and 16 lanes (8 overflow them: 683 vs 380 us at 48 k rays).  Round 3's 4 and 2 lanes
+            // per ray for 16 k-64 k rays were tuned on one scene and cost 2-2.8x on the noise and the thin-structure scenes.
+            if (a->n_nonempty_bricks >= 0) {
+                if (grid_is_noisy(a)) P = a->n_rays <= 98304 ? 16 : 1;
+                else P = a->n_rays <= 49152 ? 16 : a->n_rays <= 98304 ? 8 : 1;
+            } else {        // nothing known about the grid: 32-entry lists
+                if (a->n_rays <= 8192) P = 16;
+                else if (a->n_rays <= 49152) P = 8;
+                else if (a->n_rays <= 98304) P = 4;
+            }
         }
         if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
             P = (int)opt(OPT_SPLIT_P, P);
@@ -1334,7 +1350,18 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     if (p.gv.lds_compact_cap == 0 && p.xt) { p.xt = 0; p.gv = make_view(a, p.cap * p.blk * 8, &p.lds, budget); }
     if (p.gv.lds_compact_cap == 0 && p.blk != kBlock) { p.blk = kBlock; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
     if (p.gv.lds_compact_cap == 0) {
+        // the image does not fit beside the lists: read from L2.  A part's boundary list holds 32 entries (64 KB of LDS per
+        // workgroup, two per CU) where the grid may be noisy — the reference's rand > 0.5 grid has a boundary every other voxel and
+        // 16-entry lists overflow into the streaming mode — and 16 (32 KB, five per CU: the form `l2` of the sparse grids) elsewhere
         p.P = count_lanes_per_ray(a, false);
+        int cap = (int)opt(OPT_SPLIT_CAP, grid_is_noisy(a) ? 32 : 16);
+        if (p.P != 8 && p.P != 16) cap = 32;           // (2 and 4 lanes per ray exist with 32-entry lists only)
+        if (cap == 16) {
+            p.l2 = 1;
+            p.cap = 16;
+            p.gv = make_view(a, p.cap * kBlock * 8, &p.lds, 0);
+            return p;
+        }
         p.cap = 32;
         p.gv = make_view(a, p.cap * kBlock * 8, &p.lds);
         return p;
@@ -1511,6 +1538,10 @@ static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_c
 static int emit_hint() {
     return (int)opt(OPT_EMIT, 0);
 }
+// The emit pass of a call: cone_angle == 0 takes the tile form (its own kernel: a wave expands a block of consecutive rays,
+// emit_pass.hpp) unless the `emit` option forces one of the older forms; cone_angle != 0 takes traverse_emit_kernel (ray groups
+// or a lane per sample, chosen on the device).  `speculative`: see nfa_traverse_emit_speculative.
+static int launch_emit(const nfa_traverse_args *a, const RunStore &rs, int64_t capacity, const int64_t *n_dev, int speculative, hipStream_t s);
 static unsigned emit_ray_blocks(int64_t n_rays) {
     const int64_t nb = ceil_div(n_rays, kBlock / 16), cap = (int64_t)kNumCU * 8;
     return (unsigned)(nb < cap ? nb : cap);
@@ -1533,9 +1564,7 @@ NFA_EXPORT int nfa_traverse_fill(const nfa_traverse_args *a, int32_t skip_empty,
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     if (n_samples > 0) {
         const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
-        const unsigned nb_s = blocks_for(n_samples), nb_r = emit_ray_blocks(a->n_rays);
-        hipLaunchKernelGGL(traverse_emit_kernel, dim3(nb_s > nb_r ? nb_s : nb_r), dim3(kBlock), 0, s, *a, rs, n_samples, n_dev, 0, emit_hint());
-        if (int rc = check_launch("traverse_emit_kernel")) return rc;
+        if (int rc = launch_emit(a, rs, n_samples, n_dev, 0, s)) return rc;
     }
     if (n_overflow > 0) return launch_fill(a, 1, 0, rs.n_runs, s);
     return NFA_OK;
@@ -1550,8 +1579,30 @@ NFA_EXPORT int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const v
     if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_emit_speculative: t_starts without t_ends");
     const RunStore rs = make_runs(const_cast<void *>(workspace), a->n_rays);
     const int64_t *n_dev = (const int64_t *)((const uint8_t *)workspace + ws_totals_offset(a->n_rays));
+    return launch_emit(a, rs, capacity, n_dev, 1, (hipStream_t)stream);
+}
+
+static int launch_emit(const nfa_traverse_args *a, const RunStore &rs, int64_t capacity, const int64_t *n_dev, int speculative, hipStream_t s)
+{
+    const int hint = emit_hint();
+    if (a->cone_angle == 0.0f && a->step_size > 0.0f && (hint == 0 || hint == 3)) {
+        const int64_t R = a->n_rays;
+        // rays per wave: enough waves for every SIMD (1024) to hold two or more; segment-list capacity: a ray's runs must fit
+        // (run_capacity), 128 at least — a 64-ray block of a NeRF-like scene has 40-80 runs
+        const int rb_log2 = (int)opt(OPT_EMIT_RB, R <= 2048 ? 0 : R <= 4096 ? 1 : R <= 8192 ? 2 : R <= 32768 ? 3 : R <= 131072 ? 4 : R <= 262144 ? 5 : 6);      // (tools/experiments/r04_emit_rb*.{sh,py})
+        int seg_cap = 128;
+        while (seg_cap < rs.max_runs) seg_cap *= 2;
+        const int words = kEmitSegWords + (a->iv_vals ? 2 : 0);
+        const unsigned lds = (unsigned)(kWavesPerBlock * (seg_cap * 4 * words + kEmitRayBaseBytes));
+        const int64_t n_rb = ceil_div(R, (int64_t)1 << rb_log2), cap = (int64_t)kNumCU * 16;
+        const int64_t nb = ceil_div(n_rb, kWavesPerBlock);
+        const dim3 g((unsigned)(nb < cap ? nb : cap)), b(kBlock);
+        if (a->iv_vals) hipLaunchKernelGGL(traverse_emit_tiles_kernel<true>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, seg_cap);
+        else hipLaunchKernelGGL(traverse_emit_tiles_kernel<false>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, seg_cap);
+        return check_launch("traverse_emit_tiles_kernel");
+    }
     const unsigned nb_s = blocks_for(capacity), nb_r = emit_ray_blocks(a->n_rays);
-    hipLaunchKernelGGL(traverse_emit_kernel, dim3(nb_s > nb_r ? nb_s : nb_r), dim3(kBlock), 0, (hipStream_t)stream, *a, rs, capacity, n_dev, 1, emit_hint());
+    hipLaunchKernelGGL(traverse_emit_kernel, dim3(nb_s > nb_r ? nb_s : nb_r), dim3(kBlock), 0, s, *a, rs, capacity, n_dev, speculative, hint == 3 ? 0 : hint);
     return check_launch("traverse_emit_kernel");
 }
 

@@ -35,10 +35,11 @@ bool parse_one_of(const char *s, int64_t *out) {
 }
 bool parse_bool(const char *s, int64_t *out) { return parse_one_of<0, 1>(s, out); }
 bool parse_tile(const char *s, int64_t *out) { return parse_int(s, out) && *out >= 64 && *out % 64 == 0; }
-// strictly "rays" | "samples" (anything else used to mean "samples")
+// strictly "rays" | "samples" | "tiles" (anything else used to mean "samples")
 bool parse_emit(const char *s, int64_t *out) {
     if (!strcmp(s, "rays")) { *out = 1; return true; }
     if (!strcmp(s, "samples")) { *out = 2; return true; }
+    if (!strcmp(s, "tiles")) { *out = 3; return true; }
     return false;
 }
 
@@ -51,11 +52,13 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"cone", "0: cone_angle != 0 takes the general lane-per-ray kernel", parse_bool},
     {"split_l2", "16 lanes per ray: grid image in LDS (0) / read from L2 (1)", parse_bool},
     {"count_l2", "lane-per-ray count and fill kernels: grid image in LDS (0) / from L2 (1)", parse_bool},
-    {"emit", "emit pass: rays (16 lanes per ray walk its run records) | samples (a lane per sample)", parse_emit},
+    {"emit", "emit pass: rays (16 lanes per ray walk its run records) | samples (a lane per sample) | tiles (a wave expands a block of rays)", parse_emit},
     {"scan_rw", "packed scan: rows per wave 4 | 16", parse_one_of<4, 16>},
     {"split_blk", "workgroup size of the 16-lane count pass: 256 | 512", parse_one_of<256, 512>},
     {"split_xt", "0: no crossing-time arrays in the 512-thread count pass", parse_bool},
     {"segments", "0: several levels take the lane-per-ray count pass", parse_bool},
+    {"split_cap", "grids read from L2: entries of a part's boundary list, 16 | 32", parse_one_of<16, 32>},
+    {"emit_rb", "tile form of the emit pass: log2 of the rays per wave, 0 ... 6", parse_one_of<0, 1, 2, 3, 4, 5, 6>},
     {"speculative_emit", "0: sample_occgrid of the torch extension launches the emit pass after the read-back", parse_bool},
 };
 

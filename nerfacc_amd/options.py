@@ -17,7 +17,7 @@ import contextlib
 import ctypes
 from typing import Dict, Optional, Union
 
-_EMIT_NAMES = {1: "rays", 2: "samples"}
+_EMIT_NAMES = {1: "rays", 2: "samples", 3: "tiles"}
 
 
 def _lib():

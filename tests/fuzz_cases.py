@@ -192,7 +192,7 @@ def api_case(g, ray_counts=(3, 100, 2000, 12000)):
                 desc=f"api levels={levels} res={res} R={R} step={step} cone={cone} kw={ {k: v for k, v in kw.items() if k != 'rays_mask'} }")
 
 
-def check_api(case, emit_forms=("rays", "samples")):
+def check_api(case, emit_forms=("rays", "samples", "tiles")):
     """nerfacc_amd.grid.traverse_grids under both emit kernels vs the oracle, every output"""
     bad, n = [], 0
     import nerfacc_amd
@@ -229,7 +229,7 @@ SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 # where the grid image is read from (single level, cone_angle = 0): LDS / L2 with 16 lanes per ray, L2 with 8, and the
 # lane-per-ray kernel from LDS / L2
 IMAGE_FORMS = ("NFA_SPLIT_L2=0,NFA_SPLIT_P=16", "NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_P=8", "NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_COUNT_L2=1,NFA_SPLIT_P=1")
-EMIT_FORMS = ("rays", "samples")     # NFA_EMIT: 16 lanes per ray walking its run records / a lane per sample with searches
+EMIT_FORMS = ("rays", "samples", "tiles")     # NFA_EMIT: 16 lanes per ray walking its run records / a lane per sample with searches
 SEGMENT_FORMS = ("1", "0")
 SEG_P_FORMS = ("8", "32")        # NFA_SEG_P: one lane per level segment / four (parts), cone_angle = 0, up to 4 levels
 CONE_FORMS = ("1", "0")          # NFA_CONE: lane-per-segment walk + serial chain (cone_walk.hpp) / the general lane-per-ray kernel

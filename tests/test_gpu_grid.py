@@ -275,45 +275,3 @@ def test_sample_positions_bit_identical_to_the_torch_expression():
     p2.sum().backward()
     assert torch.equal(p2.detach(), want) and o2.grad is not None and float(o2.grad.sum()) == float(N * 3)
     assert nerfacc.sample_positions(o, d, ri[:0], ts[:0], te[:0]).shape == (0, 3)
-
-
-def test_emit_form_chosen_on_the_device_is_near_the_better_one(force_options):
-    """the emit pass picks its form from the call's totals (samples per run, emit_pass.hpp).  Two scenes pull in opposite directions:
-    the reference's `rand > 0.5` test grid (tests/test_grid.py: hundreds of two-sample runs per ray — 16 lanes per ray lose by 4x)
-    and a blob crossed by 40 k rays (1.5 M samples in long runs — they win).  The automatic choice must stay within 30 % of the
-    better forced form's emit time on both, and all three must emit the same samples."""
-    from nerfacc_amd import cuda as C
-    from nerfacc_amd.cuda import _backend
-
-    g = np.random.default_rng(7)
-
-    def rays(n, spread):
-        v = g.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
-        o = (0.5 + 1.5 * v).astype(np.float32)
-        d = (0.5 + spread * (g.random((n, 3)) - 0.5)).astype(np.float32) - o
-        return t(o), t((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
-
-    c = (np.arange(128) + 0.5) / 128
-    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
-    scenes = {"alternating voxels": (t(g.random((1, 128, 128, 128)) > 0.5), rays(4096, 1.0), 5e-3 / 3),
-              "blob, long runs": (t((((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2) < 0.3 ** 2)[None]), rays(40000, 0.4), 2e-3)}
-    aabb = t(np.array([[0, 0, 0, 1, 1, 1]], np.float32))
-    for name, (occ, (o, d), step) in scenes.items():
-        near, far = torch.zeros(o.shape[0], device=DEV), torch.full((o.shape[0],), 1e10, device=DEV)
-        us, outs = {}, {}
-        for form in ("", "rays", "samples"):
-            force_options(emit=form or None)
-            for _ in range(3):
-                outs[form] = C.sample_occgrid(o, d, occ, aabb, near, far, step, 0.0)
-            torch.cuda.synchronize()
-            timer = _backend.KernelTimer(names=("traverse_fill",))
-            _backend.set_kernel_timer(timer)
-            for _ in range(10):
-                C.sample_occgrid(o, d, occ, aabb, near, far, step, 0.0)
-            us[form] = timer.summary()["traverse_fill"][1] * 1e3
-            _backend.set_kernel_timer(None)
-        for form in ("rays", "samples"):
-            assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[""], outs[form])), (name, form)
-        best = min(us["rays"], us["samples"])
-        assert us[""] <= 1.3 * best + 2.0, (name, us)
-        assert max(us["rays"], us["samples"]) > 1.15 * best, (name, us, "the scene no longer separates the two forms")

@@ -139,14 +139,14 @@ def test_hip_reproduces_reference_k2(name, k2):
 # Every kernel FORM that can serve a case, forced through the library's options (nerfacc_amd.set_option), against the reference's
 # own output — not only against the oracle.  {} = the automatic choice.
 _ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}, {"split_p": 8}, {"split_p": 1, "count_l2": 0},
-              {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}]
-_LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}]
+              {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}]
+_LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}]
 _CONE_ONE = [{}, {"cone": 0}, {"cone": 1, "emit": "rays"}, {"cone": 1, "emit": "samples"}, {"cone": 0, "emit": "rays"}]
 _CONE_LEVELS = _CONE_ONE + [{"cone": 1, "cone_p": p} for p in (8, 16, 32, 64)] + [{"cone_p": 64, "emit": "samples"}]
 SAMPLING_FORMS = {
     "m1_sphere": _ONE_LEVEL, "m1_noise": _ONE_LEVEL, "lego_4k": _ONE_LEVEL, "lego_12k": _ONE_LEVEL, "lego_256": _ONE_LEVEL,
-    "lego_70k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}],
-    "lego_160k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 0}, {"emit": "rays"}, {"emit": "samples"}],
+    "lego_70k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}],
+    "lego_160k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 0}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}],
     "near_far": _LEVELS, "degenerate": _LEVELS, "two_level_256": _LEVELS, "non_cubic": _LEVELS, "levels4_inside": _LEVELS,
     "cone_angle": _CONE_ONE, "cone_angle_levels": _CONE_LEVELS,
 }
