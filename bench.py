@@ -90,14 +90,14 @@ class DenseGridField(torch.nn.Module):
     """sigma = exp(g[0](x)), rgb = sigmoid(g[1:4](x)); one 4-channel voxel grid, trilinear lookups
     (one gather pass forward, one scatter pass backward per query)."""
 
-    def __init__(self, aabb, res=128):
+    def __init__(self, aabb, res=128, occ_fn=None):
         super().__init__()
         self.register_buffer("aabb", torch.tensor(aabb, dtype=torch.float32))
         g = (torch.arange(res, dtype=torch.float32) + 0.5) / res
         lo, hi = self.aabb[:3], self.aabb[3:]
         X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
         pts = torch.stack([X, Y, Z], -1) * (hi - lo) + lo
-        occ = lego_like_density(pts)
+        occ = (occ_fn or lego_like_density)(pts)
         dens = torch.where(occ, math.log(50.0), math.log(1e-4)).float()
         gen = torch.Generator().manual_seed(42)
         col = torch.randn((3, res, res, res), generator=gen) * 0.5 + (pts.permute(3, 0, 1, 2) * 1.5)
@@ -497,6 +497,76 @@ def propnet_step_leg(field, pool_o, pool_d, pool_rgb, bkgd, n_steps, n_warmup, n
 # ------------------------------------------------------------------------------------------
 # GPU activity of a few profiled steps: union of kernel intervals (idle fraction) and the nfa:: share
 # ------------------------------------------------------------------------------------------
+def scene_sweep_leg(pool_o, pool_d, bkgd, n_steps, n_warmup, pretrain=300, occ_res=256, n_pool=1 << 18):
+    """BASELINE.json configs[4] (the reference's 8-scene nerf_synthetic sweep with a 256^3 occupancy grid, PSNR + rays/s per scene,
+    docs/source/examples/static/ngp.rst:36-42) on stand-ins: the eight procedural scenes of tools/scenes.py — thin structures, a
+    dense slab, a hollow shell, a near-empty grid, the reference's rand > 0.5 noise, ... — each with its own teacher field, a student
+    trained from fog for `pretrain` steps of the configs[1] loop (256^3 occupancy grid, adaptive batch towards 2^18 samples), then
+    `n_steps` timed steps: rays/s, samples/s, samples per ray, PSNR on held-out rays.  Not the metric: what it guards is that the
+    data-dependent plan switches of the sampling call (tools/scene_sweep.py checks them kernel by kernel) hold up across scenes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scenes as S
+
+    device = pool_o.device
+    n_pool = min(n_pool, pool_o.shape[0])
+    n_held = min(16384, n_pool // 4)
+    pool_o, pool_d = pool_o[:n_pool], pool_d[:n_pool]
+    held = slice(n_pool - n_held, n_pool)                    # rays the students never train on
+    out = {}
+    for name, occ_fn in S.SCENES.items():
+        torch.manual_seed(7)
+        teacher = DenseGridField(AABB, GRID_RES, occ_fn=lambda x, f=occ_fn: f(torch, x)).to(device).eval()
+        student = DenseGridField(AABB, GRID_RES).to(device)
+        with torch.no_grad():
+            student.grid[:, :1].fill_(math.log(0.5))
+            student.grid[:, 1:].zero_()
+        est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=occ_res, levels=1).to(device)
+        est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=occ_res, levels=1).to(device)
+        est_t.train()
+        for _ in range(4):
+            est_t._update(step=0, occ_eval_fn=lambda x: teacher.query_density(x) * RENDER_STEP, occ_thre=1e-2)
+        est_t.eval()
+        with torch.no_grad():
+            rgb_pool = torch.cat([render_rays(teacher, est_t, pool_o[i:i + (1 << 16)], pool_d[i:i + (1 << 16)], bkgd, False)[0]
+                                  for i in range(0, n_pool, 1 << 16)])
+        opt = torch.optim.Adam(student.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
+        est.train()
+        st = {"rays": INIT_RAYS, "step": 0, "n": 0, "s": 0}
+
+        def step():
+            est.update_every_n_steps(step=st["step"], occ_eval_fn=lambda x: student.query_density(x) * RENDER_STEP, occ_thre=1e-2)
+            idx = torch.randint(0, n_pool - n_held, (st["rays"],), device=device)
+            rgb, _, _, n_s = render_rays_reference_style(student, est, pool_o[idx], pool_d[idx], bkgd, True)
+            opt.zero_grad()
+            if n_s > 0:
+                (F.smooth_l1_loss(rgb, rgb_pool[idx]) * 1024.0).backward()
+                opt.step()
+                st["rays"] = min(max(int(st["rays"] * (TARGET_SAMPLES / n_s)), 64), n_pool - n_held)      # train_ngp_nerf_occ.py:187-194
+            st["n"] += idx.shape[0]
+            st["s"] += n_s
+            st["step"] += 1
+
+        for _ in range(pretrain + n_warmup):
+            step()
+        st.update(n=0, s=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        est.eval()
+        with torch.no_grad():
+            pred = render_rays(student, est, pool_o[held], pool_d[held], bkgd, False)[0]
+            mse = F.mse_loss(pred, rgb_pool[held]).item()
+        out[name] = {"ms_per_step": dt / n_steps * 1e3, "rays_per_sec": st["n"] / dt, "samples_per_sec": st["s"] / dt,
+                     "rays_per_iter": st["n"] / n_steps, "samples_per_ray": st["s"] / max(st["n"], 1),
+                     "occupied_fraction": est.binaries.float().mean().item(), "psnr_heldout": -10.0 * math.log10(max(mse, 1e-12))}
+    return {"workload": f"configs[4] stand-in: eight procedural scenes (tools/scenes.py), {occ_res}^3 occupancy grid, the configs[1] step; "
+                        f"{pretrain} training steps from fog, then {n_steps} timed steps; PSNR against the scene's teacher on {n_held} held-out rays",
+            "scenes": out}
+
+
 def profile_steps(step_fn, n_steps):
     """{'busy_us_per_step', 'nfa_us_per_step', 'kernels_per_step', 'nfa_kernels_per_step', 'top'} from torch.profiler's
     device-kernel events, or None when the profiler is unavailable"""
@@ -591,6 +661,8 @@ def main():
                     help="initialise the process group (and use ExchangeAdam's exchange) even with one rank: the RCCL world-1 smoke test")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (configs[4] 256^3 grid, configs[2] PropNet step)")
     ap.add_argument("--aux-steps", type=int, default=40, help="timed steps of each auxiliary leg")
+    ap.add_argument("--no-scene-sweep", action="store_true", help="skip aux.configs4_scene_sweep (eight procedural scenes at 256^3)")
+    ap.add_argument("--scene-pretrain", type=int, default=300, help="training steps from fog of every scene of aux.configs4_scene_sweep")
     ap.add_argument("--dump-sampling-state", default="",
                     help="write the occupancy grid and one ray batch of the timed steady state to this .npz "
                          "(tools/traverse_replay.py replays the sampling call on it under rocprofv3)")
@@ -897,6 +969,8 @@ def main():
             state["est"], state["num_rays"], state["step"] = saved
             del est256
         aux["configs2_propnet_step"] = propnet_step_leg(field, pool_o, pool_d, pool_rgb, bkgd, args.aux_steps, min(args.warmup, 10))
+        if not args.no_scene_sweep:
+            aux["configs4_scene_sweep"] = scene_sweep_leg(pool_o, pool_d, bkgd, args.aux_steps, min(args.warmup, 10), pretrain=args.scene_pretrain)
 
     if rank == 0:
         elapsed = main_run["elapsed"]

@@ -370,8 +370,9 @@ int nfa_edge_cdfs_bwd(const float *t_edges, const float *trans, const float *g_c
  * the key intervals overlapping query interval i (searchsorted of the query edges in the key edges, pdf.cu:245-286).
  * query_vals, cdfs_query: [n_rays, n_query + 1]; key_vals, cdfs_key: [n_rays, n_key + 1]; loss: [n_rays, n_query].
  * ids_left, ids_right (int32, indices into the key row) and coef (d loss / d w_outer): [n_rays, n_query], all three or none —
- * the backward's inputs; it returns d loss / d cdfs_key [n_rays, n_key + 1] (deterministic: no atomics).  query_vals must ascend
- * along every ray (as the edges importance_sampling returns do): the backward finds each key edge's query intervals by bisection. */
+ * the backward's inputs; it returns d loss / d cdfs_key [n_rays, n_key + 1] (deterministic: no atomics).  Rays whose query edges ascend
+ * (as the edges importance_sampling returns do) find each key edge's query intervals by bisection; a ray whose ids do not ascend
+ * (unsorted or NaN query edges) scans all of its intervals per edge — the same gradient as the reference's gather backward. */
 int nfa_pdf_loss_fwd(const float *query_vals, const float *cdfs_query, const float *key_vals, const float *cdfs_key,
                      int64_t n_rays, int64_t n_query, int64_t n_key, float eps, float *loss, int32_t *ids_left,
                      int32_t *ids_right, float *coef, void *stream);

@@ -1091,6 +1091,7 @@ inline int64_t cone_voxel_bytes(const nfa_traverse_args *a) {
     if (P >= 32) bytes += nb * (kBlock / 4) * (int64_t)(a->res[0] + a->res[1] + a->res[2] + 3) * 4 + 256;      // crossing-time arrays (K >= 4 lanes per slot)
     return bytes;
 }
+constexpr int64_t kConeVoxelBudgetBytes = 1ll << 30;
 // lanes per ray of the cone count pass, 0 = the general lane-per-ray kernel.  Needs the larger workspace
 // (nfa_traverse_workspace_bytes_for) announced through args.workspace_bytes.
 static int cone_lanes_per_ray(const nfa_traverse_args *a) {
@@ -1099,6 +1100,10 @@ static int cone_lanes_per_ray(const nfa_traverse_args *a) {
     const int64_t max_rays = 32768;       // beyond, a lane per ray fills the chip (and the voxel planes grow with the ray count)
     if (opt(OPT_CONE, 1) == 0) return 0;
     if (a->n_rays > max_rays) return 0;
+    // the per-voxel records grow with rays x (rx + ry + rz): 410 MB at 32 k rays of 4 x 128^3, twice that at 256^3.  Beyond a
+    // budget of 1 GiB the general kernel serves the call (the workspace was unbounded and, cached by the caller's
+    // allocator, stayed)
+    if (cone_voxel_bytes(a) > kConeVoxelBudgetBytes) return 0;
     if (a->workspace_bytes < ws_voxels_offset(a->n_rays) + cone_voxel_bytes(a)) return 0;
     return cone_lanes_for_levels(a->n_grids, a->n_rays);
 }

@@ -198,32 +198,48 @@ __global__ __launch_bounds__(kBlock) void pdf_loss_fwd_kernel(const float *__res
 }
 
 // d loss / d cdfs_key: w_outer = ck[ir] - ck[il], so key edge e collects + g coef of the intervals whose right index is e and
-// - g coef of those whose left index is e.  il and ir ascend along a ray (the query edges do): each edge's intervals are one
-// stretch, found by bisection and summed in order — no atomics, the same bits every run.
+// - g coef of those whose left index is e.  One wave per ray.  When il and ir ascend along the ray (query edges that ascend, as the
+// ones importance_sampling returns do) each edge's intervals are one stretch, found by bisection and summed in order; the wave
+// checks that first, and a ray whose ids do not ascend (unsorted or NaN query edges: ADVICE r3 — the forward is still the
+// reference's, and so must the gradient be) has every edge scan all of the ray's intervals, in order.  No atomics either way: the
+// same bits every run.
 __global__ __launch_bounds__(kBlock) void pdf_loss_bwd_kernel(const float *__restrict__ g_loss, const int32_t *__restrict__ il,
                                                               const int32_t *__restrict__ ir, const float *__restrict__ coef,
                                                               int64_t n_rays, int64_t nq, int64_t nk, float *__restrict__ g_ck)
 {
-    const int64_t total = n_rays * (nk + 1);
-    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * kBlock) {
-        const int64_t ray = tid / (nk + 1);
-        const int e = (int)(tid - ray * (nk + 1));
+    const int lane = lane_id();
+    for (int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); ray < n_rays; ray += (int64_t)gridDim.x * kWavesPerBlock) {
         const int64_t row = ray * nq;
-        auto stretch = [&](const int32_t *__restrict__ ids, int64_t &lo, int64_t &hi) {      // [lo, hi): ids == e
-            int64_t a = 0, b = nq;
-            while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] < e) a = m + 1; else b = m; }
-            lo = a;
-            b = nq;
-            while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] <= e) a = m + 1; else b = m; }
-            hi = a;
-        };
-        int64_t lo, hi;
-        float acc = 0.0f;
-        stretch(ir, lo, hi);
-        for (int64_t i = lo; i < hi; ++i) acc += g_loss[row + i] * coef[row + i];
-        stretch(il, lo, hi);
-        for (int64_t i = lo; i < hi; ++i) acc -= g_loss[row + i] * coef[row + i];
-        g_ck[tid] = acc;
+        bool bad = false;
+        for (int64_t i = lane; i + 1 < nq; i += 64) bad = bad || il[row + i] > il[row + i + 1] || ir[row + i] > ir[row + i + 1];
+        const bool ascending = __ballot(bad) == 0ull;
+        for (int64_t e = lane; e <= nk; e += 64) {
+            float acc = 0.0f;
+            if (ascending) {
+                auto stretch = [&](const int32_t *__restrict__ ids, int64_t &lo, int64_t &hi) {      // [lo, hi): ids == e
+                    int64_t a = 0, b = nq;
+                    while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] < e) a = m + 1; else b = m; }
+                    lo = a;
+                    b = nq;
+                    while (a < b) { const int64_t m = a + ((b - a) >> 1); if (ids[row + m] <= e) a = m + 1; else b = m; }
+                    hi = a;
+                };
+                int64_t lo, hi;
+                stretch(ir, lo, hi);
+                for (int64_t i = lo; i < hi; ++i) acc += g_loss[row + i] * coef[row + i];
+                stretch(il, lo, hi);
+                for (int64_t i = lo; i < hi; ++i) acc -= g_loss[row + i] * coef[row + i];
+            } else {
+                float sub = 0.0f;
+                for (int64_t i = 0; i < nq; ++i) {
+                    const float v = g_loss[row + i] * coef[row + i];
+                    if (ir[row + i] == e) acc += v;
+                    if (il[row + i] == e) sub += v;
+                }
+                acc -= sub;
+            }
+            g_ck[ray * (nk + 1) + e] = acc;
+        }
     }
 }
 
@@ -252,7 +268,7 @@ NFA_EXPORT int nfa_pdf_loss_bwd(const float *g_loss, const int32_t *ids_left, co
     NFA_REQUIRE(n_rays >= 0 && n_query >= 1 && n_key >= 1, "pdf_loss_bwd: n_rays < 0 or an empty level");
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(g_loss && ids_left && ids_right && coef && g_cdfs_key, "pdf_loss_bwd: NULL pointer");
-    hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(blocks_for(n_rays * (n_key + 1))), dim3(kBlock), 0, (hipStream_t)stream, g_loss, ids_left,
+    hipLaunchKernelGGL(pdf_loss_bwd_kernel, dim3(blocks_for(n_rays * kWave)), dim3(kBlock), 0, (hipStream_t)stream, g_loss, ids_left,
                        ids_right, coef, n_rays, n_query, n_key, g_cdfs_key);
     return check_launch("pdf_loss_bwd_kernel");
 }

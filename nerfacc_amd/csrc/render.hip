@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
-            float x[E], a[E], incl[E], ex[E];
+            float x[E], a[E] = {}, incl[E], ex[E];
             uint8_t keep[E];
             if (from_alpha) {   // exclusive product of (1 - alpha), volrend.py:207-209
 #pragma unroll
@@ -134,7 +134,14 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
                 seg_scan_fwd<OpProd, E>(x, s, carry, incl, ex);
             } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) { x[e] = act[e] ? p.d[e] * (p.t1[e] - p.t0[e]) : 0.0f; a[e] = 1.0f - expf(-x[e]); }
+                for (int e = 0; e < E; ++e) x[e] = act[e] ? p.d[e] * (p.t1[e] - p.t0[e]) : 0.0f;
+                // alpha is only compared with alpha_thre: with alpha_thre == 0 — configs[1]'s setting, train_ngp_nerf_occ.py:77 — nobody
+                // reads it, and its expf is a quarter of this pass's VALU work (round 4; the branch is wave-uniform, the kept samples
+                // are bit-identical: the transmittance path below is untouched)
+                if (alpha_thre > 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) a[e] = 1.0f - expf(-x[e]);
+                }
                 seg_scan_fwd<OpSum, E>(x, s, carry, incl, ex);
 #pragma unroll
                 for (int e = 0; e < E; ++e) ex[e] = expf(-ex[e]);

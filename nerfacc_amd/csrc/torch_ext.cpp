@@ -501,6 +501,16 @@ struct Rows {
     Tensor row(int64_t r) const { return buf[r].narrow(0, 0, n); }
 };
 
+// The traversal's scratch (run records, block sums: nfa_traverse_workspace_bytes_for, up to 256 MB) is the same few MB call after
+// call: one slab per (host thread, device, stream), grown when a call needs more, instead of an allocation per call.  Everything that
+// touches it — count, offsets, emit of one call, then the next call's — is enqueued on that one stream, in order.
+Tensor &traverse_workspace(const Tensor &like, hipStream_t s, int64_t bytes) {
+    thread_local std::map<std::pair<int, hipStream_t>, Tensor> slabs;
+    Tensor &t = slabs[{(int)like.device().index(), s}];
+    if (!t.defined() || t.numel() < bytes) t = at::empty({std::max<int64_t>(bytes + bytes / 4, 1 << 16)}, opts(like, at::kByte));
+    return t;
+}
+
 // traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
 // (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
 // test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
@@ -519,7 +529,7 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
                                         t_min, t_max, jitter, jitter_scale);
     Tensor packed = at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
     a.workspace_bytes = nfa_traverse_workspace_bytes_for(&a);
-    Tensor ws = at::empty({std::max<int64_t>(a.workspace_bytes, 16)}, opts(rays_o, at::kByte));
+    Tensor &ws = traverse_workspace(rays_o, s, a.workspace_bytes);
     int64_t *h = host_ints(rays_o.device().index(), s);
     a.sm_starts = ptr<int64_t>(packed);
     a.sm_cnts = ptr<int64_t>(packed) + R;

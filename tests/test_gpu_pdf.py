@@ -174,3 +174,32 @@ def test_pdf_loss_kernel_vs_the_reference_composition(R, nq, nk):
     assert torch.equal(ck.grad, g1)
     with torch.no_grad():
         assert torch.equal(_pdf_loss(qi, cq, ki, ck), loss.detach())
+
+
+def test_pdf_loss_backward_with_unsorted_query_edges():
+    """the fused path takes any batched float32 input; with query edges that do NOT ascend along a ray (or hold a NaN) the
+    forward is still the reference's composition, and the gradient must be too — the backward kernel checks a ray's ids and scans all
+    of its intervals per key edge when they do not ascend (the reference's gather backward is order-independent)"""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.estimators.prop_net import _pdf_loss
+
+    torch.manual_seed(5)
+    R, nq, nk = 300, 40, 70
+    q = torch.rand(R, nq + 1, device=DEV) * 1.2 - 0.1                          # unsorted on purpose
+    q[::3] = torch.sort(q[::3], -1)[0]                                         # every third ray ascends: both paths in one launch
+    k = torch.sort(torch.rand(R, nk + 1, device=DEV), -1)[0]
+    cq = torch.sort(torch.rand(R, nq + 1, device=DEV), -1)[0]
+    ck = torch.sort(torch.rand(R, nk + 1, device=DEV), -1)[0].requires_grad_(True)
+    ck_ref = ck.detach().clone().requires_grad_(True)
+    qi, ki = RayIntervals(vals=q), RayIntervals(vals=k)
+    loss = _pdf_loss(qi, cq, ki, ck)
+    want = _pdf_loss(qi, cq.clone().requires_grad_(True), ki, ck_ref)
+    assert torch.equal(loss, want.detach())
+    coef = torch.rand(R, nq, device=DEV)
+    (loss * coef).sum().backward()
+    (want * coef).sum().backward()
+    assert torch.allclose(ck.grad, ck_ref.grad, rtol=1e-4, atol=2e-7 * nq * float(ck_ref.grad.abs().max()) + 1e-6)
+    g1 = ck.grad.clone()
+    ck.grad = None
+    (_pdf_loss(qi, cq, ki, ck) * coef).sum().backward()
+    assert torch.equal(ck.grad, g1)                                            # still no atomics: run-to-run identical
