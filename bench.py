@@ -662,7 +662,7 @@ def main():
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (configs[4] 256^3 grid, configs[2] PropNet step)")
     ap.add_argument("--aux-steps", type=int, default=40, help="timed steps of each auxiliary leg")
     ap.add_argument("--no-scene-sweep", action="store_true", help="skip aux.configs4_scene_sweep (eight procedural scenes at 256^3)")
-    ap.add_argument("--scene-pretrain", type=int, default=300, help="training steps from fog of every scene of aux.configs4_scene_sweep")
+    ap.add_argument("--scene-pretrain", type=int, default=1000, help="training steps from fog of every scene of aux.configs4_scene_sweep")
     ap.add_argument("--dump-sampling-state", default="",
                     help="write the occupancy grid and one ray batch of the timed steady state to this .npz "
                          "(tools/traverse_replay.py replays the sampling call on it under rocprofv3)")

@@ -389,10 +389,11 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
                 const bool valid = in_sub && q < nseg;
                 if (__ballot(valid) == 0ull) break;
                 // the records of this round were requested a round ago (round 0 and 1: with the ray's counts); request the next round's
-                if (round >= 1) {
+                // (only the rays of THIS sub-block rotate their registers: a later sub-block's rays still hold their first records)
+                if (round >= 1 && in_sub) {
                     t0_q = t0_q2; first_q = first_q2; next_q = next_q2;
                     const int qn = q + W;
-                    if (in_sub && qn < nseg) {
+                    if (qn < nseg) {
                         t0_q2 = rs.t0[(int64_t)qn * R + r];
                         first_q2 = rs.first[(int64_t)qn * R + r];
                         next_q2 = qn + 1 < nseg ? rs.first[(int64_t)(qn + 1) * R + r] : 0;

@@ -275,3 +275,33 @@ def test_sample_positions_bit_identical_to_the_torch_expression():
     p2.sum().backward()
     assert torch.equal(p2.detach(), want) and o2.grad is not None and float(o2.grad.sum()) == float(N * 3)
     assert nerfacc.sample_positions(o, d, ri[:0], ts[:0], te[:0]).shape == (0, 3)
+
+
+@pytest.mark.parametrize("rb", [None, 2, 4, 5, 6])
+def test_tile_emit_sub_blocks_and_rounds_on_a_noise_grid(force_options, rb):
+    """the tile form of the emit pass (emit_pass.hpp) where a wave's block of rays has more runs than its segment list holds —
+    sub-blocks of whole rays — and a ray has more runs than lanes share it — several rounds, the next round's records requested a
+    round ahead: 70 000 rays through a 64^3 noise grid (30-60 runs per ray, 2 000-4 000 per 64-ray block against a list of 512),
+    every rays-per-wave setting, against the lane-per-sample form (which the reference fixtures and the fuzz pin)"""
+    from nerfacc_amd import cuda as C
+
+    g = np.random.default_rng(21)
+    occ = t(g.random((1, 64, 64, 64)) > 0.5)
+    aabb = t(np.array([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], np.float32))
+    R = 70000
+    o = g.standard_normal((R, 3)); o = (4.0 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = (g.random((R, 3)) * 2.4 - 1.2) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o, d = t(o), t(d)
+    near, far = torch.zeros(R, device=DEV), torch.full((R,), 1e10, device=DEV)
+    mask = t(g.random(R) < 0.6)
+    calls = {"training": lambda: C.sample_occgrid(o, d, occ, aabb, near, far, 5e-3, 0.0),
+             "marcher round": lambda: C.sample_occgrid(o, d, occ, aabb, near, far, 5e-3, 0.0, rays_mask=mask, traverse_steps_limit=24)}
+    for name, call in calls.items():
+        force_options(emit="samples", emit_rb=None)
+        want = call()
+        assert want[0].shape[0] > 500000
+        force_options(emit="tiles", emit_rb=rb)
+        for _ in range(2):                       # (the second call takes the speculative launch)
+            got = call()
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(want, got)), (name, rb)
