@@ -292,6 +292,7 @@ struct LatStep {
         return (reg && frac != half) ? c0 + (frac > half ? 1u : 0u) : 0u;
     }
 };
+constexpr int kEmitSpeculate = 4;           // run records of a ray requested together with its counts
 constexpr int kEmitSegWords = 5;            // qpos, spos, t0, j1, ray (+ 2 words of edge offset with interval outputs)
 constexpr int kEmitRayBaseBytes = 64 * 4;   // per wave, behind the segment list: first quad of every ray of the block
 constexpr int kSegSkip = 64;                // seg_ray flag: the run belongs to a ray the fallback launch writes
@@ -344,13 +345,16 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
         float t0_q = 0.0f, t0_q2 = 0.0f;
         int32_t first_q = 0, next_q = 0, first_q2 = 0, next_q2 = 0;
         if (own) {
-            // ONE round trip: the ray's counts and its first 2 W run records (their addresses do not depend on the counts)
+            // ONE round trip: the ray's counts and its first kEmitSpeculate run records (their addresses do not depend on the
+            // counts; almost every ray of a NeRF-like scene has fewer runs — requesting all 2 W of the first two rounds read 5 MB
+            // of never-written record slots per call at 6.5 k rays, counters of profiles/r04_pmc_traverse.json's first version)
             cnt = a.sm_cnts[r]; S = a.sm_starts[r]; nr = rs.n_runs[r];
             if (IV) E = a.iv_starts[r];
-            if (w < rs.max_runs) { t0_q = rs.t0[(int64_t)w * R + r]; if (w > 0) first_q = rs.first[(int64_t)w * R + r]; }
-            if (w + 1 < rs.max_runs) next_q = rs.first[(int64_t)(w + 1) * R + r];
-            if (W + w < rs.max_runs) { t0_q2 = rs.t0[(int64_t)(W + w) * R + r]; first_q2 = rs.first[(int64_t)(W + w) * R + r]; }
-            if (W + w + 1 < rs.max_runs) next_q2 = rs.first[(int64_t)(W + w + 1) * R + r];
+            const int lim = rs.max_runs < kEmitSpeculate ? rs.max_runs : kEmitSpeculate;
+            if (w < lim) { t0_q = rs.t0[(int64_t)w * R + r]; if (w > 0) first_q = rs.first[(int64_t)w * R + r]; }
+            if (w + 1 < rs.max_runs && w < lim) next_q = rs.first[(int64_t)(w + 1) * R + r];
+            if (W + w < lim) { t0_q2 = rs.t0[(int64_t)(W + w) * R + r]; first_q2 = rs.first[(int64_t)(W + w) * R + r]; }
+            if (W + w + 1 < rs.max_runs && W + w < lim) next_q2 = rs.first[(int64_t)(W + w + 1) * R + r];
         }
         if (!checked) {
             if (n_total > capacity) return;                         // outputs too small: the caller launches again after its read-back
@@ -388,12 +392,18 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
                 const int q = (round << wshift) + w;
                 const bool valid = in_sub && q < nseg;
                 if (__ballot(valid) == 0ull) break;
-                // the records of this round were requested a round ago (round 0 and 1: with the ray's counts); request the next round's
-                // (only the rays of THIS sub-block rotate their registers: a later sub-block's rays still hold their first records)
-                if (round >= 1 && in_sub) {
-                    t0_q = t0_q2; first_q = first_q2; next_q = next_q2;
+                // the records of this round were requested a round ago (the first kEmitSpeculate of a ray: with its counts); request
+                // the next round's (only the rays of THIS sub-block rotate their registers: a later sub-block's rays still hold
+                // their first records)
+                if (in_sub) {
+                    if (round >= 1) { t0_q = t0_q2; first_q = first_q2; next_q = next_q2; }
+                    if (valid && q >= kEmitSpeculate && round == 0) {      // a run beyond the speculative ones: fetched now
+                        t0_q = rs.t0[(int64_t)q * R + r];
+                        first_q = rs.first[(int64_t)q * R + r];
+                        next_q = q + 1 < nseg ? rs.first[(int64_t)(q + 1) * R + r] : 0;
+                    }
                     const int qn = q + W;
-                    if (qn < nseg) {
+                    if (qn < nseg && (round >= 1 || qn >= kEmitSpeculate)) {
                         t0_q2 = rs.t0[(int64_t)qn * R + r];
                         first_q2 = rs.first[(int64_t)qn * R + r];
                         next_q2 = qn + 1 < nseg ? rs.first[(int64_t)(qn + 1) * R + r] : 0;

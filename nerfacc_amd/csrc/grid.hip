@@ -1238,6 +1238,12 @@ static bool grid_is_noisy(const nfa_traverse_args *a) {
     const int64_t n_bricks = (int64_t)a->n_grids * ceil_div(a->res[0], 4) * ceil_div(a->res[1], 4) * ceil_div(a->res[2], 4);
     return a->n_nonempty_bricks < 0 || 2 * a->n_nonempty_bricks >= n_bricks;
 }
+// fewer than one brick in fifty holds an occupied voxel (thin structures, a small object in a large box): the rays do little but
+// walk, and hardly ever list more than a few boundaries per part
+static bool grid_is_near_empty(const nfa_traverse_args *a) {
+    const int64_t n_bricks = (int64_t)a->n_grids * ceil_div(a->res[0], 4) * ceil_div(a->res[1], 4) * ceil_div(a->res[2], 4);
+    return a->n_nonempty_bricks >= 0 && 50 * a->n_nonempty_bricks <= n_bricks;
+}
 static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
     const bool lattice = a->step_size > 0.0f && a->cone_angle == 0.0f;
     const bool split = lattice && !a->t_sorted && a->n_grids == 1 && a->traverse_steps_limit <= 0 && a->rays_mask == nullptr;
@@ -1253,21 +1259,18 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
             if (a->n_rays <= 16384) P = 16;
             else if (a->n_rays <= 98304) P = 8;
         } else {
-            // Grids read from L2 (256^3, or dense at 128^3).  Round 4, six scenes x six ray counts x two resolutions
-            // (tools/experiments/r04_count_grid.py, profiles/r04_count_pass.md).  With the share of non-empty bricks known (the
-            // caller read it back with the packed grid's header) plan_split gives every grid that is not noise-like 16-entry
-            // boundary lists — five workgroups per CU instead of two — and then 16 lanes per ray are the best or within 1.22x of it
-            // up to 48 k rays on every scene (46 vs 66 us at 12 k rays of the 256^3 lego, 124 vs 192 at 48 k), 8 up to 96 k; a
-            // noise grid keeps 32-entry lists and 16 lanes (8 overflow them: 683 vs 380 us at 48 k rays).  Round 3's 4 and 2 lanes
-            // per ray for 16 k-64 k rays were tuned on one scene and cost 2-2.8x on the noise and the thin-structure scenes.
-            if (a->n_nonempty_bricks >= 0) {
-                if (grid_is_noisy(a)) P = a->n_rays <= 98304 ? 16 : 1;
-                else P = a->n_rays <= 49152 ? 16 : a->n_rays <= 98304 ? 8 : 1;
-            } else {        // nothing known about the grid: 32-entry lists
-                if (a->n_rays <= 8192) P = 16;
-                else if (a->n_rays <= 49152) P = 8;
-                else if (a->n_rays <= 98304) P = 4;
-            }
+            // Grids read from L2 (256^3, or dense at 128^3).  Round 4, eight scenes x six ray counts x two resolutions
+            // (tools/experiments/r04_count_grid.py, tools/scene_sweep.py; profiles/r04_count_pass.md): the ray count alone cannot
+            // choose.  At 48 k rays a noise grid wants 16 lanes per ray (8 overflow their boundary lists: 683 vs 380 us) and so does
+            // a near-empty one (nothing but walking: 147 vs 121 us), while an object that fills 3-30 % of the bricks wants 8 (152
+            // vs 192 us: every lane of a ray pays for resolving and stitching its boundaries), and 4 between 48 k and 96 k rays.
+            // The share of non-empty bricks — which the caller read back with the packed grid's header — separates the three.
+            // Round 3's rule (8 / 4 / 2 lanes from 8 k / 16 k / 36 k rays) was tuned on one object and cost 2-2.8x on the noise
+            // and the thin-structure scenes; 2 lanes per ray never won.
+            if (grid_is_noisy(a) || grid_is_near_empty(a)) P = a->n_rays <= 98304 ? 16 : 1;
+            else if (a->n_rays <= 8192) P = 16;
+            else if (a->n_rays <= 49152) P = 8;
+            else if (a->n_rays <= 98304) P = 4;
         }
         if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
             P = (int)opt(OPT_SPLIT_P, P);
@@ -1356,10 +1359,12 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     if (p.gv.lds_compact_cap == 0 && p.blk != kBlock) { p.blk = kBlock; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
     if (p.gv.lds_compact_cap == 0) {
         // the image does not fit beside the lists: read from L2.  A part's boundary list holds 32 entries (64 KB of LDS per
-        // workgroup, two per CU) where the grid may be noisy — the reference's rand > 0.5 grid has a boundary every other voxel and
-        // 16-entry lists overflow into the streaming mode — and 16 (32 KB, five per CU: the form `l2` of the sparse grids) elsewhere
+        // workgroup, two per CU): 16-entry lists (32 KB, five per CU: the form `l2` of the sparse grids) are 10-20 % faster on
+        // box-like objects but overflow into the streaming mode wherever rays graze a curved, voxelised surface — a hollow
+        // sphere at 8 k rays 68 vs 45 us, six of them 79 vs 58 (profiles/r04_count_pass.md) — so only a near-empty grid gets them
+        // (thin structures at 92 k rays: 228 vs 348 us)
         p.P = count_lanes_per_ray(a, false);
-        int cap = (int)opt(OPT_SPLIT_CAP, grid_is_noisy(a) ? 32 : 16);
+        int cap = (int)opt(OPT_SPLIT_CAP, grid_is_near_empty(a) ? 16 : 32);
         if (p.P != 8 && p.P != 16) cap = 32;           // (2 and 4 lanes per ray exist with 32-entry lists only)
         if (cap == 16) {
             p.l2 = 1;

@@ -26,8 +26,9 @@ import scenes  # noqa: E402
 from nerfacc_amd import cuda as C  # noqa: E402
 from nerfacc_amd.cuda import _backend  # noqa: E402
 
-COUNT_FORMS = {"P16 lds": dict(split_p=16, split_l2=0), "P16 l2": dict(split_p=16, split_l2=1), "P8": dict(split_p=8), "P4": dict(split_p=4),
-               "P1 lds": dict(split_p=1, count_l2=0), "P1 l2": dict(split_p=1, count_l2=1)}
+COUNT_FORMS = {"P16 lds": dict(split_p=16, split_l2=0), "P16 c16": dict(split_p=16, split_l2=1, split_cap=16), "P16 c32": dict(split_p=16, split_l2=1, split_cap=32),
+               "P8 c16": dict(split_p=8, split_cap=16), "P8 c32": dict(split_p=8, split_cap=32), "P4": dict(split_p=4),
+               "P1 lds": dict(split_p=1, count_l2=0), "P1 l2": dict(split_p=1, count_l2=1)}      # (c16 / c32: boundary-list capacity, grids read from L2 only)
 EMIT_FORMS = {"tiles": dict(emit="tiles"), "rays": dict(emit="rays"), "samples": dict(emit="samples")}
 STEP = 5e-3
 
