@@ -73,8 +73,11 @@ def test_rccl_world_of_one():
     assert out["exchange_bytes"] == 4 * 4 * 128**3 and out["comm_window_ms_per_step"] > 0
 
 
-def test_exchange_adam_on_rccl_matches_fused_adam():
-    """4 steps through ExchangeAdam over an RCCL world of one == torch.optim.Adam(fused) on the same gradients"""
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_exchange_adam_on_rccl_matches_fused_adam(mode):
+    """4 steps through ExchangeAdam over an RCCL world of one == torch.optim.Adam(fused) on the same gradients — in both exchange
+    modes: RCCL's reduce_scatter_tensor and the IN-PLACE all_gather_into_tensor (input = this rank's slice of the output) of `rs_ag`
+    are exercised on the device before any multi-GPU run depends on them"""
     code = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
@@ -86,7 +89,7 @@ torch.manual_seed(0)
 a = [torch.nn.Parameter(torch.randn(1 << 20, device=dev)), torch.nn.Parameter(torch.randn(300, 7, device=dev))]
 b = [torch.nn.Parameter(x.detach().clone()) for x in a]
 oa = torch.optim.Adam(a, lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
-ob = sharding.ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=4)
+ob = sharding.ExchangeAdam(b, lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=4, overlap_backward=True, mode=%r)
 ob.timing = True
 for it in range(4):
     for ps, o in ((a, oa), (b, ob)):
@@ -99,7 +102,7 @@ for x, y in zip(a, b):
     assert torch.allclose(x, y, atol=1e-6, rtol=1e-5), (x - y).abs().max()
 dist.destroy_process_group()
 print("ok", st)
-''' % (ROOT, str(_free_port()))
+''' % (ROOT, str(_free_port()), mode)
     res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                          env=_clean_env())
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]

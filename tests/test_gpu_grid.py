@@ -305,3 +305,14 @@ def test_tile_emit_sub_blocks_and_rounds_on_a_noise_grid(force_options, rb):
         for _ in range(2):                       # (the second call takes the speculative launch)
             got = call()
             assert all(torch.equal(a_, b_) for a_, b_ in zip(want, got)), (name, rb)
+    # the reference-API call with interval outputs (edges, flags: the tile form's per-element instance) on the first 20 000 rays
+    from nerfacc_amd.grid import traverse_grids
+
+    def api():
+        iv, sm, term = traverse_grids(o[:20000], d[:20000], occ, aabb, step_size=5e-3)
+        return (iv.vals, iv.ray_indices, iv.is_left, iv.is_right, iv.packed_info, sm.vals, sm.ray_indices, sm.packed_info)
+
+    force_options(emit="samples", emit_rb=None)
+    want = api()
+    force_options(emit="tiles", emit_rb=rb)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(want, api())), ("traverse_grids", rb)
