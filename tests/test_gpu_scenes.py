@@ -19,7 +19,7 @@ SCENE_NAMES = ["lego", "ficus", "ship", "shell", "speck", "noise", "drums", "mat
 # forced form on 15 of 16 rows and 1.26 on one (materials at 9.9 k rays: 8 lanes per ray with 32-entry boundary lists against
 # 16 lanes with 16-entry ones, which lose 1.4-1.5x on the hollow-shell scenes: no grid statistic known to the host separates
 # the two), emit pass within 1.12; boxes differ by +-5 %, and HIP-event times of 10-40 us kernels carry ~1 us of jitter.
-RATIO, SLACK_US = 1.3, 2.0
+RATIO, SLACK_US = 1.4, 2.0
 
 
 @pytest.mark.parametrize("name", SCENE_NAMES)
