@@ -1267,10 +1267,15 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
             // The share of non-empty bricks — which the caller read back with the packed grid's header — separates the three.
             // Round 3's rule (8 / 4 / 2 lanes from 8 k / 16 k / 36 k rays) was tuned on one object and cost 2-2.8x on the noise
             // and the thin-structure scenes; 2 lanes per ray never won.
-            if (grid_is_noisy(a) || grid_is_near_empty(a)) P = a->n_rays <= 98304 ? 16 : 1;
-            else if (a->n_rays <= 8192) P = 16;
-            else if (a->n_rays <= 49152) P = 8;
-            else if (a->n_rays <= 98304) P = 4;
+            // With 24-entry boundary lists (plan_split; tools/experiments/r04_cap_sweep.py, last table of r04_count_pass.md) the
+            // objects in between take 16 lanes up to 16 k rays and 8 up to 98 k: 43-48 us at 10 k rays of five scenes (57-61 with
+            // 32-entry lists), 62-68 at 24 k (96-99), 110-148 at 48 k (150-155), 205-275 at 96 k (240-255 with 4 lanes).
+            if (a->n_nonempty_bricks < 0) {                 // nothing known about the grid: 32-entry lists
+                if (a->n_rays <= 8192) P = 16;
+                else if (a->n_rays <= 49152) P = 8;
+                else if (a->n_rays <= 98304) P = 4;
+            } else if (grid_is_noisy(a) || grid_is_near_empty(a)) P = a->n_rays <= 98304 ? 16 : 1;
+            else P = a->n_rays <= 16384 ? 16 : a->n_rays <= 98304 ? 8 : 1;
         }
         if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
             P = (int)opt(OPT_SPLIT_P, P);
@@ -1358,14 +1363,21 @@ static SplitPlan plan_split(const nfa_traverse_args *a) {
     if (p.gv.lds_compact_cap == 0 && p.xt) { p.xt = 0; p.gv = make_view(a, p.cap * p.blk * 8, &p.lds, budget); }
     if (p.gv.lds_compact_cap == 0 && p.blk != kBlock) { p.blk = kBlock; p.gv = make_view(a, p.cap * kBlock * 8, &p.lds); }
     if (p.gv.lds_compact_cap == 0) {
-        // the image does not fit beside the lists: read from L2.  A part's boundary list holds 32 entries (64 KB of LDS per
-        // workgroup, two per CU): 16-entry lists (32 KB, five per CU: the form `l2` of the sparse grids) are 10-20 % faster on
-        // box-like objects but overflow into the streaming mode wherever rays graze a curved, voxelised surface — a hollow
-        // sphere at 8 k rays 68 vs 45 us, six of them 79 vs 58 (profiles/r04_count_pass.md) — so only a near-empty grid gets them
-        // (thin structures at 92 k rays: 228 vs 348 us)
+        // the image does not fit beside the lists: read from L2, and the workgroup's LDS is its boundary lists.  32 entries per
+        // part = 64 KB, two workgroups per CU: what a noise grid needs (a boundary every other voxel).  16 entries = 32 KB, five
+        // per CU (the form `l2` of the sparse grids): 10-40 % faster on box-like objects, but rays that graze a curved, voxelised
+        // surface overflow them into the streaming mode — a hollow sphere at 8 k rays 68 vs 45 us, six of them 79 vs 58
+        // (profiles/r04_count_pass.md) — so only a near-empty grid gets them (thin structures at 92 k rays: 228 vs 348 us).
+        // 24 entries = 48 KB, three per CU, hold the curved scenes' parts AND keep most of the occupancy: the default in between.
         p.P = count_lanes_per_ray(a, false);
-        int cap = (int)opt(OPT_SPLIT_CAP, grid_is_near_empty(a) ? 16 : 32);
+        const int cap_auto = a->n_nonempty_bricks < 0 || grid_is_noisy(a) ? 32 : (grid_is_near_empty(a) ? 16 : 24);
+        int cap = (int)opt(OPT_SPLIT_CAP, cap_auto);
         if (p.P != 8 && p.P != 16) cap = 32;           // (2 and 4 lanes per ray exist with 32-entry lists only)
+        if (cap == 24) {
+            p.cap = 24;
+            p.gv = make_view(a, p.cap * kBlock * 8, &p.lds, 0);
+            return p;
+        }
         if (cap == 16) {
             p.l2 = 1;
             p.cap = 16;
@@ -1460,6 +1472,8 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ) {
             NFA_LAUNCH_SPLIT(true, 16, 16);
+        } else if (plan.cap == 24) {
+            if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 24); else NFA_LAUNCH_SPLIT(false, 16, 24);
         } else {
             if (P == 2) NFA_LAUNCH_SPLIT(false, 2, 32); else if (P == 4) NFA_LAUNCH_SPLIT(false, 4, 32);
             else if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 32); else NFA_LAUNCH_SPLIT(false, 16, 32);

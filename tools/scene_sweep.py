@@ -27,7 +27,8 @@ from nerfacc_amd import cuda as C  # noqa: E402
 from nerfacc_amd.cuda import _backend  # noqa: E402
 
 COUNT_FORMS = {"P16 lds": dict(split_p=16, split_l2=0), "P16 c16": dict(split_p=16, split_l2=1, split_cap=16), "P16 c32": dict(split_p=16, split_l2=1, split_cap=32),
-               "P8 c16": dict(split_p=8, split_cap=16), "P8 c32": dict(split_p=8, split_cap=32), "P4": dict(split_p=4),
+               "P16 c24": dict(split_p=16, split_l2=1, split_cap=24),
+               "P8 c16": dict(split_p=8, split_cap=16), "P8 c24": dict(split_p=8, split_cap=24), "P8 c32": dict(split_p=8, split_cap=32), "P4": dict(split_p=4),
                "P1 lds": dict(split_p=1, count_l2=0), "P1 l2": dict(split_p=1, count_l2=1)}      # (c16 / c32: boundary-list capacity, grids read from L2 only)
 EMIT_FORMS = {"tiles": dict(emit="tiles"), "rays": dict(emit="rays"), "samples": dict(emit="samples")}
 STEP = 5e-3
