@@ -17,8 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 SCENE_NAMES = ["lego", "ficus", "ship", "shell", "speck", "noise", "drums", "materials"]
 # auto <= RATIO * best + SLACK_US.  Measured at the end of round 4 (profiles/r04_scene_sweep.md): count pass within 1.09 of the best
 # forced form on 15 of 16 rows and 1.26 on one (materials at 9.9 k rays: 8 lanes per ray with 32-entry boundary lists against
-# 16 lanes with 16-entry ones, which lose 1.4-1.5x on the hollow-shell scenes: no grid statistic known to the host separates
-# the two), emit pass within 1.12; boxes differ by +-5 %, and HIP-event times of 10-40 us kernels carry ~1 us of jitter.
+# 16 lanes with 16-entry ones; since then 24-entry lists: within 1.09 on all 16 rows
+# emit pass within 1.10; boxes differ by +-5 %, and HIP-event times of 10-40 us kernels carry ~1 us of jitter.
 RATIO, SLACK_US = 1.4, 2.0
 
 
