@@ -139,7 +139,10 @@ def test_hip_reproduces_reference_k2(name, k2):
 # Every kernel FORM that can serve a case, forced through the library's options (nerfacc_amd.set_option), against the reference's
 # own output — not only against the oracle.  {} = the automatic choice.
 _ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}, {"split_p": 8}, {"split_p": 1, "count_l2": 0},
-              {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}]
+              {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"},
+              # boundary-list capacities of the forms that read the grid from L2 (lego_256, m1_noise; ignored where the image fits LDS)
+              {"split_p": 16, "split_l2": 1, "split_cap": 16}, {"split_p": 16, "split_l2": 1, "split_cap": 24},
+              {"split_p": 16, "split_l2": 1, "split_cap": 32}, {"split_p": 8, "split_cap": 24}]
 _LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"}]
 _CONE_ONE = [{}, {"cone": 0}, {"cone": 1, "emit": "rays"}, {"cone": 1, "emit": "samples"}, {"cone": 0, "emit": "rays"}]
 _CONE_LEVELS = _CONE_ONE + [{"cone": 1, "cone_p": p} for p in (8, 16, 32, 64)] + [{"cone_p": 64, "emit": "samples"}]

@@ -33,7 +33,7 @@ for case in range(n_cases):
         bad += len(b); total += n
         for line in b:
             print("MISMATCH (cone)", f"case {case}", line, flush=True)
-print(f"{n_cases} cases x (6 lane settings + 5 image placements + 3 emit forms) ({total} oracle samples in total), {bad} mismatches, {time.time() - t_begin:.0f} s")
+print(f"{n_cases} cases x ({len(F.SPLIT_P_FORMS)} lane settings + {len(F.IMAGE_FORMS)} image placements / list capacities + {len(F.EMIT_FORMS)} emit forms) ({total} oracle samples in total), {bad} mismatches, {time.time() - t_begin:.0f} s")
 bad2 = tot2 = 0
 t_begin = time.time()
 for case in range(n_cases // 4):
