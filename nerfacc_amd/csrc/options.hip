@@ -59,6 +59,7 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"segments", "0: several levels take the lane-per-ray count pass", parse_bool},
     {"split_cap", "grids read from L2: entries of a part's boundary list, 16 | 24 | 32", parse_one_of<16, 24, 32>},
     {"emit_rb", "tile form of the emit pass: log2 of the rays per wave, 0 ... 6", parse_one_of<0, 1, 2, 3, 4, 5, 6>},
+    {"chunk_prefetch", "0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call", parse_bool},
     {"speculative_emit", "0: sample_occgrid of the torch extension launches the emit pass after the read-back", parse_bool},
 };
 

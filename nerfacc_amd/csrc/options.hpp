@@ -26,6 +26,7 @@ enum Option : int {
     OPT_SEGMENTS,        // 0: several levels take the lane-per-ray count pass
     OPT_SPLIT_CAP,       // grids read from L2: entries of a part's boundary list, 16 | 32 (16: 8 and 16 lanes per ray only)
     OPT_EMIT_RB,         // tile form of the emit pass: log2 of the rays a wave takes (0 ... 6)
+    OPT_CHUNK_PREFETCH,  // 0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call
     OPT_SPECULATIVE_EMIT,// 0: the extension's sample_occgrid launches the emit pass after the read-back
     OPT_COUNT
 };

@@ -145,9 +145,11 @@ py::dict timing_summary() {
 // store, so wait_stamp synchronises the stream straight away instead of spinning for its 2 ms first
 std::atomic<bool> g_host_ints_coherent{true};
 
-int64_t *host_ints(int device, hipStream_t s) {
-    thread_local std::map<std::pair<int, hipStream_t>, int64_t *> slots;
-    auto key = std::make_pair(device, s);
+int64_t *host_ints(int device, hipStream_t s, int which = 0) {
+    // which = 1: the slot of a count pass launched AHEAD of its call (sample_occgrid's next-chunk prefetch): the calls in between
+    // (visibility_compact of the current chunk) keep using slot 0
+    thread_local std::map<std::tuple<int, hipStream_t, int>, int64_t *> slots;
+    auto key = std::make_tuple(device, s, which);
     auto it = slots.find(key);
     if (it != slots.end()) return it->second;
     int64_t *p = nullptr;
@@ -511,6 +513,37 @@ Tensor &traverse_workspace(const Tensor &like, hipStream_t s, int64_t bytes) {
     return t;
 }
 
+// The reference's eval loop (examples/utils.py:80-88) calls `estimator.sampling` on consecutive 8192-ray SLICES of one ray array, and
+// every call has to wait for its count pass before it can size its outputs (~40 us of 205 per chunk with the host idle, profiles/
+// r03_host_share.md).  When a call's rays start exactly where the previous call's ended — the second consecutive slice — the count
+// and offsets kernels of the NEXT slice are launched at the end of the call, behind its own work; the next call, if it asks for
+// exactly those rays (same pointers and count, same tensor versions, same grid, same scalars), finds its totals waiting.  A guess
+// that is not taken up costs one count pass of GPU time and nothing else: nothing it wrote is looked at.  Only plain calls qualify
+// (no jitter, masks, per-ray planes or step limits: training batches are fresh tensors and never match).  `chunk_prefetch` = 0
+// switches it off.
+struct ChunkPrefetch {
+    bool valid = false;
+    const void *o_ptr = nullptr, *d_ptr = nullptr, *aabbs_ptr = nullptr;
+    const void *bin_impl = nullptr;
+    int64_t R = 0;
+    uint32_t o_ver = 0, d_ver = 0, bin_ver = 0, aabbs_ver = 0;
+    double step = 0, cone = 0, near_plane = 0, far_plane = 0;
+    int64_t stamp = 0, ws_bytes = 0;
+    Tensor packed;
+    const void *expect_o = nullptr;     // where the next slice of the caller's loop would start (set by every qualifying call)
+};
+ChunkPrefetch &chunk_prefetch(int device, hipStream_t s) {
+    thread_local std::map<std::pair<int, hipStream_t>, ChunkPrefetch> slots;
+    if (slots.size() > 64) slots.clear();
+    return slots[{device, s}];
+}
+inline bool chunk_prefetch_allowed() {
+    int64_t v = 1;
+    int32_t is_set = 0;
+    nfa_get_option("chunk_prefetch", &v, &is_set);
+    return !is_set || v != 0;
+}
+
 // traverse_grids + the two is_left / is_right compactions of occ_grid.py:164-177 in one count pass and one emit pass:
 // (ray_indices, t_starts, t_ends, packed_info[, terminate_planes]).  rays_mask / traverse_steps_limit give one round of the
 // test-time marcher (examples/utils.py:349-372) with exactly sized outputs.
@@ -527,10 +560,21 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     nfa_traverse_args a = traverse_args(rays_o, rays_d, rays_mask, binaries, aabbs, std::nullopt, std::nullopt, std::nullopt,
                                         near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep, near_plane, far_plane,
                                         t_min, t_max, jitter, jitter_scale);
-    Tensor packed = at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
+    // a plain call (what the reference's eval loop makes): may take up, and leave behind, a count pass launched ahead
+    const bool plain = R > 0 && !rays_mask && !near_planes && !far_planes && !t_min && !t_max && !jitter && traverse_steps_limit <= 0 &&
+                       !with_terminate_planes;
+    ChunkPrefetch &pf = chunk_prefetch(rays_o.device().index(), s);
+    const bool taken = plain && pf.valid && pf.o_ptr == rays_o.data_ptr() && pf.d_ptr == rays_d.data_ptr() && pf.R == R &&
+                       pf.o_ver == rays_o._version() && pf.d_ver == rays_d._version() &&
+                       pf.bin_impl == (const void *)binaries.unsafeGetTensorImpl() && pf.bin_ver == binaries._version() &&
+                       pf.aabbs_ptr == aabbs.data_ptr() && pf.aabbs_ver == aabbs._version() && pf.step == step_size &&
+                       pf.cone == cone_angle && pf.near_plane == near_plane && pf.far_plane == far_plane;
+    pf.valid = false;                                 // taken up or stale: either way it is spent
+    Tensor packed = taken ? pf.packed : at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
+    pf.packed = Tensor();
     a.workspace_bytes = nfa_traverse_workspace_bytes_for(&a);
     Tensor &ws = traverse_workspace(rays_o, s, a.workspace_bytes);
-    int64_t *h = host_ints(rays_o.device().index(), s);
+    int64_t *h = host_ints(rays_o.device().index(), s, taken ? 1 : 0);
     a.sm_starts = ptr<int64_t>(packed);
     a.sm_cnts = ptr<int64_t>(packed) + R;
     a.totals = h;
@@ -540,13 +584,18 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         term = near_planes->clone();
         a.terminate_planes = ptr<float>(term);
     }
-    {
-        Timed t("traverse_count", s);
-        check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
+    int64_t stamp;
+    if (taken) {
+        stamp = pf.stamp;                             // count and offsets of exactly this call ran behind the previous one
+    } else {
+        {
+            Timed t("traverse_count", s);
+            check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
+        }
+        stamp = next_stamp();
+        h[3] = 0;
+        check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
     }
-    const int64_t stamp = next_stamp();
-    h[3] = 0;
-    check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
     // The emit pass is launched BEFORE the read-back, into outputs sized from the previous call on this device (training
     // steps draw about the same number of samples every time): the GPU goes from the offsets kernel straight into it
     // instead of idling through the host's wake-up, allocation and launch (16 us, tools/step_timeline.py), and the host —
@@ -596,6 +645,45 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
             Timed t("traverse_fill", s);
             check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), n, n_overflow, s));
         }
+    }
+    if (plain) {
+        // the next slice of the caller's loop, if this call continued one (its rays start where the previous call's ended) and both
+        // ray arrays have rows left behind this slice
+        const float *o_end = ptr<float>(rays_o) + 3 * R, *d_end = ptr<float>(rays_d) + 3 * R;
+        const bool continued = pf.expect_o == rays_o.data_ptr();
+        pf.expect_o = o_end;
+        auto rows_left = [&](const Tensor &t) {
+            const int64_t used = (t.storage_offset() + 3 * R) * 4;
+            return ((int64_t)t.storage().nbytes() - used) / 12;
+        };
+        const int64_t Rn = std::min<int64_t>(R, std::min(rows_left(rays_o), rows_left(rays_d)));
+        if (continued && Rn > 0 && chunk_prefetch_allowed()) {
+            nfa_traverse_args a2 = a;
+            a2.n_rays = Rn;
+            a2.rays_o = o_end;
+            a2.rays_d = d_end;
+            a2.sm_ray_indices = nullptr; a2.t_starts = nullptr; a2.t_ends = nullptr; a2.terminate_planes = nullptr;
+            pf.packed = at::empty({2, Rn}, i64);
+            a2.sm_starts = ptr<int64_t>(pf.packed);
+            a2.sm_cnts = ptr<int64_t>(pf.packed) + Rn;
+            int64_t *h2 = host_ints(rays_o.device().index(), s, 1);
+            a2.totals = h2;
+            a2.workspace_bytes = nfa_traverse_workspace_bytes_for(&a2);
+            Tensor &ws2 = traverse_workspace(rays_o, s, a2.workspace_bytes);     // (the same slab: this call's kernels are enqueued before)
+            check_rc(nfa_traverse_count(&a2, ws2.data_ptr(), s));
+            pf.stamp = next_stamp();
+            h2[3] = 0;
+            check_rc(nfa_traverse_offsets_stamped(&a2, ws2.data_ptr(), pf.stamp, s));
+            pf.o_ptr = o_end; pf.d_ptr = d_end; pf.R = Rn;
+            pf.o_ver = rays_o._version(); pf.d_ver = rays_d._version();
+            pf.bin_impl = (const void *)binaries.unsafeGetTensorImpl(); pf.bin_ver = binaries._version();
+            pf.aabbs_ptr = aabbs.data_ptr(); pf.aabbs_ver = aabbs._version();
+            pf.step = step_size; pf.cone = cone_angle; pf.near_plane = near_plane; pf.far_plane = far_plane;
+            pf.ws_bytes = a2.workspace_bytes;
+            pf.valid = true;
+        }
+    } else {
+        pf.expect_o = nullptr;
     }
     if (with_terminate_planes) return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t(), term);
     return py::make_tuple(ray_indices, ts.row(0), ts.row(1), packed.t());

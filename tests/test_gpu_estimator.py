@@ -132,3 +132,50 @@ def test_distortion_loss_matches_dense_formula():
     m = 0.5 * (ts + te)
     dense = (w[:, :, None] * w[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum((1, 2)) + ((te - ts) * w**2).sum(-1) / 3
     assert torch.allclose(got, dense, atol=1e-4, rtol=1e-4)
+
+
+def test_next_slice_count_prefetch_is_invisible(force_options):
+    """sample_occgrid launches the count pass of the NEXT consecutive ray slice behind the current call (torch_ext.cpp: ChunkPrefetch —
+    the reference's eval loop, examples/utils.py:80-88).  Whatever the caller does between two calls, the samples must be the ones a
+    fresh count pass gives: consecutive slices (guesses taken up), a slice revisited, slices out of order, the ray array modified in
+    place between two calls (same pointers, new version: the guess must be dropped), a grid update in between, another chunk size."""
+    import nerfacc_amd
+
+    rng = np.random.default_rng(5)
+    R = 40000
+    o = rng.standard_normal((R, 3)); o = (4.0 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = (rng.random((R, 3)) * 2.4 - 1.2) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    O, D = t(o), t(d)
+    est = nerfacc_amd.OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=64, levels=1).to(DEV)
+    g = (np.arange(64) + 0.5) / 64 * 3 - 1.5
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    est.binaries = t(((X**2 + Y**2 + Z**2) < 1.0)[None])
+
+    def run(order, chunk, mutate_at=None, regrid_at=None):
+        out = []
+        for k, i in enumerate(order):
+            if k == mutate_at:
+                O[i:i + chunk].mul_(1.0001)                 # in place: same pointers, the version counter moves
+            if k == regrid_at:
+                est.binaries = t(((X**2 + Y**2 + (Z - 0.2) ** 2) < 0.8)[None])
+            ri, ts, te = est.sampling(O[i:i + chunk], D[i:i + chunk], render_step_size=1e-2)
+            out.append((ri.clone(), ts.clone(), te.clone()))
+        return out
+
+    starts = list(range(0, R, 4096))
+    plans = [dict(order=starts, chunk=4096), dict(order=starts[:4] + [starts[2]] + starts[3:6], chunk=4096),
+             dict(order=starts[::-1], chunk=4096), dict(order=starts, chunk=4096, mutate_at=4), dict(order=starts, chunk=4096, regrid_at=5),
+             dict(order=list(range(0, R, 3000)), chunk=3000)]
+    for plan in plans:
+        O.copy_(t(o))
+        est.binaries = t(((X**2 + Y**2 + Z**2) < 1.0)[None])
+        force_options(chunk_prefetch=0)
+        want = run(**plan)
+        O.copy_(t(o))
+        est.binaries = t(((X**2 + Y**2 + Z**2) < 1.0)[None])
+        force_options(chunk_prefetch=1)
+        got = run(**plan)
+        for k, (a_, b_) in enumerate(zip(want, got)):
+            assert all(torch.equal(x, y) for x, y in zip(a_, b_)), (plan, k)
+        assert sum(x[0].shape[0] for x in got) > 100000
