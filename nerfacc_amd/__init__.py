@@ -11,7 +11,7 @@ from .estimators.occ_grid import OccGridEstimator
 from .estimators.prop_net import PropNetEstimator
 from .grid import ray_aabb_intersect, sample_positions, traverse_grids
 from .losses import distortion
-from .options import get_option, list_options, options, reset_options, set_option
+from .options import get_option, list_options, options, release_workspace, reset_options, set_option
 from .pack import pack_info
 from .pdf import importance_sampling, searchsorted
 from .scan import exclusive_prod, exclusive_sum, inclusive_prod, inclusive_sum
@@ -42,4 +42,4 @@ __all__ = [
     "distortion",
 ]
 # additions of this implementation (not in the reference's list of 24 names)
-__all__ += ["sample_positions", "set_option", "get_option", "reset_options", "list_options", "options"]
+__all__ += ["sample_positions", "set_option", "get_option", "reset_options", "list_options", "options", "release_workspace"]

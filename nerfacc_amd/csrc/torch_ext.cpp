@@ -506,12 +506,23 @@ struct Rows {
 // The traversal's scratch (run records, block sums: nfa_traverse_workspace_bytes_for, up to 256 MB) is the same few MB call after
 // call: one slab per (host thread, device, stream), grown when a call needs more, instead of an allocation per call.  Everything that
 // touches it — count, offsets, emit of one call, then the next call's — is enqueued on that one stream, in order.
-Tensor &traverse_workspace(const Tensor &like, hipStream_t s, int64_t bytes) {
-    thread_local std::map<std::pair<int, hipStream_t>, Tensor> slabs;
-    Tensor &t = slabs[{(int)like.device().index(), s}];
-    if (!t.defined() || t.numel() < bytes) t = at::empty({std::max<int64_t>(bytes + bytes / 4, 1 << 16)}, opts(like, at::kByte));
+// A call that needs more than kWorkspaceKeep gets its own allocation (stream-ordered by torch's caching allocator, returned to it when
+// the call ends): one frame-sized call does not pin a quarter of a GB for the life of the thread.
+constexpr int64_t kWorkspaceKeep = 64ll << 20;
+using SlabMap = std::map<std::pair<int, hipStream_t>, Tensor>;
+SlabMap &workspace_slabs() {
+    thread_local SlabMap slabs;
+    return slabs;
+}
+Tensor traverse_workspace(const Tensor &like, hipStream_t s, int64_t bytes) {
+    if (bytes > kWorkspaceKeep) return at::empty({bytes}, opts(like, at::kByte));
+    Tensor &t = workspace_slabs()[{(int)like.device().index(), s}];
+    if (!t.defined() || t.numel() < bytes)
+        t = at::empty({std::min<int64_t>(std::max<int64_t>(bytes + bytes / 4, 1 << 16), kWorkspaceKeep)}, opts(like, at::kByte));
     return t;
 }
+// drops this host thread's retained slabs (and with them any count pass launched ahead: its records lived there)
+void release_workspace();
 
 // The reference's eval loop (examples/utils.py:80-88) calls `estimator.sampling` on consecutive 8192-ray SLICES of one ray array, and
 // every call has to wait for its count pass before it can size its outputs (~40 us of 205 per chunk with the host idle, profiles/
@@ -529,13 +540,39 @@ struct ChunkPrefetch {
     uint32_t o_ver = 0, d_ver = 0, bin_ver = 0, aabbs_ver = 0;
     double step = 0, cone = 0, near_plane = 0, far_plane = 0;
     int64_t stamp = 0, ws_bytes = 0;
+    Tensor ws_keep;                     // the workspace the guess's run records live in (held: the taking call uses exactly this one)
     Tensor packed;
     const void *expect_o = nullptr;     // where the next slice of the caller's loop would start (set by every qualifying call)
+    // The guess is keyed on IDENTITY, not only on addresses: weak references to the storages of both ray arrays, of the boxes and to
+    // the grid tensor.  A weak reference keeps the (small) StorageImpl / TensorImpl object alive, so a live guess's pointer cannot be
+    // handed to another object, and an expired one says the memory behind the recorded address may have been freed and re-used (a
+    // fresh tensor at the same address starts at version 0 again: ADVICE r4).  It does not keep the caller's memory alive.
+    c10::weak_intrusive_ptr<c10::StorageImpl> o_st{c10::intrusive_ptr<c10::StorageImpl>()}, d_st{c10::intrusive_ptr<c10::StorageImpl>()},
+        aabbs_st{c10::intrusive_ptr<c10::StorageImpl>()};
+    c10::weak_intrusive_ptr<c10::TensorImpl> bin_ref{c10::intrusive_ptr<c10::TensorImpl>()};
+    bool same_storage(const c10::weak_intrusive_ptr<c10::StorageImpl> &w, const Tensor &t) const {
+        return !w.expired() && w._unsafe_get_target() == t.storage().unsafeGetStorageImpl();
+    }
+    void drop() {
+        valid = false;
+        packed = Tensor();
+        ws_keep = Tensor();
+        o_st = d_st = aabbs_st = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>());
+        bin_ref = c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>());
+    }
 };
-ChunkPrefetch &chunk_prefetch(int device, hipStream_t s) {
+std::map<std::pair<int, hipStream_t>, ChunkPrefetch> &prefetch_slots() {
     thread_local std::map<std::pair<int, hipStream_t>, ChunkPrefetch> slots;
+    return slots;
+}
+ChunkPrefetch &chunk_prefetch(int device, hipStream_t s) {
+    auto &slots = prefetch_slots();
     if (slots.size() > 64) slots.clear();
     return slots[{device, s}];
+}
+void release_workspace() {
+    prefetch_slots().clear();
+    workspace_slabs().clear();
 }
 inline bool chunk_prefetch_allowed() {
     int64_t v = 1;
@@ -561,19 +598,25 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
                                         near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, keep, near_plane, far_plane,
                                         t_min, t_max, jitter, jitter_scale);
     // a plain call (what the reference's eval loop makes): may take up, and leave behind, a count pass launched ahead
+    // (tensors created under torch.inference_mode() carry no version counter — `_version()` throws for them — so a call with any
+    //  of them neither takes up nor leaves a guess: ADVICE r4.  Writes that bypass the version counter — `x.data.copy_`, raw-pointer
+    //  kernels, DLPack consumers — are invisible to this key: such callers set chunk_prefetch = 0.)
     const bool plain = R > 0 && !rays_mask && !near_planes && !far_planes && !t_min && !t_max && !jitter && traverse_steps_limit <= 0 &&
-                       !with_terminate_planes;
+                       !with_terminate_planes && !rays_o.is_inference() && !rays_d.is_inference() && !aabbs.is_inference() &&
+                       !binaries.is_inference();
     ChunkPrefetch &pf = chunk_prefetch(rays_o.device().index(), s);
-    const bool taken = plain && pf.valid && pf.o_ptr == rays_o.data_ptr() && pf.d_ptr == rays_d.data_ptr() && pf.R == R &&
-                       pf.o_ver == rays_o._version() && pf.d_ver == rays_d._version() &&
-                       pf.bin_impl == (const void *)binaries.unsafeGetTensorImpl() && pf.bin_ver == binaries._version() &&
-                       pf.aabbs_ptr == aabbs.data_ptr() && pf.aabbs_ver == aabbs._version() && pf.step == step_size &&
-                       pf.cone == cone_angle && pf.near_plane == near_plane && pf.far_plane == far_plane;
-    pf.valid = false;                                 // taken up or stale: either way it is spent
-    Tensor packed = taken ? pf.packed : at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
-    pf.packed = Tensor();
     a.workspace_bytes = nfa_traverse_workspace_bytes_for(&a);
-    Tensor &ws = traverse_workspace(rays_o, s, a.workspace_bytes);
+    const bool taken = plain && pf.valid && pf.o_ptr == rays_o.data_ptr() && pf.d_ptr == rays_d.data_ptr() && pf.R == R &&
+                       pf.same_storage(pf.o_st, rays_o) && pf.same_storage(pf.d_st, rays_d) && pf.same_storage(pf.aabbs_st, aabbs) &&
+                       !pf.bin_ref.expired() && pf.bin_impl == (const void *)binaries.unsafeGetTensorImpl() &&
+                       pf.o_ver == rays_o._version() && pf.d_ver == rays_d._version() && pf.bin_ver == binaries._version() &&
+                       pf.aabbs_ptr == aabbs.data_ptr() && pf.aabbs_ver == aabbs._version() && pf.step == step_size &&
+                       pf.cone == cone_angle && pf.near_plane == near_plane && pf.far_plane == far_plane &&
+                       pf.ws_bytes == a.workspace_bytes && pf.ws_keep.defined();
+    Tensor ws = taken ? pf.ws_keep : traverse_workspace(rays_o, s, a.workspace_bytes);
+    Tensor packed = taken ? pf.packed : at::empty({2, R}, i64);           // [starts; cnts], handed out transposed as [R, 2]
+    const int64_t pf_stamp = pf.stamp;
+    pf.drop();                                        // taken up or stale: either way it is spent
     int64_t *h = host_ints(rays_o.device().index(), s, taken ? 1 : 0);
     a.sm_starts = ptr<int64_t>(packed);
     a.sm_cnts = ptr<int64_t>(packed) + R;
@@ -586,7 +629,7 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     }
     int64_t stamp;
     if (taken) {
-        stamp = pf.stamp;                             // count and offsets of exactly this call ran behind the previous one
+        stamp = pf_stamp;                             // count and offsets of exactly this call ran behind the previous one
     } else {
         {
             Timed t("traverse_count", s);
@@ -669,7 +712,7 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
             int64_t *h2 = host_ints(rays_o.device().index(), s, 1);
             a2.totals = h2;
             a2.workspace_bytes = nfa_traverse_workspace_bytes_for(&a2);
-            Tensor &ws2 = traverse_workspace(rays_o, s, a2.workspace_bytes);     // (the same slab: this call's kernels are enqueued before)
+            Tensor ws2 = traverse_workspace(rays_o, s, a2.workspace_bytes);      // (the same slab: this call's kernels are enqueued before)
             check_rc(nfa_traverse_count(&a2, ws2.data_ptr(), s));
             pf.stamp = next_stamp();
             h2[3] = 0;
@@ -680,6 +723,11 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
             pf.aabbs_ptr = aabbs.data_ptr(); pf.aabbs_ver = aabbs._version();
             pf.step = step_size; pf.cone = cone_angle; pf.near_plane = near_plane; pf.far_plane = far_plane;
             pf.ws_bytes = a2.workspace_bytes;
+            pf.ws_keep = ws2;
+            pf.o_st = rays_o.storage().getWeakStorageImpl();
+            pf.d_st = rays_d.storage().getWeakStorageImpl();
+            pf.aabbs_st = aabbs.storage().getWeakStorageImpl();
+            pf.bin_ref = c10::weak_intrusive_ptr<c10::TensorImpl>(binaries.getIntrusivePtr());
             pf.valid = true;
         }
     } else {
@@ -1251,6 +1299,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         raise_not_implemented("camera undistortion (camera.cu) is outside the OccGrid hot path and not built"); });
 
     // ---- fused entry points of this implementation
+    m.def("release_workspace", &release_workspace,
+          "free this host thread's retained traversal workspace (<= 64 MB per device and stream) and any count pass launched ahead");
     m.def("sample_occgrid", &sample_occgrid, "rays_o"_a, "rays_d"_a, "binaries"_a, "aabbs"_a, "near_planes"_a, "far_planes"_a, "step_size"_a,
           "cone_angle"_a, "rays_mask"_a = py::none(), "traverse_steps_limit"_a = -1, "with_terminate_planes"_a = false, "near_plane"_a = 0.0,
           "far_plane"_a = std::numeric_limits<double>::infinity(), "t_min"_a = py::none(), "t_max"_a = py::none(), "jitter"_a = py::none(),

@@ -70,3 +70,13 @@ def options(**forced):
     finally:
         for k, v in before.items():
             set_option(k, v)
+
+
+def release_workspace() -> None:
+    """Free the calling host thread's retained traversal workspace (at most 64 MB per device and stream; larger
+    calls allocate per call) and drop any count pass `sample_occgrid` launched ahead for the next ray slice."""
+    from .cuda import _backend
+
+    c = _backend._C
+    if hasattr(c, "release_workspace"):
+        c.release_workspace()

@@ -23,6 +23,13 @@ def pytest_collection_modifyitems(config, items):
     rank = lambda it: 2 if it.get_closest_marker("randomised") else (1 if it.get_closest_marker("perf") else 0)
     if any(rank(it) for it in items):
         items[:] = sorted(items, key=rank)          # (stable: the order inside each class stays the collection order)
+    # wall-clock assertions are opt-in: a plain `-m gpu` run on a noisy box must not go red for a non-bug.
+    # NFA_PERF_TESTS=1 (tools/collect_round.sh sets it) runs them.
+    if os.environ.get("NFA_PERF_TESTS", "0") in ("", "0"):
+        skip = pytest.mark.skip(reason="wall-clock assertion: set NFA_PERF_TESTS=1 to run")
+        for it in items:
+            if it.get_closest_marker("perf"):
+                it.add_marker(skip)
 
 
 @pytest.fixture

@@ -179,3 +179,62 @@ def test_next_slice_count_prefetch_is_invisible(force_options):
         for k, (a_, b_) in enumerate(zip(want, got)):
             assert all(torch.equal(x, y) for x, y in zip(a_, b_)), (plan, k)
         assert sum(x[0].shape[0] for x in got) > 100000
+
+
+def test_count_prefetch_inference_mode_and_reused_addresses(force_options):
+    """ADVICE r4 / VERDICT r4 item 6: (i) rays built under torch.inference_mode() have no version counter — the second consecutive
+    slice used to raise; such calls neither take up nor leave a guess.  (ii) an eval loop aborted after two slices, its ray tensors
+    freed, and a NEW ray tensor of the same size allocated (the caching allocator hands out the same address, version 0 again): the
+    guess left behind by the aborted loop must not be taken up for the new rays.  (iii) release_workspace() between two slices."""
+    import nerfacc_amd
+
+    rng = np.random.default_rng(9)
+    R, chunk = 16384, 4096
+
+    def rays(seed):
+        g = np.random.default_rng(seed)
+        o = g.standard_normal((R, 3)); o = (4.0 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+        d = (g.random((R, 3)) * 2.4 - 1.2) - o
+        return o, (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+    est = nerfacc_amd.OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=64, levels=1).to(DEV)
+    g = (np.arange(64) + 0.5) / 64 * 3 - 1.5
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    est.binaries = t(((X**2 + Y**2 + Z**2) < 1.0)[None])
+
+    def loop(O, D, upto=R, release_at=None):
+        out = []
+        for k, i in enumerate(range(0, upto, chunk)):
+            if k == release_at:
+                nerfacc_amd.release_workspace()
+            ri, ts, te = est.sampling(O[i:i + chunk], D[i:i + chunk], render_step_size=1e-2)
+            out.append((ri.clone(), ts.clone(), te.clone()))
+        return out
+
+    def same(a, b):
+        return len(a) == len(b) and all(torch.equal(x, y) for p, q in zip(a, b) for x, y in zip(p, q))
+
+    o1, d1 = rays(1)
+    o2, d2 = rays(2)
+    force_options(chunk_prefetch=0)
+    want1, want2 = loop(t(o1), t(d1)), loop(t(o2), t(d2))
+    force_options(chunk_prefetch=1)
+    # (i) inference-mode tensors
+    with torch.inference_mode():
+        Oi, Di = t(o1), t(d1)
+        got = loop(Oi, Di)
+    assert same(want1, got)
+    del Oi, Di
+    # (ii) aborted loop, then fresh tensors at (very likely) the same addresses with other rays
+    O, D = t(o1), t(d1)
+    p_o, p_d = O.data_ptr(), D.data_ptr()
+    part = loop(O, D, upto=2 * chunk)              # leaves a guess for slice 2 of these rays behind
+    assert same(want1[:2], part)
+    del O, D
+    O2, D2 = t(o2), t(d2)
+    reused = O2.data_ptr() == p_o and D2.data_ptr() == p_d
+    got2 = est.sampling(O2[2 * chunk:3 * chunk], D2[2 * chunk:3 * chunk], render_step_size=1e-2)      # exactly the guessed slice
+    assert all(torch.equal(x, y) for x, y in zip(want2[2], got2)), f"stale guess taken up (addresses reused: {reused})"
+    assert same(want2, loop(O2, D2))
+    # (iii) the retained workspace released between two slices
+    assert same(want2, loop(O2, D2, release_at=2))
