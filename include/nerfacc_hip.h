@@ -347,6 +347,16 @@ typedef struct nfa_ray_segments {
  * generator produces them, which keeps the library free of RNG state. */
 int nfa_importance_sampling(const nfa_ray_segments *segments, const float *cdfs, int64_t n_intervals,
                             const float *jitter, float *out_edges, float *out_mids, void *stream);
+/* The same with a PER-RAY number of intervals — the Tensor overload of the reference's importance_sampling (nerfacc.cpp:100-105,
+ * pdf.cu:294-357; its own implementation allocates no output elements, so this follows what its kernels state: pdf.cu:112-116,
+ * 207-239).  Flattened outputs: ray r has sm_cnts[r] samples from sm_starts[r] (= exclusive sum of sm_cnts) and, when sm_cnts[r] > 0,
+ * sm_cnts[r] + 1 edges from iv_starts[r] (= exclusive sum of (cnt + 1) * (cnt > 0)); n_samples = sum of sm_cnts.  iv_is_left is set on
+ * all but a ray's last edge, iv_is_right on all but its first.  Index / flag outputs are nullable.  A ray's values equal those of
+ * nfa_importance_sampling with n_intervals = sm_cnts[r]. */
+int nfa_importance_sampling_ragged(const nfa_ray_segments *segments, const float *cdfs, const int64_t *sm_starts,
+                                   const int64_t *sm_cnts, const int64_t *iv_starts, int64_t n_samples, const float *jitter,
+                                   float *sm_vals, int64_t *sm_ray_indices, float *iv_vals, int64_t *iv_ray_indices,
+                                   uint8_t *iv_is_left, uint8_t *iv_is_right, void *stream);
 /* For every query value find (left, right) with key[left] <= q < key[right] in the same ray's
  * key edges, clamped to the ray (pdf.cu:245-286).  ids are relative to the ray for a batched
  * query and absolute positions in key.vals for a flattened one, as in the reference. */

@@ -312,6 +312,21 @@ __device__ __forceinline__ int wave_seg_incl_scan_i32(int v, int dist) {
     return v;
 }
 
+// Rays per wave, decided ON THE DEVICE (round 5).  The host's choice goes by the ray count alone (enough waves for
+// every SIMD); what a wave's block costs, though, is its RUNS — every run is a segment to list, scan and bisect — and a grid of
+// alternating voxels has 30-60 runs per ray where an object has 2-5: at 65 k rays of the 256^3 noise grid 16 rays per wave took 419 us
+// and 2 rays per wave 194 (profiles/r04_emit.md).  The call's runs = edges - samples are in the workspace when this kernel starts
+// (the offsets kernel's totals), so the block is halved until it holds at most kEmitRunsPerBlock runs on average — never below
+// `rb_min` (the grid was sized for that many blocks).
+constexpr int64_t kEmitRunsPerBlock = 160;
+__device__ __forceinline__ int emit_rays_per_wave_log2(int rb_log2, int rb_min, int64_t n_rays, const int64_t *__restrict__ n_dev) {
+    if (rb_min >= rb_log2) return rb_log2;
+    const int64_t runs = n_dev[0] - n_dev[1];
+    int rb = rb_log2;
+    while (rb > rb_min && (runs << rb) > kEmitRunsPerBlock * n_rays) --rb;
+    return rb;
+}
+
 template <bool IV>
 __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const RunStore &rs, int rb_log2, int seg_cap, unsigned char *lds_raw,
                                               const int64_t *__restrict__ n_dev, int64_t capacity, int speculative)
@@ -534,10 +549,10 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
 // the tile form's own kernel: the host launches it for every cone_angle == 0 call (`emit` option: auto or tiles)
 template <bool IV>
 __global__ __launch_bounds__(kBlock) void traverse_emit_tiles_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
-                                                                     const int64_t *__restrict__ n_dev, int speculative, int rb_log2, int seg_cap)
+                                                                     const int64_t *__restrict__ n_dev, int speculative, int rb_log2, int rb_min, int seg_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
-    emit_by_tiles<IV>(a, rs, rb_log2, seg_cap, emit_lds, n_dev, capacity, speculative);
+    emit_by_tiles<IV>(a, rs, emit_rays_per_wave_log2(rb_log2, rb_min, a.n_rays, n_dev), seg_cap, emit_lds, n_dev, capacity, speculative);
 }
 
 // pass 2: ONE launch, the form chosen ON THE DEVICE from the totals the offsets kernel left in the workspace (the speculative

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "lattice.hpp"
+#include "dda_skip.hpp"       // struct Dda, dda_advance and the macro step dda_skip (host-testable)
 
 namespace nfa {
 
@@ -67,14 +68,6 @@ __device__ __forceinline__ bool slab_test(const float o[3], const float inv[3], 
 __device__ __forceinline__ int f2i(float x) { return (int)x; }  // v_cvt_i32_f32: trunc, saturating, NaN -> 0
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-struct Dda {
-    float tx, ty, tz;   // t at which the ray crosses the next x / y / z voxel plane
-    float dx, dy, dz;   // t between successive planes per axis
-    int sx, sy, sz;     // index step per axis (-1, 0, +1)
-    int cx, cy, cz;     // current voxel
-    int ox, oy, oz;     // first out-of-segment index per axis (final + step)
-};
-
 __device__ __forceinline__ void dda_axis(float o, float d, float inv, float lo, float hi, int res,
                                          float tmin, float tmax, float t_in, float t_out,
                                          float &tdist, float &delta, int &step, int &cur, int &overflow) {
@@ -103,25 +96,6 @@ __device__ __forceinline__ void dda_setup(Dda &s, const float o[3], const float 
     dda_axis(o[0], d[0], inv[0], box[0], box[3], res[0], tmin, tmax, t_in, t_out, s.tx, s.dx, s.sx, s.cx, s.ox);
     dda_axis(o[1], d[1], inv[1], box[1], box[4], res[1], tmin, tmax, t_in, t_out, s.ty, s.dy, s.sy, s.cy, s.oy);
     dda_axis(o[2], d[2], inv[2], box[2], box[5], res[2], tmin, tmax, t_in, t_out, s.tz, s.dz, s.sz, s.cz, s.oz);
-}
-
-// utils_grid.cuh:116-142: step along the axis whose next plane is strictly nearest (ties go
-// z, then y, then x by the strict '<' chain).  Written with selects: the three-way branch of
-// the reference makes a wave execute all three arms at almost every voxel.
-__device__ __forceinline__ bool dda_advance(Dda &s) {
-    const bool ax = (s.tx < s.ty) && (s.tx < s.tz);
-    const bool ay = !ax && (s.ty < s.tz);
-    const bool az = !ax && !ay;
-    s.cx += ax ? s.sx : 0;
-    s.cy += ay ? s.sy : 0;
-    s.cz += az ? s.sz : 0;
-    s.tx = ax ? s.tx + s.dx : s.tx;
-    s.ty = ay ? s.ty + s.dy : s.ty;
-    s.tz = az ? s.tz + s.dz : s.tz;
-    // (bitwise on purpose: a select between the three overflow indices makes the compiler
-    //  spill them to scratch and index them, one scratch load per voxel)
-    const bool hit_x = s.cx == s.ox, hit_y = s.cy == s.oy, hit_z = s.cz == s.oz;
-    return !((ax & hit_x) | (ay & hit_y) | (az & hit_z));
 }
 
 // grid.cu:157-161 / 199-203: advance the marching lattice, t += dt with dt fixed, until the
@@ -173,10 +147,12 @@ __global__ __launch_bounds__(kBlock) void ray_aabb_kernel(
 //   [0, n_bricks)                       dense bricks (bit = (x&3)*16 + (y&3)*4 + (z&3))
 //   [n_bricks, +4)                      header: {n_compact, 0, 0, 0}
 //   then coarse[n_words] u32 (1 bit per brick), prefix[n_words] u32 (non-empty bricks before
-//   the word), each padded to 8 bytes, then compact[n_bricks] (the non-empty bricks in order).
+//   the word), each padded to 8 bytes, then compact[n_bricks] (the non-empty bricks in order), then dist: one NIBBLE per brick
+//   (brick b in byte b / 2, low nibble first) = Chebyshev distance in bricks, within its level, to the nearest non-empty brick,
+//   capped at kDistCap (0 = the brick itself holds an occupied voxel).
 // ----------------------------------------------------------------------------------------
 struct PackedLayout {
-    int64_t n_bricks, n_words, off_header, off_coarse, off_prefix, off_compact, total_words;
+    int64_t n_bricks, n_words, off_header, off_coarse, off_prefix, off_compact, off_dist, total_words;
 };
 __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int ry, int rz) {
     PackedLayout L;
@@ -186,7 +162,8 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
     L.off_coarse = L.off_header + 12;          // header: [0] non-empty bricks, [1 + g] occupied voxels of level g (g < 8), 3 spare
     L.off_prefix = L.off_coarse + (L.n_words + 1) / 2;
     L.off_compact = L.off_prefix + (L.n_words + 1) / 2;
-    L.total_words = L.off_compact + L.n_bricks;
+    L.off_dist = L.off_compact + L.n_bricks;     // round 5: 4 bits per brick, distance to the nearest non-empty brick (brick_dist_kernel)
+    L.total_words = L.off_dist + (L.n_bricks + 15) / 16;
     return L;
 }
 
@@ -311,6 +288,51 @@ __global__ __launch_bounds__(kBlock) void compact_bricks_kernel(const uint64_t *
     }
 }
 
+// Empty-space skipping (round 5): per brick the Chebyshev distance D, in bricks and within its level, to the nearest non-empty
+// brick, capped at kDistCap.  A walk standing in a brick with D >= 1 knows that the cube of (2 D - 1)^3 bricks around it is empty
+// and leaves it in ONE macro step (dda_skip.hpp) — with D <= 4 that is at most 15 further plane crossings per axis, the range of
+// the macro step's integer bisection.  One lane per PAIR of bricks (one byte of output), brute force over the 7^3 neighbourhood of
+// the bitmap of non-empty bricks: 32 k bricks at 128^3, a few microseconds once per grid update.  Bricks beyond the grid count as
+// empty (a walk never goes there: its overflow index stops it first).
+constexpr int kDistCap = 4;
+__global__ __launch_bounds__(kBlock) void brick_dist_kernel(const uint32_t *__restrict__ coarse, int n_grids, int nbx, int nby, int nbz,
+                                                            uint8_t *__restrict__ dist)
+{
+    const int64_t per_grid = (int64_t)nbx * nby * nbz, total = per_grid * n_grids;
+    for (int64_t pair = (int64_t)blockIdx.x * kBlock + threadIdx.x; 2 * pair < total; pair += (int64_t)gridDim.x * kBlock) {
+        unsigned out = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int64_t b = 2 * pair + h;
+            if (b >= total) break;
+            const int64_t g = b / per_grid;
+            int64_t rem = b - g * per_grid;
+            const int bx = (int)(rem / ((int64_t)nby * nbz));
+            rem -= (int64_t)bx * nby * nbz;
+            const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
+            int best = kDistCap;
+            for (int dx = -(kDistCap - 1); dx <= kDistCap - 1; ++dx) {
+                const int x = bx + dx, adx = dx < 0 ? -dx : dx;
+                if (x < 0 || x >= nbx || adx >= best) continue;
+                for (int dy = -(kDistCap - 1); dy <= kDistCap - 1; ++dy) {
+                    const int y = by + dy, ady = dy < 0 ? -dy : dy;
+                    const int axy = adx > ady ? adx : ady;
+                    if (y < 0 || y >= nby || axy >= best) continue;
+                    const int64_t row = g * per_grid + ((int64_t)x * nby + y) * nbz;
+                    for (int dz = -(kDistCap - 1); dz <= kDistCap - 1; ++dz) {
+                        const int z = bz + dz, adz = dz < 0 ? -dz : dz;
+                        const int r = axy > adz ? axy : adz;
+                        if (z < 0 || z >= nbz || r >= best) continue;
+                        const int64_t id = row + z;
+                        if ((coarse[id >> 5] >> (id & 31)) & 1u) best = r;
+                    }
+                }
+            }
+            out |= (unsigned)best << (4 * h);
+        }
+        dist[pair] = (uint8_t)out;
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // K2: traversal
 // ----------------------------------------------------------------------------------------
@@ -326,6 +348,9 @@ struct GridView {
     int n_words;
     int lds_words;        // bitmap (and rank) words staged in LDS (0 = nothing staged)
     int lds_compact_cap;  // compact bricks staged in LDS (0 with lds_words > 0: bitmap only, bricks from L2)
+    const uint8_t *__restrict__ dist;   // one nibble per brick: distance to the nearest non-empty brick (brick_dist_kernel)
+    int lds_dist_off;     // byte offset of the staged distances in the kernel's dynamic LDS, -1 = read from L2
+    int lds_dist_bytes;
 };
 
 struct BrickCache {
@@ -379,6 +404,61 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
     return l;
 }
 
+// The same staging in two halves (round 5, the 512-thread crossing-time form of the split count pass): `stage_issue` requests the
+// image's words into registers, `stage_commit` writes them to LDS and joins the workgroup.  What a kernel computes between the two
+// — the ray's slab test, DDA setup and the closed-form jumps, none of which touches the image — runs under the L2 round trips of the
+// copy instead of behind them (3.6 k of the mean wave's 45 k cycles, profiles/r04_count_pass.md section 4).  At most kStageWords
+// bitmap words and kStageBricks compact bricks per thread are held; a larger image is copied by the plain loop in stage_commit.
+constexpr int kStageWords = 2, kStageBricks = 8;
+struct StagePending {
+    uint2 w[kStageWords];
+    uint64_t b[kStageBricks];
+    bool in_regs;
+};
+__device__ __forceinline__ Occ<true> stage_layout(const GridView &g, char *smem) {
+    Occ<true> l;
+    l.smem = smem;
+    l.w4 = (g.lds_words + 3) & ~3;
+    l.cap = g.lds_compact_cap;
+    l.bytes = (2 * l.w4 * 4 + g.lds_compact_cap * 8 + 15) & ~15;
+    return l;
+}
+template <int BLK>
+__device__ __forceinline__ void stage_issue(const GridView &g, StagePending &sp) {
+    sp.in_regs = g.lds_words <= kStageWords * BLK && g.lds_compact_cap <= kStageBricks * BLK;      // (workgroup-uniform)
+    // EVERY thread issues the same loads on one straight path (indices clamped, not predicated): with a branch around them the
+    // compiler's wait-count pass has to assume the path without loads at the join and waits for vmcnt(0) at the first use of the
+    // ray's values — the copy then completes before the arithmetic it was meant to run under.
+    const int tid = threadIdx.x;
+    const int w_last = g.lds_words > 0 ? g.lds_words - 1 : 0, b_last = g.lds_compact_cap > 0 ? g.lds_compact_cap - 1 : 0;
+#pragma unroll
+    for (int k = 0; k < kStageWords; ++k) {
+        const int i = min(tid + k * BLK, w_last);
+        sp.w[k] = make_uint2(g.coarse[i], g.prefix[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < kStageBricks; ++k) {
+        const int i = min(tid + k * BLK, b_last);
+        sp.b[k] = g.compact[i];
+    }
+}
+template <int BLK>
+__device__ __forceinline__ void stage_commit(const GridView &g, const Occ<true> &l, const StagePending &sp) {
+    uint2 *lw = (uint2 *)l.smem;
+    uint64_t *lb = (uint64_t *)((uint32_t *)l.smem + 2 * l.w4);
+    const int tid = threadIdx.x;
+    if (sp.in_regs) {
+#pragma unroll
+        for (int k = 0; k < kStageWords; ++k) { const int i = tid + k * BLK; if (i < g.lds_words) lw[i] = sp.w[k]; }
+#pragma unroll
+        for (int k = 0; k < kStageBricks; ++k) { const int i = tid + k * BLK; if (i < g.lds_compact_cap) lb[i] = sp.b[k]; }
+    } else {
+        for (int i = tid; i < g.lds_words; i += BLK) lw[i] = make_uint2(g.coarse[i], g.prefix[i]);
+        for (int i = tid; i < g.lds_compact_cap; i += BLK) lb[i] = g.compact[i];
+    }
+    __syncthreads();
+}
+
 // occupancy of voxel (x,y,z); the brick is re-resolved only when the walk enters another brick
 template <bool LDS_OCC>
 __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &l, BrickCache &c, int level, int x, int y, int z) {
@@ -407,6 +487,39 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
         c.bits = bits;
     }
     return (c.bits >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull;
+}
+
+// ---- empty-space skipping (round 5) -------------------------------------------------------------------------------------
+// the 64 voxels of brick `id` (same sources as `occupied`)
+template <bool LDS_OCC>
+__device__ __forceinline__ uint64_t brick_bits(const GridView &g, const Occ<LDS_OCC> &l, int id) {
+    if (LDS_OCC) {
+        const uint2 wr = ((const uint2 *)l.smem)[id >> 5];
+        const uint32_t bit = 1u << (id & 31);
+        const int k = (wr.x & bit) ? (int)wr.y + __popc(wr.x & (bit - 1u)) : 0;
+        const uint64_t b = ((const uint64_t *)((const uint32_t *)l.smem + 2 * l.w4))[k];
+        return (wr.x & bit) ? b : 0ull;
+    }
+    return g.bricks[id];
+}
+// distance (in bricks, capped at kDistCap) from brick `id` to the nearest non-empty brick of its level; 0 = non-empty
+template <bool DIST_LDS>
+__device__ __forceinline__ int brick_dist(const GridView &g, const char *smem, int id) {
+    const unsigned v = DIST_LDS ? (unsigned)((const uint8_t *)(smem + g.lds_dist_off))[id >> 1] : (unsigned)g.dist[id >> 1];
+    return (int)((v >> ((id & 1) << 2)) & 15u);
+}
+__device__ __forceinline__ void stage_dist(const GridView &g, char *smem) {
+    const uint32_t *src = (const uint32_t *)g.dist;
+    uint32_t *dst = (uint32_t *)(smem + g.lds_dist_off);
+    for (int i = threadIdx.x; i < (g.lds_dist_bytes >> 2); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+// plane crossings a macro step may take per axis BEYOND the pending one (dda_skip's k?1) from voxel c of a brick at distance D >= 1:
+// to the face of the cube of (2 D - 1)^3 empty bricks around the brick, never past the axis' overflow index
+__device__ __forceinline__ int skip_reach(int c, int step, int overflow, int D) {
+    const int to_face = 4 * (D - 1) + ((c & 3) ^ (step > 0 ? 3 : 0));
+    const int left = (overflow - c) * step;                 // crossings until the walk ends on this axis (<= 0: never, or step 0)
+    return left >= 1 ? min(to_face, left - 1) : 0;
 }
 
 // sorted ray/grid events (grid.py:156-162): EV_PRE = the caller's arrays; EV_ONE = one level,
@@ -574,15 +687,26 @@ struct FillSink {
 //   far  = full_like(far_plane);  far  = clamp(far, max=t_max)
 // Tensors (near_planes / far_planes) win when given; the scalar + t_min/t_max + jitter form saves the caller five
 // elementwise launches per sampling call.
+// Round 5: every optional array is read through a SELECTED POINTER (the array's element, or the ray's origin when the array is absent —
+// always a valid address) on one straight path, and the value is selected afterwards.  With `if (a.t_min) { ... a.t_min[r] ... }` the
+// compiler put each load in its own block with its own s_waitcnt vmcnt(0): three to four SERIALISED memory round trips at the head of
+// every traversal kernel (t_min, jitter, t_max of OccGridEstimator.sampling) before the slab test could start.
 __device__ __forceinline__ float ray_near(const nfa_traverse_args &a, int64_t r) {
-    float v = a.near_planes ? a.near_planes[r] : a.near_plane;
-    if (a.t_min) { const float m = a.t_min[r]; v = (m != m) ? m : (v < m ? m : v); }        // torch.clamp(min=): NaN bound propagates
-    if (a.jitter) v = v + a.jitter[r] * a.jitter_scale;                                        // -ffp-contract=off: mul, then add
+    const float *fallback = a.rays_o + 3 * r;
+    const float ld_n = *(a.near_planes ? a.near_planes + r : fallback);
+    const float ld_m = *(a.t_min ? a.t_min + r : fallback);
+    const float ld_j = *(a.jitter ? a.jitter + r : fallback);
+    float v = a.near_planes ? ld_n : a.near_plane;
+    if (a.t_min) { const float m = ld_m; v = (m != m) ? m : (v < m ? m : v); }                 // torch.clamp(min=): NaN bound propagates
+    if (a.jitter) v = v + ld_j * a.jitter_scale;                                               // -ffp-contract=off: mul, then add
     return v;
 }
 __device__ __forceinline__ float ray_far(const nfa_traverse_args &a, int64_t r) {
-    float v = a.far_planes ? a.far_planes[r] : a.far_plane;
-    if (a.t_max) { const float m = a.t_max[r]; v = (m != m) ? m : (v > m ? m : v); }
+    const float *fallback = a.rays_o + 3 * r;
+    const float ld_f = *(a.far_planes ? a.far_planes + r : fallback);
+    const float ld_m = *(a.t_max ? a.t_max + r : fallback);
+    float v = a.far_planes ? ld_f : a.far_plane;
+    if (a.t_max) { const float m = ld_m; v = (m != m) ? m : (v > m ? m : v); }
     return v;
 }
 
@@ -754,6 +878,172 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
     t_term = t_last;
 }
 
+// The same lattice walk with EMPTY-SPACE SKIPPING (round 5).  Phase A alternates between two tight loops — the
+// persistent "while-while" shape of GPU ray traversal:
+//   far:   the voxel's brick is empty and D bricks from the nearest non-empty one (brick_dist_kernel): ONE macro step (dda_skip)
+//          leaves the cube of (2 D - 1)^3 empty bricks around it — up to 15 plane crossings per axis, the state that the voxel walk
+//          would reach, bit for bit — and the brick under the landing voxel is looked up;
+//   near:  the brick holds an occupied voxel: the voxel walk of rounds 1-4 (boundary list, one DDA step), brick bits in a register.
+// A lane leaves a loop when its walk changes regime; the wave re-converges between the loops, so a lane in open space never pays
+// for its neighbour's voxel steps more than once per regime change (a flat "macro step or voxel step" loop body would cost the sum
+// of both at every iteration: P(the 64 lanes of a wave agree) is ~0).  On the bench scene a ray visits 188 voxels, 16 of them in
+// non-empty bricks, and takes ~11 macro steps (tools/experiments/r05_skip_stats.py).  Phase B is unchanged.
+template <int EV, bool LDS_OCC, bool DIST_LDS>
+__device__ __forceinline__ void traverse_ray_lattice_skip(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
+                                                          const char *smem, float *__restrict__ ev_lds /* [kEvCap][blockDim] */,
+                                                          int64_t r, bool active, CountSink &sink, float &t_term)
+{
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {1.f, 1.f, 1.f};
+    float near = 0.f, far = 0.f;
+    if (active) {
+        o[0] = a.rays_o[3 * r]; o[1] = a.rays_o[3 * r + 1]; o[2] = a.rays_o[3 * r + 2];
+        d[0] = a.rays_d[3 * r]; d[1] = a.rays_d[3 * r + 1]; d[2] = a.rays_d[3 * r + 2];
+        near = ray_near(a, r);
+        far = ray_far(a, r);
+    }
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    const float dt = march_dt(0.0f, 0.0f, a.step_size);     // = clamp(step_size, ., 1e10)
+    const int limit = a.traverse_steps_limit;
+    const int G = a.n_grids;
+    const int nthr = blockDim.x, tid = threadIdx.x;
+
+    Events<EV> ev;
+    if (active) ev.init(a, r, o, inv);
+
+    float t_last = near;
+    bool continuous = false, finished = !active;
+
+    for (int i = 0; i + 1 < 2 * G; ++i) {
+        int level = 0;
+        float seg_lo = 0.f, seg_hi = 0.f;
+        bool seg_live = !finished && segment_of(ev, i, G, near, far, level, seg_lo, seg_hi);
+        if (seg_live && !continuous) {
+            int64_t k; bool stuck;
+            t_last = nfa_lattice_until(t_last, dt, seg_lo, &k, &stuck);
+            if (stuck) t_last = seg_lo;
+        }
+        Dda s;
+        s.tx = s.ty = s.tz = 0.f; s.dx = s.dy = s.dz = 0.f;
+        s.sx = s.sy = s.sz = 0; s.cx = s.cy = s.cz = 0; s.ox = s.oy = s.oz = 0;
+        if (seg_live) dda_setup(s, o, d, inv, seg_lo, seg_hi, a.aabbs + 6 * level, gv.res);
+        bool have_run = false, run_occ = false;
+        float run_exit = 0.f;
+        const int id_base = level * gv.bricks_per_grid;
+        // macro steps run in the integer domain (dda_skip.hpp: IDda), which needs positive, ordered crossing times; a ray without
+        // them simply never leaves the voxel loop
+        const bool sane = seg_live && idda_sane(s);
+        // brick under the current voxel: its distance nibble and its 64 voxels (both requested together: one round trip)
+        int cur_id = -1, cur_dist = 0;
+        uint64_t cur_bits = 0;
+        while (__any(seg_live)) {
+            // ---- A: boundaries only
+            int n_ev = 0;
+            unsigned ev_occ = 0;
+            bool go = seg_live;
+            while (go) {
+                {
+                    const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + id_base;
+                    if (id != cur_id) {
+                        cur_id = id;
+                        cur_dist = brick_dist<DIST_LDS>(gv, smem, id);
+                        cur_bits = brick_bits<LDS_OCC>(gv, occ, id);
+                    }
+                }
+                if (sane && cur_dist > 0) {
+                    // far: the current voxel is empty — the occupied run before it, if any, ends here
+                    if (have_run && run_occ) {
+                        ev_lds[n_ev * nthr + tid] = run_exit;
+                        ev_occ |= 1u << n_ev;
+                        ++n_ev;
+                    }
+                    have_run = true;
+                    run_occ = false;
+                    IDda w = idda_init(s);
+                    bool far_ = true;
+                    while (far_) {
+                        const DdaSkip k = idda_skip(w, skip_reach(w.cx, w.sx, w.ox, cur_dist), skip_reach(w.cy, w.sy, w.oy, cur_dist),
+                                                    skip_reach(w.cz, w.sz, w.oz, cur_dist));
+                        run_exit = fminf(k.t_exit, seg_hi);
+                        if (!k.cont) {
+                            seg_live = false;
+                            far_ = false;
+                        } else {
+                            const int id = (int)__umul24(__umul24(w.cx >> 2, gv.nby) + (w.cy >> 2), gv.nbz) + (w.cz >> 2) + id_base;
+                            if (id != cur_id) { cur_id = id; cur_dist = brick_dist<DIST_LDS>(gv, smem, id); }
+                            far_ = cur_dist > 0;
+                        }
+                    }
+                    s.tx = nfa_u2f(w.x.tb); s.ty = nfa_u2f(w.y.tb); s.tz = nfa_u2f(w.z.tb);
+                    s.cx = w.cx; s.cy = w.cy; s.cz = w.cz;
+                    if (seg_live) cur_bits = brick_bits<LDS_OCC>(gv, occ, cur_id);
+                } else {
+                    // near: voxel by voxel inside non-empty bricks
+                    bool near_ = true;
+                    while (near_) {
+                        const float t_cell = fminf(fminf(s.tx, fminf(s.ty, s.tz)), seg_hi);
+                        const bool oc = (cur_bits >> (((s.cx & 3) << 4) | ((s.cy & 3) << 2) | (s.cz & 3))) & 1ull;
+                        if (have_run && oc != run_occ) {
+                            ev_lds[n_ev * nthr + tid] = run_exit;
+                            ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+                            ++n_ev;
+                        }
+                        have_run = true;
+                        run_occ = oc;
+                        run_exit = t_cell;
+                        if (!dda_advance(s)) {
+                            seg_live = false;
+                            near_ = false;
+                        } else {
+                            const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + id_base;
+                            if (id != cur_id) {
+                                cur_id = id;
+                                cur_dist = brick_dist<DIST_LDS>(gv, smem, id);
+                                cur_bits = brick_bits<LDS_OCC>(gv, occ, id);
+                            }
+                            near_ = !(sane && cur_dist > 0) && n_ev < kEvCap - 1;
+                        }
+                    }
+                }
+                go = seg_live && n_ev < kEvCap - 1;
+            }
+            if (!seg_live && have_run) {            // the segment's last run
+                ev_lds[n_ev * nthr + tid] = run_exit;
+                ev_occ |= (run_occ ? 1u : 0u) << n_ev;
+                ++n_ev;
+                have_run = false;
+            }
+            // ---- B: lattice arithmetic, one boundary per lane per iteration
+            int n_max = n_ev;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+            for (int j = 0; j < n_max; ++j) {
+                if (j >= n_ev || finished) continue;
+                const float bound = ev_lds[j * nthr + tid];
+                int64_t k; bool stuck;
+                const float t_new = nfa_lattice_until(t_last, dt, bound, &k, &stuck);
+                if ((ev_occ >> j) & 1u) {
+                    if (limit > 0 && sink.n_sm + k >= limit) {        // grid.cu:184,208
+                        k = limit - sink.n_sm;
+                        sink.run(t_last, k, continuous);
+                        t_last = nfa_lattice_advance(t_last, dt, k, nullptr);
+                        if (k > 0) continuous = true;
+                        finished = true;
+                        seg_live = false;
+                    } else {
+                        sink.run(t_last, k, continuous);
+                        if (k > 0) continuous = true;
+                        t_last = t_new;
+                    }
+                } else {
+                    continuous = false;
+                    t_last = stuck ? bound : t_new;
+                }
+            }
+        }
+    }
+    t_term = t_last;
+}
+
 // per-WAVE reduction of per-ray {edges, samples, overflow rays} -> wave_sums[3 w + {0,1,2}], w = the
 // wave's global index (lanes that do not own a ray pass zeros).  One triple per wave instead of
 // per workgroup: no LDS, no __syncthreads, so a wave that finished its rays retires at once.
@@ -768,17 +1058,23 @@ __device__ __forceinline__ void publish_wave_sums(int64_t n_iv, int64_t n_sm, in
 }
 
 // pass 1.  Block b owns rays [256 b, 256 b + 256).
-template <int EV, bool LATTICE, bool LDS_OCC>
+// SKIP (lattice form only): 0 = voxel by voxel, 1 = empty-space macro steps with the brick distances read from L2, 2 = with the
+// distances staged in LDS behind the boundary lists (gv.lds_dist_off)
+template <int EV, bool LATTICE, bool LDS_OCC, int SKIP = 0>
 __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_args a, GridView gv,
                                                                 int64_t *__restrict__ block_sums, RunStore rs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    if (SKIP == 2) stage_dist(gv, smem);
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = r < a.n_rays && !(a.rays_mask && !a.rays_mask[r]);
     CountSink sink{rs, r, a.n_rays};
     float t_term = 0.f;
-    if (LATTICE) {
+    if (LATTICE && SKIP) {
+        float *ev_lds = (float *)(smem + occ.bytes);
+        traverse_ray_lattice_skip<EV, LDS_OCC, SKIP == 2>(a, gv, occ, smem, ev_lds, r, active, sink, t_term);
+    } else if (LATTICE) {
         // the boundary lists sit behind the occupancy image in LDS
         float *ev_lds = (float *)(smem + occ.bytes);
         traverse_ray_lattice<EV, LDS_OCC>(a, gv, occ, ev_lds, r, active, sink, t_term);
@@ -1023,6 +1319,9 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int
     GridView gv;
     const PackedLayout L = packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]);
     gv.bricks = a->bricks;
+    gv.dist = (const uint8_t *)(a->bricks + L.off_dist);
+    gv.lds_dist_off = -1;
+    gv.lds_dist_bytes = 0;
     gv.header = (const int64_t *)(a->bricks + L.off_header);
     gv.coarse = (const uint32_t *)(a->bricks + L.off_coarse);
     gv.prefix = (const uint32_t *)(a->bricks + L.off_prefix);
@@ -1160,14 +1459,17 @@ NFA_EXPORT int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry
     return packed_layout(n_grids, rx, ry, rz).total_words;
 }
 
-static int rank_and_compact(uint64_t *bricks, const PackedLayout &L, hipStream_t s) {
+static int rank_and_compact(uint64_t *bricks, const PackedLayout &L, hipStream_t s, int n_grids, int rx, int ry, int rz) {
     uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
     uint32_t *prefix = (uint32_t *)(bricks + L.off_prefix);
     hipLaunchKernelGGL(rank_bricks_kernel, dim3(1), dim3(1024), 0, s, coarse, L.n_words, prefix, (int64_t *)(bricks + L.off_header));
     if (int rc = check_launch("rank_bricks_kernel")) return rc;
     hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
                        bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
-    return check_launch("compact_bricks_kernel");
+    if (int rc = check_launch("compact_bricks_kernel")) return rc;
+    hipLaunchKernelGGL(brick_dist_kernel, dim3(blocks_for((L.n_bricks + 1) / 2)), dim3(kBlock), 0, s, coarse, n_grids, (rx + 3) / 4, (ry + 3) / 4,
+                       (rz + 3) / 4, (uint8_t *)(bricks + L.off_dist));
+    return check_launch("brick_dist_kernel");
 }
 
 NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
@@ -1186,7 +1488,7 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
                        binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
                        (const float *)nullptr, (const double *)nullptr, 0, 0.0f, (uint8_t *)nullptr, (float *)nullptr);
     if (int rc = check_launch("pack_bricks_kernel")) return rc;
-    return rank_and_compact(bricks, L, s);
+    return rank_and_compact(bricks, L, s, n_grids, rx, ry, rz);
 }
 
 // nfa_grid_threshold + nfa_pack_binaries in four launches instead of five: the pass that compares the occupancies
@@ -1209,7 +1511,7 @@ NFA_EXPORT int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int
                        (const uint8_t *)nullptr, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
                        occs, (const double *)workspace, nb, occ_thre, binaries, threshold_out);
     if (int rc = check_launch("pack_bricks_kernel<occs>")) return rc;
-    return rank_and_compact(bricks, L, s);
+    return rank_and_compact(bricks, L, s, n_grids, rx, ry, rz);
 }
 
 NFA_EXPORT int64_t nfa_traverse_workspace_bytes(int64_t n_rays) {
@@ -1493,20 +1795,42 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (l2) gv = make_view(a, kEvBytes, &lds, 0);
     }
     const bool lds_occ = gv.lds_compact_cap > 0;
-#define NFA_LAUNCH_COUNT(EVM, LAT, LDSO)                                                                                    \
-    do {                                                                                                                    \
-        if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO>, lds)) return rc;                                       \
-        hipLaunchKernelGGL((traverse_count_kernel<EVM, LAT, LDSO>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    // empty-space skipping (lattice form): the brick distances (half a byte per brick) staged in LDS behind the lists when they are
+    // at most 16 KB (128^3: every workgroup-per-CU count stays as it was with 16-entry... lists + image), else read from L2 —
+    // next to the brick word they replace for every empty brick.  NFA_SKIP = 0 | 1 | 2 overrides (2 falls back to 1 when they do not fit)
+    int skip = 0;
+    if (lattice) {
+        const int64_t dist_bytes = (((packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]).n_bricks + 1) / 2) + 15) & ~15ll;
+        const bool fits = dist_bytes <= 16 * 1024 && lds + dist_bytes <= 80 * 1024;
+        skip = (int)opt(OPT_SKIP, fits ? 2 : 1);
+        if (skip == 2 && !(dist_bytes + lds <= 80 * 1024)) skip = 1;
+        if (skip == 2) {
+            gv.lds_dist_off = lds;
+            gv.lds_dist_bytes = (int)dist_bytes;
+            lds += (int)dist_bytes;
+        }
+    }
+#define NFA_LAUNCH_COUNT(EVM, LAT, LDSO, SK)                                                                                    \
+    do {                                                                                                                        \
+        if (int rc = allow_lds(traverse_count_kernel<EVM, LAT, LDSO, SK>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((traverse_count_kernel<EVM, LAT, LDSO, SK>), dim3(nb), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+    } while (0)
+#define NFA_COUNT_LAT(EVM, LDSO)                                                      \
+    do {                                                                              \
+        if (skip == 2) NFA_LAUNCH_COUNT(EVM, true, LDSO, 2);                          \
+        else if (skip == 1) NFA_LAUNCH_COUNT(EVM, true, LDSO, 1);                     \
+        else NFA_LAUNCH_COUNT(EVM, true, LDSO, 0);                                    \
     } while (0)
 #define NFA_COUNT_EV(EVM)                                                              \
     do {                                                                               \
-        if (lattice) { if (lds_occ) NFA_LAUNCH_COUNT(EVM, true, true); else NFA_LAUNCH_COUNT(EVM, true, false); }   \
-        else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true); else NFA_LAUNCH_COUNT(EVM, false, false); } \
+        if (lattice) { if (lds_occ) NFA_COUNT_LAT(EVM, true); else NFA_COUNT_LAT(EVM, false); }   \
+        else         { if (lds_occ) NFA_LAUNCH_COUNT(EVM, false, true, 0); else NFA_LAUNCH_COUNT(EVM, false, false, 0); } \
     } while (0)
     if (evm == EV_PRE) NFA_COUNT_EV(EV_PRE);
     else if (evm == EV_ONE) NFA_COUNT_EV(EV_ONE);
     else NFA_COUNT_EV(EV_MANY);
 #undef NFA_COUNT_EV
+#undef NFA_COUNT_LAT
 #undef NFA_LAUNCH_COUNT
     return check_launch("traverse_count_kernel");
 }
@@ -1614,15 +1938,19 @@ static int launch_emit(const nfa_traverse_args *a, const RunStore &rs, int64_t c
         // rays per wave: enough waves for every SIMD (1024) to hold two or more; segment-list capacity: a ray's runs must fit
         // (run_capacity), 128 at least — a 64-ray block of a NeRF-like scene has 40-80 runs
         const int rb_log2 = (int)opt(OPT_EMIT_RB, R <= 2048 ? 0 : R <= 4096 ? 1 : R <= 8192 ? 2 : R <= 32768 ? 3 : R <= 131072 ? 4 : R <= 262144 ? 5 : 6);      // (tools/experiments/r04_emit_rb*.{sh,py})
+        // the kernel may take FEWER rays per wave than that when the call turns out to have many runs per ray (emit_rays_per_wave_log2:
+        // it sees the totals, the host at a speculative launch does not) — down to rb_min, which the grid is sized for; a forced
+        // `emit_rb` is taken as it is
+        const int rb_min = opt_is_set(OPT_EMIT_RB) ? rb_log2 : (rb_log2 > 3 ? rb_log2 - 3 : 0);
         int seg_cap = 128;
         while (seg_cap < rs.max_runs) seg_cap *= 2;
         const int words = kEmitSegWords + (a->iv_vals ? 2 : 0);
         const unsigned lds = (unsigned)(kWavesPerBlock * (seg_cap * 4 * words + kEmitRayBaseBytes));
-        const int64_t n_rb = ceil_div(R, (int64_t)1 << rb_log2), cap = (int64_t)kNumCU * 16;
+        const int64_t n_rb = ceil_div(R, (int64_t)1 << rb_min), cap = (int64_t)kNumCU * 16;
         const int64_t nb = ceil_div(n_rb, kWavesPerBlock);
         const dim3 g((unsigned)(nb < cap ? nb : cap)), b(kBlock);
-        if (a->iv_vals) hipLaunchKernelGGL(traverse_emit_tiles_kernel<true>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, seg_cap);
-        else hipLaunchKernelGGL(traverse_emit_tiles_kernel<false>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, seg_cap);
+        if (a->iv_vals) hipLaunchKernelGGL(traverse_emit_tiles_kernel<true>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, rb_min, seg_cap);
+        else hipLaunchKernelGGL(traverse_emit_tiles_kernel<false>, g, b, lds, s, *a, rs, capacity, n_dev, speculative, rb_log2, rb_min, seg_cap);
         return check_launch("traverse_emit_tiles_kernel");
     }
     const unsigned nb_s = blocks_for(capacity), nb_r = emit_ray_blocks(a->n_rays);

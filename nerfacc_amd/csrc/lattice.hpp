@@ -33,6 +33,12 @@ NFA_HD float nfa_u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 
 // Exact value after j sequential steps t = RN(t + d) (j >= 0, d > 0).  If the sequence gets
 // stuck (t + d == t) the stuck value is returned.  `*taken` (optional) = steps really taken.
+//
+// Round 5: the trip is ONE basic block.  Round 2-4's body had three data-dependent `break`s and 64-bit step counts inside; the
+// compiler cut it into a dozen exec-masked blocks (~110 instructions and ~12 branches per binade: profiles/r04_count_pass.md
+// section 4 — lane 0's jump from the near plane, ~10 binades, was 11 k cycles of every count-pass wave).  Now every quantity is
+// computed unconditionally in 32 bits and selected, the loop's only exit is its condition, and the plain-add prologue stops at
+// 8 d instead of 32 d (a trip is cheap enough to take the binades [8 d, 32 d) as well).
 NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
 {
     const int64_t j0 = j;
@@ -40,22 +46,23 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
     const int ed = (int)((db >> 23) & 0xffu);
     const uint32_t D = (db & 0x7fffffu) | 0x800000u;
     const bool d_ok = ed >= 1 && ed < 255 && (db >> 31) == 0;     // positive normal
-    // Close to zero the binades are short (a binade below 32 d holds < 32 lattice points): plain
+    // Close to zero the binades are short (a binade below 8 d holds < 8 lattice points): plain
     // adds are cheaper there than the per-binade bookkeeping below.
     if (d_ok) {
-        const float small = d * 32.0f;
-        if (t > -small) {                               // (t only grows: checked once; a 32-bit counter keeps the loop at four instructions)
-            const int lim = j < 64 ? (int)j : 64;
+        const float small = d * 8.0f;
+        if (t > -small) {                               // (t only grows: checked once; a 32-bit counter keeps the loop short)
+            const int lim = j < 24 ? (int)j : 24;
             int cnt = 0;
             while (cnt < lim && t < small) { t = t + d; ++cnt; }
             j -= cnt;
         }
     }
-    // One trip = either n >= 1 steps inside the current binade (integer multiply-add) or one real
-    // fp32 add (binade crossings, ties on an odd mantissa, anything irregular).  Both candidates
-    // are computed and one is selected: on the GPU a wave whose lanes disagree would execute both
-    // sides of a branch anyway, and straight-line code keeps a lone wave's pipeline full.
-    while (j > 0) {
+    // One trip = either n >= 1 steps inside the current binade (integer multiply-add) followed by the real add that leaves
+    // it, or one real fp32 add (ties on an odd mantissa, anything irregular).  Both candidates are computed and one is
+    // selected: on the GPU a wave whose lanes disagree would execute both sides of a branch anyway, and straight-line
+    // code keeps a lone wave's pipeline full.
+    bool live = j > 0;
+    while (live) {
         const uint32_t tb = nfa_f2u(t);
         const int e = (int)((tb >> 23) & 0xffu);
         const int sh = e - ed;
@@ -69,32 +76,36 @@ NFA_HD float nfa_lattice_advance(float t, float d, int64_t j, int64_t *taken)
         const bool tie_odd = tie && (m & 1u);                     // one real step makes m even
         // round to nearest; on a tie round-half-even makes the increment c0 + (c0 & 1) once m is even
         const uint32_t c = c0 + (rem > half ? 1u : 0u) + ((tie && !(m & 1u)) ? (c0 & 1u) : 0u);
-        if (ok && !tie_odd && c == 0u) break;                     // t + d rounds back to t: stuck
         const uint32_t lim = (1u << 24) - c0 - 1u;                // next sum may pass 2^(e+1) beyond this
-        const bool fast = ok && !tie_odd && m <= lim;
+        // (c == 0: t + d rounds back to t — the real add below finds the walk stuck)
+        const bool fast = ok && !tie_odd && c != 0u && m <= lim;
         const float nt = t + d;
-        if (!fast && nt == t) break;
+        const bool stuck = !fast && nt == t;
         // steps that provably stay inside the binade: floor((lim - m) / c) + 1.  The quotient is
         // taken in fp32 (both operands < 2^24: exact, and the correctly rounded quotient truncates
         // to floor or floor + 1) and corrected once — an integer divide is ~40 instructions on the GPU.
         const uint32_t cd = fast ? c : 1u;
         const uint32_t x = fast ? lim - m : 0u;
         uint32_t q = (uint32_t)((float)x / (float)cd);
-        q -= ((uint64_t)q * cd > x) ? 1u : 0u;
-        const uint64_t jmax = (uint64_t)q + 1u;
-        const uint64_t n = fast ? (jmax < (uint64_t)j ? jmax : (uint64_t)j) : 1u;
-        const uint32_t m2 = m + (uint32_t)n * cd;                  // <= 2^24
+        q -= (q * cd > x) ? 1u : 0u;                               // (q cd <= x + cd < 2^25)
+        const uint32_t jmax = q + 1u;                              // <= 2^24
+        const uint32_t jc = j > (int64_t)0x40000000 ? 0x40000000u : (uint32_t)j;
+        const uint32_t n = fast ? (jmax < jc ? jmax : jc) : 1u;
+        const uint32_t m2 = m + n * cd;                            // <= 2^24
         const float tf = (m2 >> 24) ? nfa_u2f((uint32_t)(e + 1) << 23) : nfa_u2f(((uint32_t)e << 23) | (m2 & 0x7fffffu));
-        t = fast ? tf : nt;
-        j -= (int64_t)n;
-        // A jump that stopped at the binade's edge is followed by a real add (the crossing): take it here instead of paying
+        const float t1 = fast ? tf : nt;
+        const int64_t j1 = j - (int64_t)n;
+        // A jump that stopped at the binade's edge is followed by a real add (the crossing): taken here instead of paying
         // another trip's bookkeeping for it — the usual walk is then ONE trip per binade instead of two.
-        if (fast && n == jmax && j > 0) {
-            const float t2 = t + d;
-            if (t2 == t) break;
-            t = t2;
-            --j;
+        const bool cross = fast && n == jmax && j1 > 0;
+        const float t2 = t1 + d;
+        const bool stuck2 = cross && t2 == t1;
+        const bool crossed = cross && !stuck2;
+        if (!stuck) {
+            t = crossed ? t2 : t1;
+            j = j1 - (crossed ? 1 : 0);
         }
+        live = !stuck && !stuck2 && j > 0;
     }
     if (taken) *taken = j0 - j;
     return t;

@@ -19,15 +19,17 @@ enum Option : int {
     OPT_CONE,            // 0: the general lane-per-ray kernel for cone_angle != 0
     OPT_SPLIT_L2,        // 16 lanes per ray: grid image in LDS (0) / read from L2 (1)
     OPT_COUNT_L2,        // lane-per-ray count and fill kernels: image in LDS (0) / from L2 (1)
-    OPT_EMIT,            // emit pass: 1 = rays (16 lanes per ray), 2 = samples (a lane per sample)
+    OPT_EMIT,            // emit pass: 1 = rays (16 lanes per ray), 2 = samples (a lane per sample), 3 = tiles (a wave expands a block of rays)
     OPT_SCAN_RW,         // packed scan: rows per wave 4 | 16
     OPT_SPLIT_BLK,       // workgroup size of the 16-lane count pass: 256 | 512
     OPT_SPLIT_XT,        // 0: no crossing-time arrays in the 512-thread form
     OPT_SEGMENTS,        // 0: several levels take the lane-per-ray count pass
-    OPT_SPLIT_CAP,       // grids read from L2: entries of a part's boundary list, 16 | 32 (16: 8 and 16 lanes per ray only)
+    OPT_SPLIT_CAP,       // grids read from L2: entries of a part's boundary list, 16 | 24 | 32 (16 / 24: 8 and 16 lanes per ray only)
     OPT_EMIT_RB,         // tile form of the emit pass: log2 of the rays a wave takes (0 ... 6)
     OPT_CHUNK_PREFETCH,  // 0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call
     OPT_SPECULATIVE_EMIT,// 0: the extension's sample_occgrid launches the emit pass after the read-back
+    OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps with the brick distances
+                         // read from L2, 2 = with the distances staged in LDS
     OPT_COUNT
 };
 

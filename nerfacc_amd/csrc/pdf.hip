@@ -78,6 +78,54 @@ __device__ __forceinline__ int64_t chunk_of(const int64_t *__restrict__ starts, 
     return lo - 1;
 }
 
+// importance_sampling with a PER-RAY number of intervals (nerfacc.cpp:100-105, pdf.cu:294-357: the overload whose reference
+// implementation sizes its outputs with memalloc_data's missing argument and so allocates nothing).  Semantics as the reference's
+// two kernels state them for flattened outputs (pdf.cu:112-116, 207-239): ray r gets n_r samples at sm_starts[r] .. and, when n_r > 0,
+// n_r + 1 interval edges at iv_starts[r] .. flagged is_left (all but the last) / is_right (all but the first); a ray with n_r = 0
+// gets nothing.  One lane per output sample; the per-sample arithmetic is draw_sample / the edge rule of the batched kernel above, so
+// a ray's values equal the batched call's with n_intervals = n_r bit for bit.  n_r = 1 writes both edges (the reference reads the
+// next ray's first sample there: pdf.cu:211 "FIXME: out of bounds?").
+__global__ __launch_bounds__(kBlock) void importance_sampling_ragged_kernel(
+    nfa_ray_segments seg, const float *__restrict__ cdfs, const int64_t *__restrict__ sm_starts, const int64_t *__restrict__ sm_cnts,
+    const int64_t *__restrict__ iv_starts, int64_t n_samples, const float *__restrict__ jitter,
+    float *__restrict__ sm_vals, int64_t *__restrict__ sm_ray_indices, float *__restrict__ iv_vals, int64_t *__restrict__ iv_ray_indices,
+    uint8_t *__restrict__ iv_is_left, uint8_t *__restrict__ iv_is_right)
+{
+    for (int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x; tid < n_samples; tid += (int64_t)gridDim.x * kBlock) {
+        const int64_t ray = chunk_of(sm_starts, seg.n_rays, tid);        // (rays without samples share their start with the next ray: the
+        const int64_t n_out = sm_cnts[ray], sid = tid - sm_starts[ray];  //  LAST chunk that starts at or before tid is the one that owns it)
+        int64_t base, last;
+        ray_span(seg, ray, base, last);
+        const int64_t e0 = iv_starts[ray];
+        auto edge = [&](int64_t k, float v, bool left, bool right) {
+            iv_vals[e0 + k] = v;
+            if (iv_ray_indices) iv_ray_indices[e0 + k] = ray;
+            if (iv_is_left) iv_is_left[e0 + k] = left ? 1 : 0;
+            if (iv_is_right) iv_is_right[e0 + k] = right ? 1 : 0;
+        };
+        if (sm_ray_indices) sm_ray_indices[tid] = ray;
+        if (last < base) {                       // a ray without edges: nothing to invert
+            sm_vals[tid] = 0.0f;
+            edge(sid, 0.0f, true, sid > 0);
+            if (sid == n_out - 1) edge(n_out, 0.0f, false, true);
+            continue;
+        }
+        const float bias = jitter ? jitter[ray] : 0.5f;
+        const float t = draw_sample(seg.vals, cdfs, base, last, sid, n_out, bias);
+        sm_vals[tid] = t;
+        const float tmin = seg.vals[base], tmax = seg.vals[last];
+        if (sid == 0) {
+            const float t_next = (n_out > 1) ? draw_sample(seg.vals, cdfs, base, last, 1, n_out, bias) : t;
+            edge(0, fmaxf(t - (t_next - t) * 0.5f, tmin), true, false);
+            if (n_out == 1) edge(1, fminf(t, tmax), false, true);
+        } else {
+            const float t_prev = draw_sample(seg.vals, cdfs, base, last, sid - 1, n_out, bias);
+            edge(sid, (t + t_prev) * 0.5f, true, true);
+            if (sid == n_out - 1) edge(sid + 1, fminf(t + (t - t_prev) * 0.5f, tmax), false, true);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void searchsorted_kernel(
     nfa_ray_segments query, nfa_ray_segments key, int64_t *__restrict__ ids_left, int64_t *__restrict__ ids_right)
 {
@@ -318,6 +366,20 @@ NFA_EXPORT int nfa_importance_sampling(const nfa_ray_segments *segments, const f
     hipLaunchKernelGGL(importance_sampling_kernel, dim3(blocks_for(segments->n_rays * n_intervals)), dim3(kBlock), 0,
                        (hipStream_t)stream, *segments, cdfs, n_intervals, jitter, out_edges, out_mids);
     return check_launch("importance_sampling_kernel");
+}
+
+NFA_EXPORT int nfa_importance_sampling_ragged(const nfa_ray_segments *segments, const float *cdfs, const int64_t *sm_starts,
+                                              const int64_t *sm_cnts, const int64_t *iv_starts, int64_t n_samples, const float *jitter,
+                                              float *sm_vals, int64_t *sm_ray_indices, float *iv_vals, int64_t *iv_ray_indices,
+                                              uint8_t *iv_is_left, uint8_t *iv_is_right, void *stream)
+{
+    if (int rc = check_segments(segments, "importance_sampling_ragged")) return rc;
+    NFA_REQUIRE(n_samples >= 0, "importance_sampling_ragged: n_samples < 0");
+    if (segments->n_rays == 0 || n_samples == 0) return NFA_OK;
+    NFA_REQUIRE(cdfs && sm_starts && sm_cnts && iv_starts && sm_vals && iv_vals, "importance_sampling_ragged: NULL pointer");
+    hipLaunchKernelGGL(importance_sampling_ragged_kernel, dim3(blocks_for(n_samples)), dim3(kBlock), 0, (hipStream_t)stream, *segments, cdfs,
+                       sm_starts, sm_cnts, iv_starts, n_samples, jitter, sm_vals, sm_ray_indices, iv_vals, iv_ray_indices, iv_is_left, iv_is_right);
+    return check_launch("importance_sampling_ragged_kernel");
 }
 
 NFA_EXPORT int nfa_searchsorted(const nfa_ray_segments *query, const nfa_ray_segments *key,

@@ -243,6 +243,11 @@ __device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int gr
 // XT: the plane-crossing times of the ray's three axes are written out in LDS (lanes 1..3 of the ray walk the x / y / z chains
 // with plain adds — exact by construction — n + 1 values each); the walk's end times and every part's seam restart are then
 // reads and two binary searches instead of closed forms (512-thread form only: the arrays need 1.5 KB per ray).
+#ifdef NFA_NO_LATE_STAGE                       // A/B builds: the image staged before anything else, as in rounds 2-4
+constexpr bool kNoLateStage = true;
+#else
+constexpr bool kNoLateStage = false;
+#endif
 template <bool LDS_OCC, int P, int CAP, int BLK = kBlock, bool XT = false>
 __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
                                                                    int64_t *__restrict__ block_sums, RunStore rs)
@@ -258,7 +263,17 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     const float o[3] = {a.rays_o[3 * rr], a.rays_o[3 * rr + 1], a.rays_o[3 * rr + 2]};
     const float d[3] = {a.rays_d[3 * rr], a.rays_d[3 * rr + 1], a.rays_d[3 * rr + 2]};
     const float near = ray_near(a, rr), far = ray_far(a, rr);
-    const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    // crossing-time form with the image in LDS: the image's words are only REQUESTED here and written to LDS behind the closed-form
+    // call below (stage_issue / stage_commit, grid.hip) — everything up to the seam restart works on the ray alone
+    constexpr bool kLateStage = XT && LDS_OCC && !kNoLateStage;
+    StagePending sp;
+    Occ<LDS_OCC> occ;
+    if constexpr (kLateStage) {
+        occ = stage_layout(gv, smem);
+        stage_issue<BLK>(gv, sp);
+    } else {
+        occ = stage_occupancy<LDS_OCC>(gv, smem);
+    }
     NFA_PHASE_MARK(0);
     float *ev_lds = (float *)(smem + occ.bytes);        // [CAP][BLK] times, then [CAP][BLK] indices
     const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
             adv_t = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
             adv_d = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
             int n = ax == 0 ? nx : (ax == 1 ? ny : nz);
-            const int cap_n = gv.res[ax];
+            const int cap_n = ax == 0 ? gv.res[0] : (ax == 1 ? gv.res[1] : gv.res[2]);     // (gv.res[ax] is a memory load from the kernel arguments + a wait for EVERYTHING in flight)
             n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
             const int L = (n + 1 + 4) / 5;
             i_lo = k * L;
@@ -386,6 +401,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
         Ty = nfa_lattice_advance(s.ty, s.dy, ny - 1, nullptr);
         Tz = nfa_lattice_advance(s.tz, s.dz, nz - 1, nullptr);
     }
+    if constexpr (kLateStage) stage_commit<BLK>(gv, occ, sp);
     int end_rank = 2; float T_end = Tx;                                   // ranks: z 0, y 1, x 2
     if (crossing_precedes(Ty, 1, T_end, end_rank)) { T_end = Ty; end_rank = 1; }
     if (crossing_precedes(Tz, 0, T_end, end_rank)) { T_end = Tz; end_rank = 0; }

@@ -788,12 +788,42 @@ Tensor prod_bwd(const OptTensor &indices, const OptTensor &chunk_starts, const O
 // pdf (nerfacc.cpp:100-117)
 // ---------------------------------------------------------------------------------------------------
 std::vector<RaySegmentsSpec> importance_sampling(const RaySegmentsSpec &seg, const Tensor &cdfs, const py::object &n_intervals, bool stratified) {
-    if (!py::isinstance<py::int_>(n_intervals))
-        raise_not_implemented("importance_sampling with a per-ray Tensor count is broken in the reference (pdf.cu:324 allocates 0 "
-                              "elements) and is not provided; pass an int.");
     seg.check();
     check_input(cdfs, "cdfs", at::kFloat);
     TORCH_CHECK(cdfs.numel() == seg.vals->numel(), "cdfs and ray_segments.vals must have the same number of elements");
+    if (!py::isinstance<py::int_>(n_intervals)) {
+        // per-ray counts (nerfacc.cpp:100-105): flattened outputs sized from the counts — one host read of their sum, as the
+        // reference's memalloc_data_from_chunk does (data_spec.hpp:86-97)
+        Tensor cnts = n_intervals.cast<Tensor>();
+        TORCH_CHECK(cnts.is_cuda() && cnts.device() == cdfs.device(), "n_intervals_per_ray must live on the device of cdfs");
+        nfa_ray_segments view = seg.view();
+        cnts = cnts.to(at::kLong).reshape({-1}).contiguous();
+        TORCH_CHECK(cnts.numel() == view.n_rays, "n_intervals_per_ray must hold one count per ray (", view.n_rays, "), got ", cnts.numel());
+        TORCH_CHECK(cnts.numel() == 0 || cnts.min().item<int64_t>() >= 0, "n_intervals_per_ray must not be negative");
+        RaySegmentsSpec samples, intervals;
+        samples.chunk_cnts = cnts;
+        Tensor cs = at::cumsum(cnts, 0);
+        samples.chunk_starts = cs - cnts;
+        intervals.chunk_cnts = (cnts + 1) * (cnts > 0).to(at::kLong);
+        Tensor ics = at::cumsum(*intervals.chunk_cnts, 0);
+        intervals.chunk_starts = ics - *intervals.chunk_cnts;
+        const int64_t n_s = cnts.numel() ? cs[-1].item<int64_t>() : 0, n_e = cnts.numel() ? ics[-1].item<int64_t>() : 0;
+        const auto i64 = opts(cdfs, at::kLong), b8 = opts(cdfs, at::kBool);
+        samples.vals = at::empty({n_s}, cdfs.options());
+        samples.ray_indices = at::empty({n_s}, i64);
+        intervals.vals = at::empty({n_e}, cdfs.options());
+        intervals.ray_indices = at::empty({n_e}, i64);
+        intervals.is_left = at::empty({n_e}, b8);
+        intervals.is_right = at::empty({n_e}, b8);
+        Tensor jitter;
+        if (stratified) jitter = at::rand({view.n_rays}, cdfs.options());
+        Guard g(device_of(cdfs));
+        check_rc(nfa_importance_sampling_ragged(&view, ptr<float>(cdfs), ptr<int64_t>(samples.chunk_starts), ptr<int64_t>(cnts),
+                                                ptr<int64_t>(intervals.chunk_starts), n_s, ptr<float>(jitter), ptr<float>(samples.vals),
+                                                ptr<int64_t>(samples.ray_indices), ptr<float>(intervals.vals), ptr<int64_t>(intervals.ray_indices),
+                                                (uint8_t *)intervals.is_left->data_ptr(), (uint8_t *)intervals.is_right->data_ptr(), stream_of(cdfs)));
+        return {intervals, samples};
+    }
     const int64_t n = n_intervals.cast<int64_t>();
     nfa_ray_segments view = seg.view();
     std::vector<int64_t> lead;

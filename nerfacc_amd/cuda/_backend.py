@@ -100,6 +100,8 @@ def load_library() -> ctypes.CDLL:
             )
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get("NERFACC_AMD_LIB") and not hasattr(lib, name):
+                continue             # an explicitly named variant build (A/B against an older source tree) may predate an entry point
             fn = getattr(lib, name)  # AttributeError => the header and the library disagree
             fn.restype = res
             fn.argtypes = args
@@ -570,16 +572,43 @@ class _CtypesC:
     # ---------------------------------------------------------------- pdf
     @staticmethod
     def importance_sampling(ray_segments: _PyRaySegmentsSpec, cdfs, n_intervels_per_ray, stratified: bool):
-        """nerfacc.cpp:100-112.  Only the int overload exists here: the Tensor-count overload
-        of the reference allocates zero elements (pdf.cu:324) and cannot have callers."""
-        if isinstance(n_intervels_per_ray, torch.Tensor):
-            raise NotImplementedError(
-                "importance_sampling with a per-ray Tensor count is broken in the reference "
-                "(pdf.cu:324 allocates 0 elements) and is not provided; pass an int.")
+        """nerfacc.cpp:100-112: an int (batched outputs) or a per-ray Tensor of counts (flattened outputs; the reference's own
+        implementation of that overload allocates zero elements, pdf.cu:324 — this one follows what its kernels state)."""
         ray_segments.check()
         _check_input(cdfs, "cdfs", torch.float32)
         if cdfs.numel() != ray_segments.vals.numel():
             raise RuntimeError("cdfs and ray_segments.vals must have the same number of elements")
+        if isinstance(n_intervels_per_ray, torch.Tensor):
+            view = ray_segments._view()
+            cnts = n_intervels_per_ray.to(torch.int64).reshape(-1).contiguous()
+            if cnts.device != cdfs.device or not cnts.is_cuda:
+                raise RuntimeError("n_intervals_per_ray must live on the device of cdfs")
+            if cnts.numel() != int(view.n_rays):
+                raise RuntimeError(f"n_intervals_per_ray must hold one count per ray ({int(view.n_rays)}), got {cnts.numel()}")
+            if cnts.numel() and int(cnts.min()) < 0:
+                raise RuntimeError("n_intervals_per_ray must not be negative")
+            dev = cdfs.device
+            samples, intervals = _PyRaySegmentsSpec(), _PyRaySegmentsSpec()
+            samples.chunk_cnts = cnts
+            cs = torch.cumsum(cnts, 0)
+            samples.chunk_starts = cs - cnts
+            intervals.chunk_cnts = (cnts + 1) * (cnts > 0).to(torch.int64)
+            ics = torch.cumsum(intervals.chunk_cnts, 0)
+            intervals.chunk_starts = ics - intervals.chunk_cnts
+            n_s, n_e = (int(cs[-1]), int(ics[-1])) if cnts.numel() else (0, 0)
+            samples.vals = torch.empty(n_s, dtype=torch.float32, device=dev)
+            samples.ray_indices = torch.empty(n_s, dtype=torch.int64, device=dev)
+            intervals.vals = torch.empty(n_e, dtype=torch.float32, device=dev)
+            intervals.ray_indices = torch.empty(n_e, dtype=torch.int64, device=dev)
+            intervals.is_left = torch.empty(n_e, dtype=torch.bool, device=dev)
+            intervals.is_right = torch.empty(n_e, dtype=torch.bool, device=dev)
+            jitter = torch.rand(int(view.n_rays), dtype=torch.float32, device=dev) if stratified else None
+            with _Guard(cdfs):
+                _check(load_library().nfa_importance_sampling_ragged(
+                    ctypes.byref(view), _ptr(cdfs), _ptr(samples.chunk_starts), _ptr(cnts), _ptr(intervals.chunk_starts), n_s, _ptr(jitter),
+                    _ptr(samples.vals), _ptr(samples.ray_indices), _ptr(intervals.vals), _ptr(intervals.ray_indices),
+                    _ptr(intervals.is_left), _ptr(intervals.is_right), _stream(cdfs)))
+            return [intervals, samples]
         n = int(n_intervels_per_ray)
         view = ray_segments._view()
         if ray_segments.vals.dim() > 1:

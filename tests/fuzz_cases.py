@@ -229,7 +229,10 @@ SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 # where the grid image is read from (single level, cone_angle = 0): LDS / L2 with 16 lanes per ray, L2 with 8, and the
 # lane-per-ray kernel from LDS / L2
 IMAGE_FORMS = ("NFA_SPLIT_L2=0,NFA_SPLIT_P=16", "NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_P=8", "NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_COUNT_L2=1,NFA_SPLIT_P=1",
-               "NFA_SPLIT_CAP=24,NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_CAP=24,NFA_SPLIT_P=8", "NFA_SPLIT_CAP=16,NFA_SPLIT_L2=1,NFA_SPLIT_P=16")      # (+ list capacities: grids read from L2)
+               "NFA_SPLIT_CAP=24,NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_CAP=24,NFA_SPLIT_P=8", "NFA_SPLIT_CAP=16,NFA_SPLIT_L2=1,NFA_SPLIT_P=16",      # (+ list capacities: grids read from L2)
+               # round 5: the lane-per-ray walk voxel by voxel / with empty-space macro steps, brick distances from L2 / in LDS
+               "NFA_SKIP=0,NFA_COUNT_L2=1,NFA_SPLIT_P=1", "NFA_SKIP=1,NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_SKIP=1,NFA_COUNT_L2=1,NFA_SPLIT_P=1",
+               "NFA_SKIP=2,NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_SKIP=2,NFA_COUNT_L2=1,NFA_SPLIT_P=1")
 EMIT_FORMS = ("rays", "samples", "tiles")     # NFA_EMIT: 16 lanes per ray walking its run records / a lane per sample with searches
 SEGMENT_FORMS = ("1", "0")
 SEG_P_FORMS = ("8", "32")        # NFA_SEG_P: one lane per level segment / four (parts), cone_angle = 0, up to 4 levels

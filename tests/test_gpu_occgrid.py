@@ -241,3 +241,38 @@ def test_update_cell_selection_without_nonzero_sync_matches_reference_compositio
         want.append(torch.cat([uniform, occupied], dim=0))
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 20, 28, 12), (1, 5, 7, 3), (3, 64, 64, 64)])
+def test_brick_distance_field(shape):
+    """round 5: the packed grid carries, per 4^3 brick, the Chebyshev distance (in bricks, within its level, capped at 4) to the nearest
+    non-empty brick — what the empty-space macro steps of the count pass size their jumps from (grid.hip: brick_dist_kernel).
+    Checked against scipy's chessboard distance transform of the brick bitmap."""
+    from scipy import ndimage
+
+    from nerfacc_amd.cuda import _backend
+
+    rng = np.random.default_rng(3)
+    G, rx, ry, rz = shape
+    occ = np.zeros(shape, bool)
+    for g in range(G):                                  # a few blobs and single voxels per level; level 1 of several stays empty
+        if G > 1 and g == 1:
+            continue
+        for _ in range(4):
+            c = rng.integers(0, [rx, ry, rz])
+            r = rng.integers(0, 3)
+            occ[g, max(c[0] - r, 0):c[0] + r + 1, max(c[1] - r, 0):c[1] + r + 1, max(c[2] - r, 0):c[2] + r + 1] = True
+    packed = _backend.packed_bricks(t(occ)).cpu().numpy()
+    nbx, nby, nbz = (rx + 3) // 4, (ry + 3) // 4, (rz + 3) // 4
+    nb = G * nbx * nby * nbz
+    nw = (nb + 31) // 32
+    off_dist = nb + 12 + 2 * ((nw + 1) // 2) + nb
+    nib = packed[off_dist:off_dist + (nb + 15) // 16].view(np.uint8)
+    dist = np.stack([nib & 15, nib >> 4], -1).reshape(-1)[:nb].reshape(G, nbx, nby, nbz)
+    pad = np.zeros((G, nbx * 4, nby * 4, nbz * 4), bool)
+    pad[:, :rx, :ry, :rz] = occ
+    nonempty = pad.reshape(G, nbx, 4, nby, 4, nbz, 4).any(axis=(2, 4, 6))
+    for g in range(G):
+        want = np.minimum(ndimage.distance_transform_cdt(~nonempty[g], metric="chessboard"), 4) if nonempty[g].any() else np.full((nbx, nby, nbz), 4)
+        assert np.array_equal(dist[g], want), (shape, g)

@@ -55,8 +55,59 @@ def test_importance_sampling_vs_twin_and_oracle(golden):
     iv3, s3 = importance_sampling(intervals, cdfs, 64, True)
     assert (s3.vals[:, 1:] >= s3.vals[:, :-1]).all()
     assert (iv3.vals >= intervals.vals.min(-1, keepdim=True)[0] - 1e-6).all()
-    with pytest.raises(NotImplementedError):
-        importance_sampling(intervals, cdfs, torch.full((5,), 10, device=DEV), False)
+
+
+@pytest.mark.parametrize("flattened_input", [False, True])
+def test_importance_sampling_per_ray_counts(flattened_input):
+    """round 5: the Tensor overload (nerfacc.cpp:100-105; the reference's own allocates nothing, pdf.cu:324).  Flattened outputs whose
+    rows equal the int call with that ray's count — bit for bit, it is the same arithmetic — and the reference's pure-torch twin
+    `_sample_from_weighted` (tests/test_pdf.py:65-94's tolerance); packed_info / ray_indices / flags as pdf.cu:112-116, 207-239 state;
+    rays with a count of 0 get nothing."""
+    from nerfacc_amd.data_specs import RayIntervals
+    from nerfacc_amd.pdf import _sample_from_weighted, importance_sampling
+
+    R, S = 37, 64
+    intervals = _intervals(R, S, 7)
+    cdfs = torch.sort(torch.rand_like(intervals.vals), -1)[0]
+    g = torch.Generator().manual_seed(3)
+    cnts = torch.randint(0, 40, (R,), generator=g)
+    cnts[[0, 5, 6, R - 1]] = 0                        # leading, adjacent and trailing rays without samples
+    cnts[[2, 9]] = 1
+    cnts_d = cnts.to(DEV)
+    src = intervals
+    if flattened_input:
+        pk = torch.stack([torch.arange(R, device=DEV) * (S + 1), torch.full((R,), S + 1, device=DEV)], -1)
+        src = RayIntervals(vals=intervals.vals.reshape(-1), packed_info=pk)
+    iv, sm = importance_sampling(src, cdfs.reshape(-1) if flattened_input else cdfs, cnts_d, False)
+    assert sm.vals.shape == (int(cnts.sum()),) and iv.vals.shape == (int((cnts + (cnts > 0)).sum()),)
+    assert torch.equal(sm.packed_info[:, 1].cpu(), cnts) and torch.equal(sm.packed_info[:, 0].cpu(), torch.cumsum(cnts, 0) - cnts)
+    ecnt = (cnts + 1) * (cnts > 0)
+    assert torch.equal(iv.packed_info[:, 1].cpu(), ecnt) and torch.equal(iv.packed_info[:, 0].cpu(), torch.cumsum(ecnt, 0) - ecnt)
+    assert torch.equal(sm.ray_indices.cpu(), torch.repeat_interleave(torch.arange(R), cnts))
+    assert torch.equal(iv.ray_indices.cpu(), torch.repeat_interleave(torch.arange(R), ecnt))
+    for r in range(R):
+        k = int(cnts[r])
+        s0, e0 = int(sm.packed_info[r, 0]), int(iv.packed_info[r, 0])
+        if k == 0:
+            continue
+        b_iv, b_sm = importance_sampling(RayIntervals(vals=intervals.vals[r:r + 1]), cdfs[r:r + 1], k, False)
+        assert torch.equal(sm.vals[s0:s0 + k], b_sm.vals[0]) and torch.equal(iv.vals[e0:e0 + k + 1], b_iv.vals[0]), r
+        fl, fr = iv.is_left[e0:e0 + k + 1], iv.is_right[e0:e0 + k + 1]
+        assert fl[:-1].all() and not fl[-1] and fr[1:].all() and not fr[0]
+        if k > 1:
+            e, m = _sample_from_weighted(intervals.vals[r:r + 1], cdfs[r:r + 1, 1:] - cdfs[r:r + 1, :-1], k, False,
+                                         intervals.vals[r].min(), intervals.vals[r].max())
+            assert torch.allclose(iv.vals[e0:e0 + k + 1], e[0], atol=1e-4) and torch.allclose(sm.vals[s0:s0 + k], m[0], atol=1e-4)
+        re, rm = oracle.importance_sampling(n(intervals.vals[r:r + 1]), n(cdfs[r:r + 1]), k)
+        np.testing.assert_allclose(n(iv.vals[e0:e0 + k + 1]), re[0], atol=1e-6)
+        np.testing.assert_allclose(n(sm.vals[s0:s0 + k]), rm[0], atol=1e-6)
+    # stratified, all rays empty, wrong sizes
+    iv2, sm2 = importance_sampling(src, cdfs.reshape(-1) if flattened_input else cdfs, cnts_d, True)
+    assert sm2.vals.shape == sm.vals.shape and torch.isfinite(sm2.vals).all()
+    iv3, sm3 = importance_sampling(src, cdfs.reshape(-1) if flattened_input else cdfs, torch.zeros(R, dtype=torch.long, device=DEV), False)
+    assert sm3.vals.numel() == 0 and iv3.vals.numel() == 0
+    with pytest.raises(RuntimeError):
+        importance_sampling(src, cdfs.reshape(-1) if flattened_input else cdfs, cnts_d[:-1], False)
 
 
 def test_flattened_docstring_examples():

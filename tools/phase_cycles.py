@@ -14,7 +14,9 @@ extra = os.environ.get("NFA_PHASE_EXTRA", "").split()          # further -D flag
 so = os.path.join(out_dir, "libnerfacc_hip_prof" + "".join(c if c.isalnum() else "_" for c in "".join(extra)) + ".so")
 srcs = sorted(glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hip")))
 hdrs = glob.glob(os.path.join(ROOT, "nerfacc_amd", "csrc", "*.hpp")) + [os.path.join(ROOT, "include", "nerfacc_hip.h")]
-if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs + hdrs):
+if os.environ.get("NFA_PHASE_LIB"):                 # a prebuilt instrumented library (A/B against another source tree)
+    so = os.path.abspath(os.environ["NFA_PHASE_LIB"])
+elif not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs + hdrs):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                            "-fvisibility=hidden", "-DNFA_PHASE_CYCLES", *extra, "-shared", *srcs, "-o", so])
 if "--build-only" in sys.argv:
