@@ -661,6 +661,8 @@ def main():
                     help="initialise the process group (and use ExchangeAdam's exchange) even with one rank: the RCCL world-1 smoke test")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (configs[4] 256^3 grid, configs[2] PropNet step)")
     ap.add_argument("--aux-steps", type=int, default=40, help="timed steps of each auxiliary leg")
+    ap.add_argument("--no-rank-step", action="store_true", help="skip aux.configs3_rank_step (configs[3]'s per-rank step over RCCL world-of-one)")
+    ap.add_argument("--rank-step-pretrain", type=int, default=150, help="training steps from fog of the multi-tensor field of aux.configs3_rank_step")
     ap.add_argument("--no-scene-sweep", action="store_true", help="skip aux.configs4_scene_sweep (eight procedural scenes at 256^3)")
     ap.add_argument("--scene-pretrain", type=int, default=1000, help="training steps from fog of every scene of aux.configs4_scene_sweep")
     ap.add_argument("--dump-sampling-state", default="",
@@ -919,9 +921,14 @@ def main():
             optimizer.timing = False
             exchange_modes[alt] = {"ms_per_step": r["elapsed"] / args.aux_steps * 1e3, "comm_ms_per_step": c["wait_ms"],
                                    "comm_window_ms_per_step": c["window_ms"], "steps": args.aux_steps}
-            optimizer.set_mode(args.exchange_mode)
         except Exception as e:      # noqa: BLE001
             exchange_modes[alt] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            optimizer.timing = False
+            try:
+                optimizer.set_mode(args.exchange_mode)       # (the headline's mode again, also after an error: ADVICE r4)
+            except Exception:      # noqa: BLE001
+                pass
         state.pop("proposal", None)
 
     other = None
@@ -975,11 +982,73 @@ def main():
         if not args.no_scene_sweep:
             aux["configs4_scene_sweep"] = scene_sweep_leg(pool_o, pool_d, bkgd, args.aux_steps, min(args.warmup, 10), pretrain=args.scene_pretrain)
 
+    # ---- aux.configs3_rank_step: what ONE rank of configs[3] does per step — 8192 fixed rays (65536 / 8) and the
+    # gradient exchange of ExchangeAdam over RCCL with a world of one (the collectives are real RCCL calls; with one rank they move
+    # nothing, so the times are the exchange's fixed cost and, more to the point, the WINDOW the step leaves for hiding it), in both
+    # exchange modes, with the headline's single-tensor field and with a multi-tensor one (feature grid + MLP: chunks leave from
+    # inside backward).  The 8-rank figures are a link-model projection, labelled as such — no node has been available.
+    rank_step = None
+    if not args.no_aux and world_size == 1 and not exchanging and args.field == "grid" and not args.no_rank_step:
+        rank_step = {"workload": "configs[3] per-rank share: the configs[1] step at 8192 fixed rays with ExchangeAdam over RCCL (world of one), "
+                                 "chunks launched from inside backward (overlap_backward)", "fields": {}}
+        saved = (field, optimizer, exchanging, fixed_rays, state["num_rays"], state["est"], state["step"])
+        try:
+            import copy
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
+            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
+            exchanging, fixed_rays = True, 8192
+            for kind in ("grid", "grid+mlp"):
+                field = copy.deepcopy(saved[0]) if kind == "grid" else GridMlpField(AABB).to(device)
+                est_k = saved[5]
+                if kind != "grid":                               # its own occupancy grid, trained from fog for a moment
+                    est_k = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=args.occ_res, levels=1).to(device)
+                    est_k.train()
+                state["est"], state["num_rays"], state["step"] = est_k, 8192, 0 if kind != "grid" else saved[6]
+                res_k = {"parameters": int(sum(p.numel() for p in field.parameters())), "tensors": len(list(field.parameters()))}
+                optimizer = sharding.ExchangeAdam(field.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, n_chunks=args.grad_chunks,
+                                                  overlap_backward=True, mode="allreduce")
+                for mode in ("allreduce", "rs_ag"):
+                    optimizer.set_mode(mode)
+                    for _ in range(args.rank_step_pretrain if (kind != "grid" and mode == "allreduce") else 5):
+                        step_api()
+                    state["step"] += (-state["step"]) % 16 + 1
+                    optimizer.timing = True
+                    r = timed_region(step_api, args.aux_steps, with_timer=False)
+                    c = optimizer.comm_stats()
+                    optimizer.timing = False
+                    t_step = r["elapsed"] / args.aux_steps * 1e3
+                    # link model (the brief's figures: 7 xGMI links x ~153 GB/s per GPU, ring collectives per-link bound): a ring
+                    # all-reduce moves 2 (N - 1) / N of the buffer per rank; one ring = one link, RCCL may run up to seven in parallel
+                    B, N = float(c["exchange_bytes"]), 8
+                    t_one = 2.0 * (N - 1) / N * B / 153e9 * 1e3
+                    t_seven = t_one / (7 * 0.7)
+                    budget = max(c["window_ms"] - c["wait_ms"], 0.0)             # compute between the first chunk's launch and the last one's use
+                    exposed = [max(t_seven - budget, 0.0), max(t_one - budget, 0.0)]
+                    res_k[mode] = {"ms_per_step": t_step, "rays_per_sec": r["rays"] / r["elapsed"], "samples_per_ray": r["samples"] / max(r["rays"], 1),
+                                   "comm_ms_per_step": c["wait_ms"], "comm_window_ms_per_step": c["window_ms"], "exchange_bytes": c["exchange_bytes"],
+                                   "projected_8_ranks": {"ring_allreduce_ms": {"seven_rings_70pct": t_seven, "one_ring": t_one},
+                                                         "overlap_budget_ms": budget, "exposed_ms": exposed,
+                                                         "weak_scaling_efficiency": [t_step / (t_step + e) for e in exposed],
+                                                         "note": "model, not a measurement: exposed = ring time - the compute window this step leaves between "
+                                                                 "launching its first chunk and needing its last"}}
+                optimizer.close()
+                rank_step["fields"][kind] = res_k
+        except Exception as e:      # noqa: BLE001  (an auxiliary leg must never cost the headline its line)
+            rank_step["error"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            field, optimizer, exchanging, fixed_rays = saved[:4]
+            state["num_rays"], state["est"], state["step"] = saved[4:]
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
     if rank == 0:
         elapsed = main_run["elapsed"]
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel of OUR path (profiles/): the sampling traversal — count pass
-        # (traverse_count_split_kernel at this ray count) + emit pass (traverse_emit_kernel), one launch each per
+        # (traverse_count_split_kernel at this ray count) + emit pass (traverse_emit_tiles_kernel), one launch each per
         # step, timed live with HIP events on the launch stream around their single-kernel C-ABI calls.
         # Algorithmic bytes: 16 B per emitted candidate sample (ray_indices i64 + t_starts + t_ends)
         # + 48 B per ray + the grid once, G*V bool bytes as the API hands it over.
@@ -1000,7 +1069,7 @@ def main():
         alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {
-            "kernel": "traverse_count_split_kernel + traverse_emit_kernel (the sampling traversal)",
+            "kernel": "traverse_count_split_kernel + traverse_emit_tiles_kernel (the sampling traversal)",
             "bound": "issue/latency", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_source": None,
             "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
@@ -1075,6 +1144,22 @@ def main():
             out["exchange_bytes"] = comm["exchange_bytes"]
             out["comm_note"] = ("comm_ms_per_step = time the compute stream stood still waiting for gradient chunks (exposed exchange), "
                                 "comm_window = first all-reduce launch (inside backward) to last chunk's arrival; rank 0's events")
+        if rank_step is not None:
+            out.setdefault("aux", {})["configs3_rank_step"] = rank_step
+        if prof is not None and "error" not in prof:
+            # the PATH's own fraction at this size: algorithmic bytes of every nfa:: kernel of a step
+            # (sampling 16 c + 48 R + the bool grid; filter 21 c + 16 N; rendering forward 44 N + 20 R, backward 60 N + 20 R;
+            # c = candidate samples, N = rendered samples, R = rays) over their summed kernel time from the profiled pass
+            n_s = main_run["local_samples"] / max(args.steps, 1)
+            path_bytes = (16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)) + (21.0 * cand + 16.0 * n_s) \
+                + (44.0 * n_s + 20.0 * rays_per_launch) + (60.0 * n_s + 20.0 * rays_per_launch)
+            path_gbs = path_bytes / (prof["nfa_us_per_step"] * 1e-6) / 1e9 if prof["nfa_us_per_step"] > 0 else 0.0
+            roof["path"] = {"kernels": "every nfa:: kernel of a step (sampling, visibility filter, rendering forward + backward)",
+                            "us_per_step": prof["nfa_us_per_step"], "launches_per_step": prof["nfa_kernels_per_step"],
+                            "algorithmic_bytes_per_step": path_bytes, "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": path_gbs / HBM_PEAK_GBS,
+                            "path_only_loop_ms_per_step": (path_only["elapsed"] / args.steps * 1e3) if path_only is not None else None,
+                            "note": "latency-bound at this size: ~9 launches of 5-30 us each; the same kernels reach 0.35-0.7 of 8 TB/s at N = 2^24 (profiles/)"}
         if prof is not None:
             if "error" in prof:
                 out["gpu_activity"] = prof

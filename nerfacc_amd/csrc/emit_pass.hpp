@@ -318,7 +318,7 @@ __device__ __forceinline__ int wave_seg_incl_scan_i32(int v, int dist) {
 // and 2 rays per wave 194 (profiles/r04_emit.md).  The call's runs = edges - samples are in the workspace when this kernel starts
 // (the offsets kernel's totals), so the block is halved until it holds at most kEmitRunsPerBlock runs on average — never below
 // `rb_min` (the grid was sized for that many blocks).
-constexpr int64_t kEmitRunsPerBlock = 160;
+constexpr int64_t kEmitRunsPerBlock = 192;
 __device__ __forceinline__ int emit_rays_per_wave_log2(int rb_log2, int rb_min, int64_t n_rays, const int64_t *__restrict__ n_dev) {
     if (rb_min >= rb_log2) return rb_log2;
     const int64_t runs = n_dev[0] - n_dev[1];

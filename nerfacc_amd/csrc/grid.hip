@@ -351,6 +351,7 @@ struct GridView {
     const uint8_t *__restrict__ dist;   // one nibble per brick: distance to the nearest non-empty brick (brick_dist_kernel)
     int lds_dist_off;     // byte offset of the staged distances in the kernel's dynamic LDS, -1 = read from L2
     int lds_dist_bytes;
+    int skip_auto;        // 1: a wave takes the empty-space macro steps only when its 64 rays are coherent (wave_rays_coherent)
 };
 
 struct BrickCache {
@@ -1058,6 +1059,28 @@ __device__ __forceinline__ void publish_wave_sums(int64_t n_iv, int64_t n_sm, in
 }
 
 // pass 1.  Block b owns rays [256 b, 256 b + 256).
+// Are the rays of this wave (one per lane) a coherent bundle — neighbouring pixels of one camera?  Wave-uniform answer: every active
+// lane's direction within ~8 degrees of the first active lane's (normalised dot product > 0.99) and its origin within 5 % of the first
+// level's box of that lane's.  Random training rays practically never pass; rows of an image do.
+__device__ __forceinline__ bool wave_rays_coherent(const nfa_traverse_args &a, int64_t r, bool active) {
+    const unsigned long long am = __ballot(active);
+    if (am == 0ull) return false;
+    const int l0 = __ffsll((long long)am) - 1;
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
+    if (active) {
+        o[0] = a.rays_o[3 * r]; o[1] = a.rays_o[3 * r + 1]; o[2] = a.rays_o[3 * r + 2];
+        d[0] = a.rays_d[3 * r]; d[1] = a.rays_d[3 * r + 1]; d[2] = a.rays_d[3 * r + 2];
+    }
+    const float o0[3] = {__shfl(o[0], l0, 64), __shfl(o[1], l0, 64), __shfl(o[2], l0, 64)};
+    const float d0[3] = {__shfl(d[0], l0, 64), __shfl(d[1], l0, 64), __shfl(d[2], l0, 64)};
+    const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], d00 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2];
+    const float dot = d[0] * d0[0] + d[1] * d0[1] + d[2] * d0[2];
+    const float ext = fmaxf(a.aabbs[3] - a.aabbs[0], fmaxf(a.aabbs[4] - a.aabbs[1], a.aabbs[5] - a.aabbs[2]));
+    const float od = fmaxf(fabsf(o[0] - o0[0]), fmaxf(fabsf(o[1] - o0[1]), fabsf(o[2] - o0[2])));
+    const bool ok = dot > 0.0f && dot * dot > 0.9801f * dd * d00 && od <= 0.05f * ext;
+    return __ballot(active && !ok) == 0ull;
+}
+
 // SKIP (lattice form only): 0 = voxel by voxel, 1 = empty-space macro steps with the brick distances read from L2, 2 = with the
 // distances staged in LDS behind the boundary lists (gv.lds_dist_off)
 template <int EV, bool LATTICE, bool LDS_OCC, int SKIP = 0>
@@ -1073,7 +1096,13 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
     float t_term = 0.f;
     if (LATTICE && SKIP) {
         float *ev_lds = (float *)(smem + occ.bytes);
-        traverse_ray_lattice_skip<EV, LDS_OCC, SKIP == 2>(a, gv, occ, smem, ev_lds, r, active, sink, t_term);
+        // The macro steps pay off when the lanes of a wave change regime TOGETHER (pixel-ordered rays of a frame: 276 -> 189 us at
+        // 10^6 rays, 268 -> 167 for a round of the test-time marcher) and cost 17-30 % when they do not (a training batch: every
+        // regime change is paid at the slowest lane's length in both loops; profiles/r05_count_pass.md).  Which of the two a wave is
+        // can be read off its rays: same origin region, directions within a few degrees of lane 0's.
+        const bool use_skip = !gv.skip_auto || wave_rays_coherent(a, r, active);
+        if (use_skip) traverse_ray_lattice_skip<EV, LDS_OCC, SKIP == 2>(a, gv, occ, smem, ev_lds, r, active, sink, t_term);
+        else traverse_ray_lattice<EV, LDS_OCC>(a, gv, occ, ev_lds, r, active, sink, t_term);
     } else if (LATTICE) {
         // the boundary lists sit behind the occupancy image in LDS
         float *ev_lds = (float *)(smem + occ.bytes);
@@ -1322,6 +1351,7 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int
     gv.dist = (const uint8_t *)(a->bricks + L.off_dist);
     gv.lds_dist_off = -1;
     gv.lds_dist_bytes = 0;
+    gv.skip_auto = 0;
     gv.header = (const int64_t *)(a->bricks + L.off_header);
     gv.coarse = (const uint32_t *)(a->bricks + L.off_coarse);
     gv.prefix = (const uint32_t *)(a->bricks + L.off_prefix);
@@ -1802,7 +1832,14 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     if (lattice) {
         const int64_t dist_bytes = (((packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]).n_bricks + 1) / 2) + 15) & ~15ll;
         const bool fits = dist_bytes <= 16 * 1024 && lds + dist_bytes <= 80 * 1024;
-        skip = (int)opt(OPT_SKIP, fits ? 2 : 1);
+        (void)fits;
+        // Measured (profiles/r05_count_pass.md): on incoherent rays — training batches, the replay's tiled batch — the wave pays the
+        // longest far phase AND the longest near phase of its 64 lanes at every regime change and the macro steps lose: 10^6 rays
+        // 621 us voxel by voxel, 728 with the distances from L2, 828 from LDS (three workgroups per CU instead of five); on the
+        // pixel-ordered rays of a frame they win, 276 -> 189 (L2) / 208 (LDS).  So: unset = every WAVE decides from its rays
+        // (wave_rays_coherent), distances from L2; 0 = never; 1 / 2 = always, distances from L2 / LDS.
+        skip = (int)opt(OPT_SKIP, 1);
+        gv.skip_auto = opt_is_set(OPT_SKIP) ? 0 : 1;
         if (skip == 2 && !(dist_bytes + lds <= 80 * 1024)) skip = 1;
         if (skip == 2) {
             gv.lds_dist_off = lds;

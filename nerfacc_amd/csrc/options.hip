@@ -61,7 +61,7 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"emit_rb", "tile form of the emit pass: log2 of the rays per wave, 0 ... 6", parse_one_of<0, 1, 2, 3, 4, 5, 6>},
     {"chunk_prefetch", "0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call", parse_bool},
     {"speculative_emit", "0: sample_occgrid of the torch extension launches the emit pass after the read-back", parse_bool},
-    {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps, brick distances from L2, 2 = distances staged in LDS", parse_one_of<0, 1, 2>},
+    {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps, brick distances from L2, 2 = distances staged in LDS (unset: a wave takes the macro steps when its rays are coherent)", parse_one_of<0, 1, 2>},
 };
 
 int find_option(const char *name) {

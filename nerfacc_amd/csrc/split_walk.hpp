@@ -603,8 +603,10 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
                 const int64_t K = ev_K[j * BLK + tid];
                 const float T = ev_lds[j * BLK + tid];
                 if (((ev_occ >> j) & 1u) && K > K_prev) {
+#ifndef NFA_EXP_NO_RECORDS                         // (experiment builds: what do the scattered record stores cost?)
                     rs.t0[(int64_t)idx * R + r] = T_prev;
                     rs.first[(int64_t)idx * R + r] = (int32_t)first;
+#endif
                     first += K - K_prev;
                     ++idx;
                 }
@@ -651,6 +653,12 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
         out_iv = sink.n_iv;
         out_sm = sink.n_sm;
         if (a.terminate_planes) a.terminate_planes[r] = t_term;
+        // The serial walk's loads are waited for HERE, inside its branch.  The compiler's wait-count pass merges the branches' pending
+        // loads at the join below; with a load of this (never taken, in a training step) branch still "in flight" there, the main path
+        // got an s_waitcnt vmcnt(0) in front of its last stores — and on gfx9 vmcnt counts STORES too: every wave sat out the write
+        // latency of its run records before it could retire (6 k of the mean wave's 48 k cycles, 20 k in the waves with the most runs;
+        // profiles/r05_count_pass.md).  0x0F70 = vmcnt(0), the other counters untouched.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     if (ray_ok && part == 0) {
         if (a.iv_cnts) a.iv_cnts[r] = out_iv;

@@ -20,6 +20,8 @@ The occupancy grid stays identical on all ranks either by seeding its update ide
 from contextlib import contextmanager
 from typing import Iterable, List, Tuple
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -117,7 +119,7 @@ def allreduce_counts_end(pending: "_PendingCounts") -> Tuple[int, int]:
 # launches the same chunks later, from step(), so any collective issued in between would reach the process group in a
 # different order on different ranks — a hang or a size mismatch.  Collectives the caller issues through
 # torch.distributed directly cannot be checked: the rule is in ExchangeAdam's docstring.
-_OPEN_EXCHANGES: set = set()
+_OPEN_EXCHANGES = weakref.WeakSet()          # optimizers with an exchange in flight (a WeakSet: a collected optimizer cannot leave its id behind)
 
 
 def _require_no_open_exchange(what: str) -> None:
@@ -304,7 +306,7 @@ class ExchangeAdam:
         else:
             self._works[k] = dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
             self._log("all_reduce", k, b - a)
-        _OPEN_EXCHANGES.add(id(self))
+        _OPEN_EXCHANGES.add(self)
 
     def _launch_ready(self) -> None:
         while self._next >= 0 and self._have[self._next] >= self._need[self._next]:
@@ -337,6 +339,19 @@ class ExchangeAdam:
     def step(self) -> None:
         """finish the exchange (launch the chunks the backward pass did not, in the fixed order) and update every chunk
         as it arrives, in arrival (= launch) order"""
+        try:
+            self._step()
+        finally:
+            # whatever happened (a world-size assert, a failed collective, a replaced gradient): the exchange is over as far as the
+            # module's other collectives are concerned, and the next backward() starts from a clean slate (ADVICE r4)
+            self._first_launch = None
+            self._works = [None] * len(self.bounds)
+            self._have = [0] * len(self.bounds)
+            self._reported = [False] * len(self.params)
+            self._next = len(self.bounds) - 1
+            _OPEN_EXCHANGES.discard(self)
+
+    def _step(self) -> None:
         self.t += 1
         self.step_tensor += 1
         exchanging = self._exchanging()
@@ -396,7 +411,7 @@ class ExchangeAdam:
         self._have = [0] * len(self.bounds)
         self._reported = [False] * len(self.params)
         self._next = len(self.bounds) - 1
-        _OPEN_EXCHANGES.discard(id(self))
+        _OPEN_EXCHANGES.discard(self)
 
     def set_mode(self, mode: str) -> None:
         """switch between "allreduce" and "rs_ag" between steps (a COLLECTIVE when leaving rs_ag: the moments are gathered so
@@ -417,7 +432,7 @@ class ExchangeAdam:
             h.remove()
         self._hooks = []
         self.overlap_backward = False
-        _OPEN_EXCHANGES.discard(id(self))
+        _OPEN_EXCHANGES.discard(self)
 
     def comm_stats(self, reset: bool = True) -> dict:
         """per-step averages over the steps taken with `timing = True` (synchronises the device)"""

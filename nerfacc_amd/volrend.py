@@ -9,9 +9,11 @@ single HIP kernels with hand-written backward kernels (render.hip):
   rendering (rgb_sigma_fn)                                         -> 1 kernel fwd, 1 bwd
   accumulate_along_rays                                            -> 1 kernel fwd, 1 bwd
 
-Batched inputs ([n_rays, n_samples], no ray_indices) stay plain differentiable torch code,
-as in the reference.  The fused kernels give gradients for sigmas / rgbs / alphas / weights /
-values.  When t_starts, t_ends or prefix_trans require grad (the reference's expressions are
+Batched CUDA float32 inputs ([n_rays, n_samples], no ray_indices) are the flattened layout with a
+constant number of samples per ray and take the same fused kernels (round 3: `_dense_keys` caches
+their keys); anything else batched (other dtypes, CPU tensors for the reference's CPU-only tests,
+inputs whose t / prefix need gradients) is the reference's plain differentiable torch code.  The
+fused kernels give gradients for sigmas / rgbs / alphas / weights / values.  When t_starts, t_ends or prefix_trans require grad (the reference's expressions are
 differentiable w.r.t. them) the flattened paths switch to the same composition of
 differentiable ops as the reference (per-ray scans from scan.py + elementwise torch), so those
 gradients exist too — at the reference's cost instead of the fused kernels'.

@@ -43,7 +43,7 @@ def test_two_ranks_on_one_device(extra, launch):
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + bench_args
     else:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
-    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=_clean_env())
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints ONE line
@@ -64,7 +64,7 @@ def test_rccl_world_of_one():
     all-reduce (launched from the gradient hook inside backward) + fused per-chunk Adam, comm figures on the line"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "4",
            "--warmup", "2", "--windows", "1", "--pretrain", "40", "--pool", "65536", "--no-cpu-baseline", "--no-aux", "--no-profile"]
-    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=_clean_env())
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -103,7 +103,7 @@ for x, y in zip(a, b):
 dist.destroy_process_group()
 print("ok", st)
 ''' % (ROOT, str(_free_port()), mode)
-    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
                          env=_clean_env())
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 

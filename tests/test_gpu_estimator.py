@@ -238,3 +238,36 @@ def test_count_prefetch_inference_mode_and_reused_addresses(force_options):
     assert same(want2, loop(O2, D2))
     # (iii) the retained workspace released between two slices
     assert same(want2, loop(O2, D2, release_at=2))
+
+
+def test_pixel_ordered_frame_macro_steps_match_the_voxel_walk(force_options):
+    """round 5: beyond ~10^5 rays the count pass gives a ray a lane, and a WAVE whose rays are a coherent bundle (neighbouring pixels of
+    one camera) crosses empty space in macro steps sized by the brick distance field (grid.hip: wave_rays_coherent,
+    traverse_ray_lattice_skip).  A 400 x 400 frame: the automatic plan, both forced macro-step forms and the voxel walk give the same
+    samples, and those are the oracle's."""
+    import nerfacc_amd
+
+    H = W = 400
+    cam = np.array([0.3, 0.5, 3.6], np.float32)
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    d = np.stack([(ii - W / 2 + 0.5) / (1.1 * W), -(jj - H / 2 + 0.5) / (1.1 * H) - 0.1, -np.ones_like(ii)], -1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.ascontiguousarray(np.broadcast_to(cam, d.shape))
+    res = 128
+    g = (np.arange(res) + 0.5) / res * 3 - 1.5
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    occ = (((X**2 + Y**2 + Z**2) < 0.9) & ((X**2 + Y**2 + Z**2) > 0.5) | ((np.abs(X - 0.9) < 0.05) & (np.abs(Y) < 0.6)))[None]
+    est = nerfacc_amd.OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=res, levels=1).to(DEV)
+    est.binaries = t(occ)
+    O, D = t(o), t(d)
+    outs = {}
+    for tag, f in (("auto", {}), ("skip0", dict(skip=0)), ("skip1", dict(skip=1)), ("skip2", dict(skip=2)), ("lds", dict(count_l2=0)),
+                   ("lds skip1", dict(count_l2=0, skip=1))):
+        with nerfacc_amd.options(**f):
+            outs[tag] = est.sampling(O, D, render_step_size=5e-3)
+    for tag, got in outs.items():
+        assert all(torch.equal(a, b) for a, b in zip(outs["skip0"], got)), tag
+    ri, ts, te = outs["auto"]
+    r_ri, r_ts, r_te, _ = oracle.sampling(o, d, occ, np.array([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], np.float32), render_step_size=5e-3)
+    assert ri.shape[0] > 2_000_000
+    assert np.array_equal(n(ri), r_ri) and np.array_equal(n(ts), r_ts) and np.array_equal(n(te), r_te)

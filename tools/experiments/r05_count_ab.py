@@ -64,6 +64,35 @@ for n in ((6564, 13000, 50000, 200000, 1000000) if not quick else (6564, 1000000
             assert all(torch.equal(a, b) for a, b in zip(out, out2)), form
             row("bench state 128^3", n, out2, c2, e2, form=form)
 
+# pixel-ordered rays of one 1000 x 1000 frame (what the test-time marcher and a whole-frame sampling call see): neighbouring lanes walk
+# neighbouring paths
+if "--coherent" in sys.argv or True:
+    H = W = 1000
+    cam = np.array([0.0, 0.6, 4.0], np.float32)
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    dirs = np.stack([(ii - W / 2 + 0.5) / (1.2 * W), -(jj - H / 2 + 0.5) / (1.2 * H) - 0.15, -np.ones_like(ii)], -1).reshape(-1, 3)
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    O, D = T(np.broadcast_to(cam, dirs.shape)), T(dirs)
+    n = O.shape[0]
+    NEAR, FAR = torch.zeros(n, device=dev), torch.full((n,), 1e10, device=dev)
+    call = lambda: C.sample_occgrid(O, D, binaries, aabbs, NEAR, FAR, step, 0.0)
+    out, c, e = timed(call, 6)
+    row("frame 1000x1000 128^3", n, out, c, e)
+    forms = [("P1 l2", dict(split_p=1, count_l2=1)), ("P1 lds", dict(split_p=1, count_l2=0))]
+    if HAS_SKIP:
+        forms += [(f"P1 {w} skip{k}", dict(split_p=1, count_l2=c_, skip=k)) for w, c_ in (("lds", 0), ("l2", 1)) for k in (0, 1, 2)]
+    for form, f in forms:
+        with nerfacc_amd.options(**f):
+            out2, c2, e2 = timed(call, 6)
+        assert all(torch.equal(a, b) for a, b in zip(out, out2)), form
+        row("frame 1000x1000 128^3", n, out2, c2, e2, form=form)
+    # one round of the test-time marcher's shape: a step limit of 4 samples per ray and a mask (lane-per-ray lattice kernel)
+    mask = torch.ones(n, dtype=torch.bool, device=dev)
+    for form, f in ([("limit4 skip0", dict(skip=0)), ("limit4 skip1", dict(skip=1)), ("limit4 skip2", dict(skip=2))] if HAS_SKIP else [("limit4", {})]):
+        with nerfacc_amd.options(**f):
+            out3, c3, e3 = timed(lambda: C.sample_occgrid(O, D, binaries, aabbs, NEAR, FAR, step, 0.0, mask, 4), 6)
+        row("frame 1000x1000 128^3", n, out3, c3, e3, form=form)
+
 for name, r, n in (("lego", 256, 8192), ("lego", 256, 100000), ("drums", 256, 8192), ("noise", 128, 8192), ("lego", 128, 100000)):
     occ = T(scenes.occupancy_grid(name, r)); ab = T(scenes.AABB[None].copy())
     o, d = (T(x) for x in scenes.rays(n, seed=11))
