@@ -295,21 +295,25 @@ __global__ __launch_bounds__(kBlock) void compact_bricks_kernel(const uint64_t *
 // the bitmap of non-empty bricks: 32 k bricks at 128^3, a few microseconds once per grid update.  Bricks beyond the grid count as
 // empty (a walk never goes there: its overflow index stops it first).
 constexpr int kDistCap = 4;
+// One lane per brick (the two nibbles of an output byte meet through a lane shuffle); per (dx, dy) the 7 bits of the neighbouring
+// z-row around bz come out of the bitmap with two word loads and a funnel shift, and the nearest set bit of the window is four mask
+// tests — 49 windows instead of 343 single-bit probes (round 5, second form: 47 -> ~10 us at 128^3 in the bench's kernel trace).
 __global__ __launch_bounds__(kBlock) void brick_dist_kernel(const uint32_t *__restrict__ coarse, int n_grids, int nbx, int nby, int nbz,
                                                             uint8_t *__restrict__ dist)
 {
     const int64_t per_grid = (int64_t)nbx * nby * nbz, total = per_grid * n_grids;
-    for (int64_t pair = (int64_t)blockIdx.x * kBlock + threadIdx.x; 2 * pair < total; pair += (int64_t)gridDim.x * kBlock) {
-        unsigned out = 0;
-        for (int h = 0; h < 2; ++h) {
-            const int64_t b = 2 * pair + h;
-            if (b >= total) break;
+    const int64_t rounded = (total + 63) / 64 * 64, n_words = (total + 31) / 32;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < rounded; b += (int64_t)gridDim.x * kBlock) {
+        int best = kDistCap;
+        if (b < total) {
             const int64_t g = b / per_grid;
             int64_t rem = b - g * per_grid;
             const int bx = (int)(rem / ((int64_t)nby * nbz));
             rem -= (int64_t)bx * nby * nbz;
             const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
-            int best = kDistCap;
+            // window bits k = 0 .. 6 <-> z = bz - 3 + k; the bits whose z lies outside the row are masked off
+            const int lo_z = bz - 3, k_lo = lo_z < 0 ? -lo_z : 0, k_hi = (bz + 3 >= nbz) ? (nbz - 1 - lo_z) : 6;      // valid k range
+            const unsigned valid = ((2u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
             for (int dx = -(kDistCap - 1); dx <= kDistCap - 1; ++dx) {
                 const int x = bx + dx, adx = dx < 0 ? -dx : dx;
                 if (x < 0 || x >= nbx || adx >= best) continue;
@@ -317,19 +321,23 @@ __global__ __launch_bounds__(kBlock) void brick_dist_kernel(const uint32_t *__re
                     const int y = by + dy, ady = dy < 0 ? -dy : dy;
                     const int axy = adx > ady ? adx : ady;
                     if (y < 0 || y >= nby || axy >= best) continue;
-                    const int64_t row = g * per_grid + ((int64_t)x * nby + y) * nbz;
-                    for (int dz = -(kDistCap - 1); dz <= kDistCap - 1; ++dz) {
-                        const int z = bz + dz, adz = dz < 0 ? -dz : dz;
-                        const int r = axy > adz ? axy : adz;
-                        if (z < 0 || z >= nbz || r >= best) continue;
-                        const int64_t id = row + z;
-                        if ((coarse[id >> 5] >> (id & 31)) & 1u) best = r;
-                    }
+                    // bit position of (x, y, bz - 3) in the bitmap; may be "negative" at the very start of the array: shift instead
+                    const int64_t pos = g * per_grid + ((int64_t)x * nby + y) * nbz + lo_z;
+                    const int64_t p0 = pos < 0 ? 0 : pos;
+                    const int64_t wi = p0 >> 5;
+                    const uint64_t two = (uint64_t)coarse[wi] | ((wi + 1 < n_words) ? ((uint64_t)coarse[wi + 1] << 32) : 0ull);
+                    unsigned w = (unsigned)(two >> (p0 & 31));
+                    if (pos < 0) w <<= (unsigned)(-pos);              // (only the first row of the first level, bz < 3)
+                    w &= valid & 0x7fu;
+                    if (!w) continue;
+                    const int dz = (w & 0x08u) ? 0 : (w & 0x1cu) ? 1 : (w & 0x3eu) ? 2 : 3;
+                    const int r = axy > dz ? axy : dz;
+                    best = r < best ? r : best;
                 }
             }
-            out |= (unsigned)best << (4 * h);
         }
-        dist[pair] = (uint8_t)out;
+        const int other = __shfl_xor(best, 1, 64);                   // bricks 2 i and 2 i + 1 sit in adjacent lanes (b is even on even lanes)
+        if (!(threadIdx.x & 1) && b < total) dist[b >> 1] = (uint8_t)(best | ((b + 1 < total ? other : kDistCap) << 4));
     }
 }
 
@@ -410,7 +418,7 @@ __device__ __forceinline__ Occ<LDS_OCC> stage_occupancy(const GridView &g, char 
 // — the ray's slab test, DDA setup and the closed-form jumps, none of which touches the image — runs under the L2 round trips of the
 // copy instead of behind them (3.6 k of the mean wave's 45 k cycles, profiles/r04_count_pass.md section 4).  At most kStageWords
 // bitmap words and kStageBricks compact bricks per thread are held; a larger image is copied by the plain loop in stage_commit.
-constexpr int kStageWords = 2, kStageBricks = 8;
+constexpr int kStageWords = 3, kStageBricks = 8;
 struct StagePending {
     uint2 w[kStageWords];
     uint64_t b[kStageBricks];
@@ -424,8 +432,9 @@ __device__ __forceinline__ Occ<true> stage_layout(const GridView &g, char *smem)
     l.bytes = (2 * l.w4 * 4 + g.lds_compact_cap * 8 + 15) & ~15;
     return l;
 }
-template <int BLK>
+template <int BLK_UNUSED>
 __device__ __forceinline__ void stage_issue(const GridView &g, StagePending &sp) {
+    const int BLK = (int)blockDim.x;                   // (the launch may hold fewer threads than the layout's stride: split_launch_threads)
     sp.in_regs = g.lds_words <= kStageWords * BLK && g.lds_compact_cap <= kStageBricks * BLK;      // (workgroup-uniform)
     // EVERY thread issues the same loads on one straight path (indices clamped, not predicated): with a branch around them the
     // compiler's wait-count pass has to assume the path without loads at the join and waits for vmcnt(0) at the first use of the
@@ -443,8 +452,9 @@ __device__ __forceinline__ void stage_issue(const GridView &g, StagePending &sp)
         sp.b[k] = g.compact[i];
     }
 }
-template <int BLK>
+template <int BLK_UNUSED>
 __device__ __forceinline__ void stage_commit(const GridView &g, const Occ<true> &l, const StagePending &sp) {
+    const int BLK = (int)blockDim.x;
     uint2 *lw = (uint2 *)l.smem;
     uint64_t *lb = (uint64_t *)((uint32_t *)l.smem + 2 * l.w4);
     const int tid = threadIdx.x;
@@ -1497,7 +1507,7 @@ static int rank_and_compact(uint64_t *bricks, const PackedLayout &L, hipStream_t
     hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
                        bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
     if (int rc = check_launch("compact_bricks_kernel")) return rc;
-    hipLaunchKernelGGL(brick_dist_kernel, dim3(blocks_for((L.n_bricks + 1) / 2)), dim3(kBlock), 0, s, coarse, n_grids, (rx + 3) / 4, (ry + 3) / 4,
+    hipLaunchKernelGGL(brick_dist_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s, coarse, n_grids, (rx + 3) / 4, (ry + 3) / 4,
                        (rz + 3) / 4, (uint8_t *)(bricks + L.off_dist));
     return check_launch("brick_dist_kernel");
 }
@@ -1611,6 +1621,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         }
         if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
             P = (int)opt(OPT_SPLIT_P, P);
+            if (P == 32) P = 16;                              // (32 = the widened crossing-time form: plan_split decides whether it applies)
             if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for sparse grids: they never won)
         }
     }
@@ -1621,7 +1632,7 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
 // sparse occupancy image in LDS (blob-like grid) 16 (8 at P = 16) is plenty; otherwise the grid may
 // be dense or noisy — a boundary every other voxel for the reference's rand > 0.5 test grid — and
 // LDS is free of the image, so the lists get 32 entries (the width of the lane's mask register).
-struct SplitPlan { int P, cap, lds, blk, xt, seg, l2; GridView gv; };
+struct SplitPlan { int P, cap, lds, blk, xt, seg, l2; GridView gv; int thr = 0; };     // thr: threads LAUNCHED per workgroup (0 = blk)
 // several levels: one lane per level segment (traverse_count_segments_kernel) while the batch is too small to fill the chip
 // with a lane per ray — measured on 4 x 128^3 (profiles/r02_microbench.md): 125 vs 235 us at 1 k rays, 124 vs 267 at 4 k,
 // 169 vs 291 at 16 k, 309 vs 320 at 32 k, 566 vs 387 at 65 k (count pass alone).  NFA_SEGMENTS = 0 switches it off
@@ -1644,7 +1655,42 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     { const int v = (int)opt(OPT_SEG_P, 0); if (v == 8 && P == 32) P = 8; else if (v == 32 && P == 8 && room) P = 32; }
     return P;
 }
+// The 512-thread crossing-time form is one workgroup per CU (its LDS).  6 564 rays at 32 rays per workgroup are 206 workgroups: 50
+// CUs idle while the others hold two waves per SIMD.  The workgroup CAN therefore be launched with fewer threads than its LDS layout's
+// stride (`split_thr` = 192 ... 512 in steps of 64: e.g. 448 puts 235 workgroups of 28 rays on the chip).
+static int split_launch_threads(const nfa_traverse_args *a, int P, int blk, int xt) {
+    if (!(blk == 512 && xt && P == 16)) return blk;
+    const int per_wave = kWave / P;
+    (void)per_wave;
+    // Measured (profiles/r05_count_pass.md section 5): no gain — 29.0 us at 448 threads against 29.1 at 512 for 6 564 rays, 30.2 against
+    // 28.9 at 3 500 rays (narrower workgroups), and 46-49 us as soon as a second round of workgroups is needed.  The launch's time does
+    // not depend on how the rays are spread: it is the dependent chain of a wave.  Kept as an option only.
+    int thr = blk;
+    { const int v = (int)opt(OPT_SPLIT_THR, 0); if (v >= 192 && v <= 512 && v % 64 == 0) thr = v; }
+    return thr;
+}
+static SplitPlan plan_split_(const nfa_traverse_args *a);
 static SplitPlan plan_split(const nfa_traverse_args *a) {
+    SplitPlan p = plan_split_(a);
+    p.thr = p.seg ? p.blk : split_launch_threads(a, p.P, p.blk, p.xt && p.gv.lds_compact_cap > 0);
+    // 32 lanes per ray (round 5): the launch's time is its slowest WAVE's dependent chain whatever the ray count between 3 k and 8 k
+    // (29 us at 3 500 and at 8 192 rays) — so the chain is what to shorten: parts half as long (walk, boundary positions, stitch), 1024-thread
+    // workgroups of 32 rays (the same LDS: image + 8-entry lists + crossing-time arrays), two rays per wave.  `split_p = 32` / `16` force.
+    if (!p.seg && p.P == 16 && p.blk == 512 && p.xt && p.gv.lds_compact_cap > 0 && !p.l2) {
+        // Measured: 29.3-29.7 us against 28.6-30.1 with 16 lanes between 3.5 k and 8 k rays — the halved parts are paid for by four waves
+        // per SIMD instead of two (a 1024-thread workgroup; tools/ubench/launch_floor.hip: a dependent ALU chain runs 30 % slower at that
+        // occupancy).  Bit-exact (fixtures under `split_p = 32`), off unless asked for.
+        const int64_t want = opt(OPT_SPLIT_P, 16);
+        int lds32 = 0;
+        const int xt_bytes = 32 * (a->res[0] + a->res[1] + a->res[2] + 3) * 4;
+        GridView gv32 = make_view(a, 8 * 1024 * 8 + xt_bytes, &lds32, 156 * 1024);
+        if (want == 32 && gv32.lds_compact_cap > 0 && ceil_div(a->n_rays, (int64_t)32) <= kNumCU) {
+            p.P = 32; p.cap = 8; p.blk = 1024; p.thr = 1024; p.lds = lds32; p.gv = gv32;
+        }
+    }
+    return p;
+}
+static SplitPlan plan_split_(const nfa_traverse_args *a) {
     SplitPlan p;
     p.seg = 0;
     p.l2 = 0;
@@ -1775,7 +1821,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         const int lds = plan.lds;
         const GridView &gv = plan.gv;
         const bool lds_occ = gv.lds_compact_cap > 0;
-        const unsigned nbs = (unsigned)ceil_div(a->n_rays, plan.blk / P);
+        const unsigned nbs = (unsigned)ceil_div(a->n_rays, plan.thr / P);
         if (plan.seg) {
 #define NFA_LAUNCH_SEG(LDSO, PP, CAP, KK)                                                                                       \
     do {                                                                                                                       \
@@ -1796,9 +1842,12 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (plan.l2) {
             // grid image from L2: 16-entry lists, 32 KB of LDS per workgroup
             if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 16);
+        } else if (lds_occ && plan.blk == 1024 && P == 32) {
+            if (int rc = allow_lds(traverse_count_split_kernel<true, 32, 8, 1024, true>, lds)) return rc;
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 32, 8, 1024, true>), dim3(nbs), dim3(1024), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ && plan.blk == 512 && plan.xt) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true>, lds)) return rc;
-            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(plan.thr), lds, s, *a, gv, block_sums, rs);
         } else if (lds_occ && plan.blk == 512) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
@@ -1887,7 +1936,7 @@ NFA_EXPORT int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const vo
     const SplitPlan plan = plan_split(a);
     const int P = plan.P;
     const unsigned nb = (unsigned)ceil_div(a->n_rays, kBlock);
-    const int64_t n_sums = ceil_div(a->n_rays, plan.blk / P) * (plan.blk / kWave);      // one triple per wave of the count launch
+    const int64_t n_sums = ceil_div(a->n_rays, plan.thr / P) * (plan.thr / kWave);      // one triple per wave of the count launch
     hipLaunchKernelGGL(traverse_offsets_kernel, dim3(nb), dim3(kBlock), 0, s, a->iv_cnts, a->iv_starts, a->sm_cnts,
                        a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals,
                        (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)), stamp);

@@ -192,7 +192,7 @@ __device__ unsigned long long g_phase_slow[16] = {0};                           
 #define NFA_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] = now_ - phase_t_; phase_t_ = now_; } while (0)
 #define NFA_PHASE_END()                                                                        \
     do {                                                                                      \
-        const int slot_ = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);           \
+        const int slot_ = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);           \
         if (lane_id() == 0) {                                                                 \
             const unsigned long long tot_ = __builtin_readcyclecounter() - phase_t0_;          \
             atomicMax(&g_phase_max_wave, tot_);                                                \
@@ -224,6 +224,8 @@ __device__ __forceinline__ int group_incl_sum_i32(int v, int part) {
     if (P > 2) { const int u = group_shr_i32<2>(v); if (part >= 2) v += u; }
     if (P > 4) { const int u = group_shr_i32<4>(v); if (part >= 4) v += u; }
     if (P > 8) { const int u = group_shr_i32<8>(v); if (part >= 8) v += u; }
+    // P = 32: a ray's group is two DPP rows; the upper row adds the lower row's total (row_bcast:15 hands lane 15 of every row to the next)
+    if (P > 16) { const int u = __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xf, 0xf, false); if (part >= 16) v += u; }
     return v;
 }
 template <int P>
@@ -232,6 +234,7 @@ __device__ __forceinline__ int64_t group_incl_sum_i64(int64_t v, int part) {
     if (P > 2) { const int64_t u = group_shr_i64<2>(v); if (part >= 2) v += u; }
     if (P > 4) { const int64_t u = group_shr_i64<4>(v); if (part >= 4) v += u; }
     if (P > 8) { const int64_t u = group_shr_i64<8>(v); if (part >= 8) v += u; }
+    if (P > 16) { const int64_t u = dpp_i64<kDppRowBcast15>(v); if (part >= 16) v += u; }
     return v;
 }
 // the group's P bits of a wave-wide ballot
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     NFA_PHASE_BEGIN();
     const int tid = threadIdx.x, part = tid % P;
     const int64_t R = a.n_rays;
-    const int64_t r = (int64_t)blockIdx.x * (BLK / P) + tid / P;
+    const int64_t r = (int64_t)blockIdx.x * ((int)blockDim.x / P) + tid / P;      // (blockDim.x <= BLK: the crossing-time form may be launched narrower, grid.hip: split_launch_threads)
     const bool ray_ok = r < R;
     const int64_t rr = ray_ok ? r : 0;
     // the ray's loads are requested BEFORE the occupancy image is staged: their L2 round trip overlaps the image's
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
     float *xt_ray = nullptr;
     if (XT) xt_ray = (float *)(smem + occ.bytes) + 2 * CAP * BLK + (tid / P) * (gv.res[0] + gv.res[1] + gv.res[2] + 3);
     if (XT) {
-        static_assert(!XT || P == 16, "the crossing-time arrays are filled by lanes 1..15 of a ray's group");
+        static_assert(!XT || P == 16 || P == 32, "the crossing-time arrays are filled by lanes 1 .. 3 KPA of a ray's group");
+        constexpr int KPA = (P - 1) / 3;          // lanes per axis: 5 of 16, 10 of 32 (lane 31 idles)
         // ONE closed-form call per ray group: lane 0 jumps the lattice from `near` to the segment start, lanes 1..15 jump to
         // the first entry of their fifth of the x / y / z chain (5 lanes per axis); then short plain-add loops: lane 0's last
         // few lattice steps, the others' <= 26 chain entries (exact by construction).
@@ -318,14 +322,14 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
             const float est = (seg_lo - h - near) / dt;
             if (est > 24.0f && est < 1.0e9f) { const int64_t guess = (int64_t)est; adv_j = guess - nfa_jump_margin(guess); jump = true; }
         }
-        if (live && part >= 1) {
-            const int ax = (part - 1) / 5, k = (part - 1) % 5;
+        if (live && part >= 1 && part <= 3 * KPA) {
+            const int ax = (part - 1) / KPA, k = (part - 1) % KPA;
             adv_t = ax == 0 ? s.tx : (ax == 1 ? s.ty : s.tz);
             adv_d = ax == 0 ? s.dx : (ax == 1 ? s.dy : s.dz);
             int n = ax == 0 ? nx : (ax == 1 ? ny : nz);
             const int cap_n = ax == 0 ? gv.res[0] : (ax == 1 ? gv.res[1] : gv.res[2]);     // (gv.res[ax] is a memory load from the kernel arguments + a wait for EVERYTHING in flight)
             n = n < 0 ? 0 : (n > cap_n ? cap_n : n);
-            const int L = (n + 1 + 4) / 5;
+            const int L = (n + 1 + KPA - 1) / KPA;
             i_lo = k * L;
             i_hi = (k + 1) * L < n + 1 ? (k + 1) * L : n + 1;
             adv_j = i_lo;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
                 t = nt;
             }
             t_seg = t;
-        } else if (live) {
+        } else if (live && part <= 3 * KPA) {
             float t = adv_v;
             for (int i = i_lo; i < i_hi; ++i) { dst[i] = t; t = t + adv_d; }
         }

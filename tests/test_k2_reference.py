@@ -143,6 +143,8 @@ _ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}
               # boundary-list capacities of the forms that read the grid from L2 (lego_256, m1_noise; ignored where the image fits LDS)
               {"split_p": 16, "split_l2": 1, "split_cap": 16}, {"split_p": 16, "split_l2": 1, "split_cap": 24},
               {"split_p": 16, "split_l2": 1, "split_cap": 32}, {"split_p": 8, "split_cap": 24},
+              # round 5: 32 lanes per ray and narrower launches of the crossing-time form (lego_4k: 4096 rays on a grid that fits LDS)
+              {"split_p": 32}, {"split_p": 16, "split_thr": 448}, {"split_p": 16, "split_thr": 192},
               # round 5: the lane-per-ray walk with and without empty-space macro steps (brick distances from L2 / staged in LDS)
               {"split_p": 1, "count_l2": 0, "skip": 0}, {"split_p": 1, "count_l2": 1, "skip": 0}, {"split_p": 1, "count_l2": 0, "skip": 1},
               {"split_p": 1, "count_l2": 1, "skip": 1}, {"split_p": 1, "count_l2": 0, "skip": 2}, {"split_p": 1, "count_l2": 1, "skip": 2}]
