@@ -17,6 +17,8 @@ if want bench; then
   rm -rf $OUT/${TAG}_kt
 fi
 if want pmc; then
+  timeout 400 tools/pmc_traverse.sh profiles/r02_sampling_state.npz $OUT/${TAG}_pmc_1m 6 --rays=1000000 > /dev/null 2>&1
+  rm -rf $OUT/${TAG}_pmc_1m/*/*kernel_trace.csv $OUT/${TAG}_pmc_1m/*/*.db
   timeout 400 tools/pmc_traverse.sh profiles/r02_sampling_state.npz $OUT/${TAG}_pmc 20 > /dev/null 2>&1
   rm -rf $OUT/${TAG}_pmc/*/*kernel_trace.csv $OUT/${TAG}_pmc/*/*.db
 fi

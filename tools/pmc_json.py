@@ -5,6 +5,13 @@ import numpy as np
 state, out = sys.argv[1], sys.argv[2]
 st = np.load(state)
 R, cand = int(st["rays_o"].shape[0]), int(st["candidates"])
+# runs with `--rays=N` (tools/pmc_traverse.sh's 4th argument) tile the state's batch: the header has to say what was launched, not what
+# the state holds (r04_pmc_traverse_1m.json said 6564 rays for a 10^6-ray run).  The replay prints both.
+for lg in glob.glob(os.path.join(out, "trace.log")):
+    for line in open(lg):
+        if line.startswith("rays ") and " candidates " in line:
+            w = line.split()
+            R, cand = int(w[1]), int(w[3])
 KERNELS = ("traverse_count", "traverse_offsets", "traverse_emit")
 def short(name):
     for k in KERNELS:
@@ -27,7 +34,7 @@ def avg(k, c, skip=1):
     v = agg[k].get(c, [])
     v = v[skip:] if len(v) > skip else v
     return float(np.mean(v)) if v else None
-res = {"state": os.path.basename(state), "rays_per_launch": R, "candidate_samples_per_launch": cand, "kernels": {}}
+res = {"state": os.path.basename(state) + ("" if R == int(st["rays_o"].shape[0]) else f" tiled to {R} rays"), "rays_per_launch": R, "candidate_samples_per_launch": cand, "kernels": {}}
 CLOCK_HZ, SIMDS = 2.4e9, 1024
 tot_bytes = 0.0
 for k in KERNELS:
