@@ -79,8 +79,12 @@ int nfa_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
  * (bit = (x&3)*16 + (y&3)*4 + (z&3)), bricks x-major like the voxels, followed in the same
  * buffer by a 12-word header (word 0: number of non-empty bricks; words 1..8: occupied voxels of level 0..7 — what
  * `nonzero(binaries[level])` would count, so that the grid update can size it without a host sync), a bitmap of the
- * non-empty bricks, its rank prefix and the compacted non-empty bricks (the form the kernels stage into LDS).
- * nfa_packed_grid_words: size of that buffer in uint64 words for [n_grids, rx, ry, rz]. */
+ * non-empty bricks, its rank prefix, the compacted non-empty bricks (the form the kernels stage into LDS) and — round 5 — one
+ * NIBBLE per brick: the Chebyshev distance, in bricks and within its level, to the nearest non-empty brick, capped at 4 (what the
+ * empty-space macro steps of the lane-per-ray count pass size their jumps from; written by nfa_pack_binaries /
+ * nfa_grid_threshold_packed with the rest).
+ * nfa_packed_grid_words: size of that buffer in uint64 words for [n_grids, rx, ry, rz] — ALWAYS size the buffer with this call
+ * (the layout grew in round 5; a buffer sized by an older formula is too small). */
 int64_t nfa_packed_grid_words(int32_t n_grids, int32_t rx, int32_t ry, int32_t rz);
 int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz,
                       uint64_t *bricks, void *stream);
