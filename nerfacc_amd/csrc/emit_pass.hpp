@@ -294,7 +294,12 @@ struct LatStep {
 };
 constexpr int kEmitSpeculate = 4;           // run records of a ray requested together with its counts
 constexpr int kEmitSegWords = 5;            // qpos, spos, t0, j1, ray (+ 2 words of edge offset with interval outputs)
-constexpr int kEmitRayBaseBytes = 64 * 4;   // per wave, behind the segment list: first quad of every ray of the block
+constexpr int kEmitRayBaseBytes = 64 * 4 + 64;   // per wave, behind the segment list: first quad of every ray of the block, then 64 flag bytes
+                                                  // (which quad slots of the current chunk open a run: emit_by_tiles, round 5)
+#ifndef NFA_EMIT_BISECT
+#define NFA_EMIT_BISECT 1             // 1: per-quad bisection over the segment list; 0: the run of every quad slot from a ballot of "a run opens
+#endif                                // here" flags (round 5: two LDS round trips per chunk instead of seven per quad — measured NO faster: 207-209 us
+                                      // both ways at 10^6 rays, 12.9 vs 12.6 us at 6.5 k; the searches are not what the kernel waits for)
 constexpr int kSegSkip = 64;                // seg_ray flag: the run belongs to a ray the fallback launch writes
 
 // inclusive scan over the lanes of a wave, restarting at every segment head; `dist` = lanes between this lane and its segment's head
@@ -318,7 +323,7 @@ __device__ __forceinline__ int wave_seg_incl_scan_i32(int v, int dist) {
 // and 2 rays per wave 194 (profiles/r04_emit.md).  The call's runs = edges - samples are in the workspace when this kernel starts
 // (the offsets kernel's totals), so the block is halved until it holds at most kEmitRunsPerBlock runs on average — never below
 // `rb_min` (the grid was sized for that many blocks).
-constexpr int64_t kEmitRunsPerBlock = 192;
+constexpr int64_t kEmitRunsPerBlock = 288;
 __device__ __forceinline__ int emit_rays_per_wave_log2(int rb_log2, int rb_min, int64_t n_rays, const int64_t *__restrict__ n_dev) {
     if (rb_min >= rb_log2) return rb_log2;
     const int64_t runs = n_dev[0] - n_dev[1];
@@ -346,7 +351,9 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
     int32_t *seg_j1 = (int32_t *)(seg_t0 + seg_cap);              // index of the first lattice point past t0's binade (INT_MAX: none in the run)
     int32_t *seg_ray = seg_j1 + seg_cap;                          // the run's ray (its index in the block; + kSegSkip: not written here)
     int32_t *ray_base = seg_ray + seg_cap;                        // [64] first quad of every ray
-    int64_t *seg_eoff = (int64_t *)(ray_base + 64);               // (IV only) edge index of a sample = its sample index + this
+    unsigned char *run_flag = (unsigned char *)(ray_base + 64);   // [64] quad slot of the current chunk opens a run (zero between chunks)
+    int64_t *seg_eoff = (int64_t *)(ray_base + 64 + 16);          // (IV only) edge index of a sample = its sample index + this
+    run_flag[lane] = 0;                                           // (LDS comes uninitialised; every reader clears its flag again)
     // W = 64 / RB lanes share a ray while the segment list is built: lane (ray_l, w) takes the ray's runs w, w + W, ...
     const int RB = 1 << rb_log2, wshift = 6 - rb_log2, W = 1 << wshift;
     const int ray_l = lane >> wshift, w = lane & (W - 1);
@@ -467,10 +474,34 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             for (int qc = 0; qc < n_quads; qc += 64) {
                 const int slot = qc + lane;
                 int seg = seg_lo;
+#if !NFA_EMIT_BISECT
+                // The run of every quad slot of this chunk WITHOUT a search (round 5): the runs that open inside the chunk are
+                // seg_lo + 1, seg_lo + 2, ... (at most 64: a run has at least one quad; seg_lo is the run of the quad BEFORE the chunk, so a
+                // run may open on the chunk's very first slot); lane i looks at run seg_lo + 1 + i and, when it opens at slot qc + st with
+                // 0 <= st < 64, raises flag st; a ballot of the flags is the chunk's map of run starts and a slot's run is seg_lo + the
+                // starts at or below it.  Two LDS round trips per chunk instead of the bisection's seven
+                // dependent ones per quad.
+                {
+                    const int c = seg_lo + 1 + lane;
+                    if (c < n_sub) {
+                        const int st = seg_qpos[c] - qc;
+                        if (st >= 0 && st < 64) run_flag[st] = 1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const bool opens = run_flag[lane] != 0;
+                    run_flag[lane] = 0;
+                    const unsigned long long starts = __ballot(opens);
+                    seg = seg_lo + __popcll(starts & lanes_le(lane));
+                }
+#endif
                 if (slot < n_quads) {
+#if NFA_EMIT_BISECT
                     int lo = seg_lo, hi = seg_lo + 65 < n_sub ? seg_lo + 65 : n_sub;
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_qpos[mid] <= slot) lo = mid; else hi = mid; }
                     seg = lo;
+#endif
                     const int ray_s = seg_ray[seg];
                     if (ray_s < kSegSkip) {
                         const int sp = seg_spos[seg];
@@ -547,8 +578,11 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
 }
 
 // the tile form's own kernel: the host launches it for every cone_angle == 0 call (`emit` option: auto or tiles)
+#ifndef NFA_EMIT_MINBLOCKS
+#define NFA_EMIT_MINBLOCKS 5          // workgroups the compiler has to fit per CU (x 4 waves = waves per SIMD): bounds the VGPR count
+#endif
 template <bool IV>
-__global__ __launch_bounds__(kBlock) void traverse_emit_tiles_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
+__global__ __launch_bounds__(kBlock, NFA_EMIT_MINBLOCKS) void traverse_emit_tiles_kernel(nfa_traverse_args a, RunStore rs, int64_t capacity,
                                                                      const int64_t *__restrict__ n_dev, int speculative, int rb_log2, int rb_min, int seg_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
