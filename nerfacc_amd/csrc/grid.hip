@@ -1182,10 +1182,34 @@ __global__ __launch_bounds__(kBlock) void traverse_offsets_kernel(
     const int64_t c_sm = in ? sm_cnts[r] : 0;
     int64_t p0 = 0, p1 = 0, ov = 0;
     const int64_t before = (int64_t)b * sums_per_block;
-    for (int64_t j = threadIdx.x; j < before; j += kBlock) { p0 += block_sums[3 * j]; p1 += block_sums[3 * j + 1]; }
+    // (four strides per trip, every load of a trip requested before the first is added: the last block walks ~1 600 triples at the bench
+    //  size — seven DEPENDENT-looking trips of one load pair each were most of this kernel's 6.6 us, and the host waits for its stamp)
+    for (int64_t j = threadIdx.x; j < before; j += 4 * kBlock) {
+        int64_t a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = j + u * kBlock;
+            const bool in_k = k < before;
+            a0[u] = in_k ? block_sums[3 * k] : 0;
+            a1[u] = in_k ? block_sums[3 * k + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p0 += a0[u]; p1 += a1[u]; }
+    }
     int64_t ed = 0;
     if (last)                                     // rays that need the pass-2 re-traversal; the call's edges (also without iv_cnts: the emit
-        for (int64_t j = threadIdx.x; j < n_sums; j += kBlock) { ov += block_sums[3 * j + 2]; ed += block_sums[3 * j]; }      // pass reads runs = edges - samples)
+        for (int64_t j = threadIdx.x; j < n_sums; j += 4 * kBlock) {                                                         // pass reads runs = edges - samples)
+            int64_t b0[4], b2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t k = j + u * kBlock;
+                const bool in_k = k < n_sums;
+                b2[u] = in_k ? block_sums[3 * k + 2] : 0;
+                b0[u] = in_k ? block_sums[3 * k] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ov += b2[u]; ed += b0[u]; }
+        }
     int64_t t0, t1;
     block_excl_scan_i64(p0, lds, t0);
     block_excl_scan_i64(p1, lds, t1);
