@@ -30,9 +30,15 @@ ri, ts, te, pk = call()
 torch.cuda.synchronize()
 timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill"))
 _backend.set_kernel_timer(timer)
+gap_us = next((float(a.split("=")[1]) for a in sys.argv if a.startswith("--gap-us=")), 0.0)     # idle GPU time between calls (what a host-bound training loop leaves)
 t0 = time.perf_counter()
 for _ in range(reps):
     call()
+    if gap_us > 0:
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + gap_us * 1e-6
+        while time.perf_counter() < t_end:
+            pass
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / reps
 summ = timer.summary()
