@@ -1040,6 +1040,12 @@ def _select_backend():
 
 BACKEND = "ctypes"          # set for real just below (the functions above read it at call time)
 _C, BACKEND = _select_backend()
+if BACKEND == "ext":
+    # the extension keeps device tensors in thread-local slots (traversal workspace, a count pass launched ahead): hand the main
+    # thread's back while the interpreter and the HIP runtime are still up (destruction order at shutdown)
+    import atexit
+
+    atexit.register(lambda: getattr(_C, "release_workspace", lambda: None)())
 RaySegmentsSpec = _C.RaySegmentsSpec
 
 __all__ = ["_C", "BACKEND", "KernelTimer", "set_kernel_timer", "load_library", "LIB_PATH", "EXPORTED_SYMBOLS", "RaySegmentsSpec", "packed_bricks"]
