@@ -305,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
             out_iv = sink.n_iv;
             out_sm = sink.n_sm;
             if (a.terminate_planes) a.terminate_planes[r] = t_term;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the general walk's loads end HERE, not at the join (split_walk.hpp has the story)
         }
         if (a.iv_cnts) a.iv_cnts[r] = out_iv;
         a.sm_cnts[r] = out_sm;

@@ -163,7 +163,7 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
     L.off_prefix = L.off_coarse + (L.n_words + 1) / 2;
     L.off_compact = L.off_prefix + (L.n_words + 1) / 2;
     L.off_dist = L.off_compact + L.n_bricks;     // round 5: 4 bits per brick, distance to the nearest non-empty brick (brick_dist_kernel)
-    L.total_words = L.off_dist + (L.n_bricks + 15) / 16;
+    L.total_words = L.off_dist + 2 * ((L.n_bricks + 31) / 32);      // (whole 16-byte units: stage_dist copies the nibbles in 16-byte-rounded pieces)
     return L;
 }
 

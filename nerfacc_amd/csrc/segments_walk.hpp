@@ -367,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_segments_kernel(nfa_tra
         out_iv = sink.n_iv;
         out_sm = sink.n_sm;
         if (a.terminate_planes) a.terminate_planes[r] = t_term;
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the serial walk's loads end HERE, not at the join (split_walk.hpp has the story)
     }
     if (ray_ok && part == 0) {
         if (a.iv_cnts) a.iv_cnts[r] = out_iv;
