@@ -481,10 +481,12 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
         uint64_t bits = 0;
         const uint32_t *lc = (const uint32_t *)l.smem;
         if (LDS_OCC) {
-            const uint2 wr = ((const uint2 *)l.smem)[id >> 5];
-            const uint32_t w = wr.x;
+            // (read as ONE 64-bit word: as a uint2 the compiler fetched .y in a second, dependent ds_read inside the branch — three LDS
+            //  round trips per non-empty brick instead of two)
+            const uint64_t wr64 = ((const uint64_t *)l.smem)[id >> 5];
+            const uint32_t w = (uint32_t)wr64, wr_y = (uint32_t)(wr64 >> 32);
             if (w & bit) {
-                const int k = (int)wr.y + __popc(w & (bit - 1u));
+                const int k = (int)wr_y + __popc(w & (bit - 1u));
                 // the LDS image holds ALL non-empty bricks (make_view only selects this variant
                 // when they fit), so there is no global fallback here: a "k < cap ? lds : global"
                 // select is compiled into one flat load, which is what this code avoids
@@ -505,11 +507,12 @@ __device__ __forceinline__ bool occupied(const GridView &g, const Occ<LDS_OCC> &
 template <bool LDS_OCC>
 __device__ __forceinline__ uint64_t brick_bits(const GridView &g, const Occ<LDS_OCC> &l, int id) {
     if (LDS_OCC) {
-        const uint2 wr = ((const uint2 *)l.smem)[id >> 5];
+        const uint64_t wr64 = ((const uint64_t *)l.smem)[id >> 5];          // {bitmap word, rank prefix} in one ds_read_b64
+        const uint32_t wx = (uint32_t)wr64, wy = (uint32_t)(wr64 >> 32);
         const uint32_t bit = 1u << (id & 31);
-        const int k = (wr.x & bit) ? (int)wr.y + __popc(wr.x & (bit - 1u)) : 0;
+        const int k = (wx & bit) ? (int)wy + __popc(wx & (bit - 1u)) : 0;
         const uint64_t b = ((const uint64_t *)((const uint32_t *)l.smem + 2 * l.w4))[k];
-        return (wr.x & bit) ? b : 0ull;
+        return (wx & bit) ? b : 0ull;
     }
     return g.bricks[id];
 }
