@@ -318,7 +318,9 @@ int nfa_rendering_fwd(const int64_t *ray_indices, const float *t_starts, const f
                       const float *bkgd, int32_t expected_depths, float *weights, float *trans,
                       float *alphas, float *colors, float *opacities, float *depths, void *stream);
 /* VJP of the above w.r.t. sigmas and rgbs.  g_colors/g_opacities/g_depths per ray,
- * g_weights/g_trans/g_alphas per sample; all six nullable.  opacities/depths: forward outputs. */
+ * g_weights/g_trans/g_alphas per sample; all six nullable.  opacities/depths: forward outputs.
+ * weights / trans / alphas must be the forward pass's outputs for the same inputs: the kernel forms weights as
+ * trans * alphas (exactly what the forward pass stored) and does not read the weights array. */
 int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                       const float *sigmas, const float *rgbs, const float *weights,
                       const float *trans, const float *alphas, const float *opacities,

@@ -31,6 +31,8 @@ enum Option : int {
     OPT_SPLIT_THR,       // crossing-time form of the count pass: threads launched per workgroup, 192 ... 512 in steps of 64
     OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps with the brick distances
                          // read from L2, 2 = with the distances staged in LDS
+    OPT_VIS_ONEPASS,     // visibility filter with compacted outputs: 0 = mask / (scan) / compaction kernels, 1 = the one-pass look-back form
+    OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 8 (the LDS image per wave holds one chunk more)
     OPT_COUNT
 };
 

@@ -13,6 +13,8 @@
 //   nfa_pack_info / nfa_unpack_info            pack.py:10-49
 // All are HBM-streaming (bytes per sample in DESIGN.md), need no LDS, and are deterministic
 // for ray-sorted input (per-ray sums are formed inside one wave, in a fixed order).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace nfa {
@@ -105,11 +107,56 @@ __global__ __launch_bounds__(kBlock) void weight_bwd_kernel(
 // 1) keep mask, per-wave-tile kept counts and the range each wave owned (for the compaction's walk)
 template <int E>
 struct VisIn { float d[E], t0[E], t1[E]; };
+// Keep / head bit planes of the filter (between the mask pass and the compaction).  Per chunk of 64 E samples and per SLOT, 2 E
+// words: [keep bits of element e = 0 .. E-1 | head bits of element e], bit l = lane l's element.  A chunk has two slots because
+// two waves can own elements of it — the wave of the nominal tile it lies in ("home", slot 0) and the one earlier wave whose last
+// ray straddles into it (slot 1); each writes whole words of its own slot (bits of elements it does not own are 0), so there
+// is no read-modify-write and no byte-per-sample mask: 0.5 byte per sample instead of 1 written and 1 read.
+template <int E>
+__device__ __forceinline__ int64_t vis_plane_words(int64_t base, int slot) { return ((base / (64 * E)) * 2 + slot) * (2 * E); }
+__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// keep[e] of one chunk: transmittance before the sample >= eps (and alpha >= alpha_thre); `carry` is the walk's scan carry
+template <int E, class P>
+__device__ __forceinline__ void vis_keep(int from_alpha, const bool (&act)[E], const P &p, const SegFwd<E> &s, float &carry,
+                                         float eps, float alpha_thre, uint8_t (&keep)[E])
+{
+    float x[E], a[E] = {}, incl[E], ex[E];
+    if (from_alpha) {   // exclusive product of (1 - alpha), volrend.py:207-209
+#pragma unroll
+        for (int e = 0; e < E; ++e) { a[e] = p.d[e]; x[e] = act[e] ? 1.0f - a[e] : 1.0f; }
+        seg_scan_fwd<OpProd, E>(x, s, carry, incl, ex);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = act[e] ? p.d[e] * (p.t1[e] - p.t0[e]) : 0.0f;
+        // alpha is only compared with alpha_thre: with alpha_thre == 0 — configs[1]'s setting, train_ngp_nerf_occ.py:77 — nobody
+        // reads it, and its expf is a quarter of this pass's VALU work (round 4; the branch is wave-uniform, the kept samples
+        // are bit-identical: the transmittance path below is untouched)
+        if (alpha_thre > 0.0f) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = 1.0f - expf(-x[e]);
+        }
+        seg_scan_fwd<OpSum, E>(x, s, carry, incl, ex);
+#pragma unroll
+        for (int e = 0; e < E; ++e) ex[e] = expf(-ex[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        bool k = act[e] && (ex[e] >= eps);
+        if (alpha_thre > 0.0f) k = k && (a[e] >= alpha_thre);
+        keep[e] = k ? 1 : 0;
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, int spec, float eps, float alpha_thre,
-    uint8_t *__restrict__ mask, int64_t *__restrict__ tile_cnts, int64_t *__restrict__ tile_rng, int64_t *__restrict__ wg_sums)
+    uint8_t *__restrict__ mask, uint64_t *__restrict__ planes, int64_t *__restrict__ tile_cnts, int64_t *__restrict__ tile_rng,
+    int64_t *__restrict__ wg_sums)
 {
     __shared__ int64_t s_kept[kWavesPerBlock];
     const int64_t w = wave_index();
@@ -126,48 +173,37 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
-            float x[E], a[E] = {}, incl[E], ex[E];
             uint8_t keep[E];
-            if (from_alpha) {   // exclusive product of (1 - alpha), volrend.py:207-209
-#pragma unroll
-                for (int e = 0; e < E; ++e) { a[e] = p.d[e]; x[e] = act[e] ? 1.0f - a[e] : 1.0f; }
-                seg_scan_fwd<OpProd, E>(x, s, carry, incl, ex);
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) x[e] = act[e] ? p.d[e] * (p.t1[e] - p.t0[e]) : 0.0f;
-                // alpha is only compared with alpha_thre: with alpha_thre == 0 — configs[1]'s setting, train_ngp_nerf_occ.py:77 — nobody
-                // reads it, and its expf is a quarter of this pass's VALU work (round 4; the branch is wave-uniform, the kept samples
-                // are bit-identical: the transmittance path below is untouched)
-                if (alpha_thre > 0.0f) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) a[e] = 1.0f - expf(-x[e]);
-                }
-                seg_scan_fwd<OpSum, E>(x, s, carry, incl, ex);
-#pragma unroll
-                for (int e = 0; e < E; ++e) ex[e] = expf(-ex[e]);
-            }
-            bool any_act = false, lane_first = false;
-            int fe = 0, le = 0;
+            vis_keep<E>(from_alpha, act, p, s, carry, eps, alpha_thre, keep);
+            if (mask) st_vec<E>(mask, i0, act, keep);
+            // the chunk's keep / head / active bits, bit l of word e = element (lane l, e); all wave-uniform from here on
+            unsigned long long kb[E], hb[E];
+            int lo = 64 * E, hi = -1;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                bool k = act[e] && (ex[e] >= eps);
-                if (alpha_thre > 0.0f) k = k && (a[e] >= alpha_thre);
-                keep[e] = k ? 1 : 0;
-                kept += __popcll(__ballot(k));
-                if (act[e]) { if (!any_act) fe = e; le = e; any_act = true; }
-            }
-            st_vec<E>(mask, i0, act, keep);
-            (void)lane_first;
-            const unsigned long long am = __ballot(any_act);
-            if (am) {
-                const int64_t base = i0 - (int64_t)lane * E;
-                if (first) {
-                    const int l = __ffsll((long long)am) - 1;
-                    rb = base + l * E + __builtin_amdgcn_readlane(fe, l);
-                    first = false;
+                kb[e] = __ballot(keep[e] != 0);
+                hb[e] = __ballot(act[e] && s.head[e]);
+                kept += __popcll(kb[e]);
+                const unsigned long long ab = __ballot(act[e]);
+                if (ab) {
+                    const int f = (__ffsll((long long)ab) - 1) * E + e, l = (63 - __clzll((long long)ab)) * E + e;
+                    lo = f < lo ? f : lo;
+                    hi = l > hi ? l : hi;
                 }
-                const int l = 63 - __clzll((long long)am);
-                re = base + l * E + __builtin_amdgcn_readlane(le, l) + 1;
+            }
+            const int64_t base = readfirstlane_i64(i0);           // (lane 0's i0)
+            if (hi >= 0) {
+                if (first) { rb = base + lo; first = false; }
+                re = base + hi + 1;
+            }
+            // the words go to the chunk's "home" slot (chunk inside this wave's nominal tile) or to its "straddler" slot (beyond it:
+            // the tail of this wave's last ray; the wave of that tile fills the home slot with ITS elements) — see vis_plane_words
+            if (planes) {
+                uint64_t *pw = planes + vis_plane_words<E>(base, base < (w + 1) * tile ? 0 : 1);
+                unsigned long long v = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { v = lane == e ? kb[e] : v; v = lane == E + e ? hb[e] : v; }
+                if (lane < 2 * E) pw[lane] = v;
             }
         },
         [](int64_t) {});
@@ -208,16 +244,18 @@ __global__ __launch_bounds__(kBlock) void visibility_group_scan_kernel(int64_t *
 //           group totals: the wave adds the totals of the groups before its own
 // The last wave stores the total in modes 1 and 2.
 constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
+constexpr int64_t kVisOnePassChunks = 4;               // chunks (64 E samples) per tile of that form
+template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const uint8_t *__restrict__ mask, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
-    const int64_t *__restrict__ tile_rng, int mode, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t stamp,
+    const uint64_t *__restrict__ planes, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
+    const int64_t *__restrict__ tile_rng, int mode, int64_t n, int64_t tile, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t stamp,
     int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
     const int64_t w_ = wave_index();
     if (w_ >= n_tiles) return;
     const int lane = lane_id();
-    const int64_t rb = tile_rng[2 * w_], re = tile_rng[2 * w_ + 1];
+    const int64_t rb = readfirstlane_i64(tile_rng[2 * w_]), re = readfirstlane_i64(tile_rng[2 * w_ + 1]);
     int64_t dst;
     if (mode == 1) {
         // group_sums holds the survivors per WORKGROUP of the mask pass here: add up the workgroups before this wave's, then
@@ -247,18 +285,266 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
         dst = tile_offs[w_];
     }
     if (!o_keys || rb >= re) return;
-    for (int64_t base = (rb >> 6) << 6; base < re; base += 64) {      // the mask kernel's chunks
-        const int64_t i = base + lane;
-        const bool keep = i >= rb && i < re && mask[i];
-        const unsigned long long b = __ballot(keep);
-        if (keep) {
-            const int64_t k = dst + __popcll(b & lanes_lt(lane));
-            st_stream(o_keys + k, keys[i]);
-            st_stream(o_ts + k, ts[i]);
-            st_stream(o_te + k, te[i]);
+    // Walk the mask pass's chunks of this wave's range.  What is read per sample: the bit planes (0.5 byte), t_starts / t_ends as
+    // aligned vectors, and the KEY ONLY AT RAY HEADS (keys are constant along a ray: every other element takes the key of the
+    // nearest head before it — from its own lane, from a lower lane through ds_bpermute, or from the previous chunk) instead of
+    // 8 bytes for every sample.  Chunks without a survivor (the cut-off tails of opaque rays) are skipped without a load.
+    constexpr int64_t CH = 64 * E;
+    const int64_t tile_end = (w_ + 1) * tile;
+    int64_t carry_key = 0;
+    for (int64_t base = (rb / CH) * CH; base < re; base += CH) {
+        const uint64_t *pw = planes + vis_plane_words<E>(base, base < tile_end ? 0 : 1);
+        unsigned long long kb[E], hb[E], any_k = 0, any_h = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { kb[e] = pw[e]; hb[e] = pw[E + e]; any_k |= kb[e]; any_h |= hb[e]; }
+        const int64_t i0 = base + (int64_t)lane * E;
+        bool keep[E], head[E];
+        int64_t key[E];
+        int64_t lk = 0;                                   // key of the lane's last head (lanes of any_h)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            keep[e] = (kb[e] >> lane) & 1ull;
+            head[e] = (hb[e] >> lane) & 1ull;
+            key[e] = 0;
+            if (head[e]) { key[e] = keys[i0 + e]; lk = key[e]; }
         }
-        dst += __popcll(b);
+        if (any_k) {
+            float t0[E], t1[E];
+            ld_vec<E>(ts, i0, n, 0.0f, t0);
+            ld_vec<E>(te, i0, n, 0.0f, t1);
+            // the key that comes into the lane: the last head of the nearest lower lane that has one, else the previous chunk's
+            const unsigned long long lower = any_h & lanes_lt(lane);
+            const int src = lower ? 63 - __clzll((long long)lower) : lane;
+            const int64_t from_lane = __shfl(lk, src, 64);
+            int64_t in_key = lower ? from_lane : carry_key;
+            int below = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) below += __popcll(kb[e] & lanes_lt(lane));
+            int64_t k = dst + below;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                in_key = head[e] ? key[e] : in_key;
+                if (keep[e]) {
+                    st_stream(o_keys + k, in_key);
+                    st_stream(o_ts + k, t0[e]);
+                    st_stream(o_te + k, t1[e]);
+                    ++k;
+                }
+                dst += __popcll(kb[e]);
+            }
+        }
+        if (any_h) {                                      // the key that leaves the chunk: its last head
+            int last_e = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (hb[e] >> (63 - __clzll((long long)any_h)) & 1ull) last_e = e;
+            const int l = 63 - __clzll((long long)any_h);
+            int64_t ck = key[0];
+#pragma unroll
+            for (int e = 1; e < E; ++e) ck = last_e == e ? key[e] : ck;
+            carry_key = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)ck >> 32), l) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)ck, l));
+        }
     }
+}
+
+// ----------------------------------------------------------------------------------------
+// The one-pass form of the filter (option vis_onepass = 1; never chosen automatically: on MI355X it measures 1.3-1.7x SLOWER than
+// the three kernels above although it moves a third fewer bytes — every tile waits for the slowest of the ~1000 tile groups in
+// flight before it, profiles/r05_streaming.md section 3).
+//
+// The three-kernel form reads keys / t_starts / t_ends twice (mask pass, compaction) and moves a mask byte per sample in
+// between: 54 bytes per sample for 36 algorithmic ones.  Here a wave walks its rays ONCE: the survivors of its tile are
+// packed into LDS in sample order as they are found (ballot ranks), the tile's survivor count is published, the destination
+// is the sum of the counts of the tiles before (decoupled look-back: a wave reads the 64 states before its own at a time,
+// nearest first, and stops at the first tile that has published its inclusive prefix), and the LDS image leaves as one
+// contiguous, coalesced copy.  36 bytes per sample cross the HBM interface.
+//
+// States are 64-bit words [status:2 | value:62] (0 = nothing yet, 1 = the group's own count, 2 = count of all groups up to and
+// including it), one per GROUP of four consecutive tiles (a workgroup's four waves add up in LDS first: a quarter of the states to
+// look through), zeroed by the launch's memset together with the ticket counter in front of them.  Groups are handed out by an
+// atomic ticket: a workgroup only ever waits for groups with SMALLER tickets, whose workgroups were therefore already running
+// when it drew its own — forward progress does not depend on the order in which the hardware dispatches workgroups, nor on
+// the launch fitting the chip.  Workgroups are persistent (a few per CU) and draw the next ticket while they work on the
+// current one.
+//
+// A ray that straddles far beyond the nominal tile can give a wave more survivors than its LDS image holds.  From the chunk that
+// would overflow on, the wave only counts and leaves keep bytes (in the caller's mask, or in the workspace); once its destination
+// is known it compacts that remainder as the compaction kernel would.  Its count is published at the same point as everybody
+// else's: nobody is serialised behind a long ray.
+// ----------------------------------------------------------------------------------------
+constexpr uint64_t kVisValueMask = (1ull << 62) - 1ull;
+constexpr int kVisStateAgg = 1, kVisStatePrefix = 2;
+
+// sum of the survivor counts of tile groups [0, t) (every lane returns it): 256 states per round trip, lane l looking at the
+// groups t - 1 - l, t - 65 - l, ... (position 0 = the nearest)
+__device__ __forceinline__ int64_t vis_lookback(const uint64_t *__restrict__ st, int64_t t, int lane) {
+    constexpr int U = 4;
+    int64_t excl = 0;
+    for (int64_t j = t - 1; j >= 0; j -= 64 * U) {
+        uint64_t v[U];
+        unsigned long long take[U];
+        bool has_prefix;
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t idx = j - u * 64 - lane;
+                v[u] = idx >= 0 ? __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : ((uint64_t)kVisStatePrefix << 62);            // before the first group: prefix 0
+            }
+            bool ok = true;
+            has_prefix = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long ready = __ballot((v[u] >> 62) != 0);
+                const unsigned long long pre = __ballot((v[u] >> 62) == (uint64_t)kVisStatePrefix);
+                // positions up to the nearest published prefix are summed; everything nearer must be ready
+                unsigned long long need = has_prefix ? 0ull : ~0ull;
+                if (!has_prefix && pre) { need = ((pre & (0ull - pre)) << 1) - 1ull; has_prefix = true; }
+                take[u] = need;
+                ok = ok && ((ready & need) == need);
+            }
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        int64_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum += ((take[u] >> lane) & 1ull) ? (int64_t)(v[u] & kVisValueMask) : (int64_t)0;
+        excl += wave_sum_i64(sum);
+        if (has_prefix) break;
+    }
+    return excl;
+}
+
+#ifndef NFA_VIS_EXP
+#define NFA_VIS_EXP 0          // timing experiments only (results are wrong): 2 no look-back, 4 no staging / no flush
+#endif
+template <int E>
+__global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
+    const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
+    const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, float eps, float alpha_thre,
+    uint8_t *__restrict__ mask, uint8_t *__restrict__ ov_mask, uint64_t *__restrict__ state, int64_t n_tiles, int cap,
+    int64_t *__restrict__ n_out, int64_t stamp, int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
+{
+    extern __shared__ __align__(16) uint8_t vis_smem[];
+    __shared__ unsigned long long s_ticket[2];
+    __shared__ int64_t s_kept[2][kWavesPerBlock], s_excl[2];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int64_t n_groups = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    unsigned long long *ctr = (unsigned long long *)state;
+    uint64_t *st = state + 1;
+    // the wave's LDS image: keys[cap] | t_starts[cap] | t_ends[cap]  (addressed through vis_smem itself: pointers derived from it
+    // and selected against the global outputs lose their LDS address space and the compiler parks them in scratch)
+    const uint32_t img = (uint32_t)wv * (uint32_t)cap * 16u;
+#define L_KEYS(j) (*(int64_t *)(vis_smem + img + 8u * (uint32_t)(j)))
+#define L_TS(j) (*(float *)(vis_smem + img + 8u * (uint32_t)cap + 4u * (uint32_t)(j)))
+#define L_TE(j) (*(float *)(vis_smem + img + 12u * (uint32_t)cap + 4u * (uint32_t)(j)))
+    if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ctr, 1ull);
+    __syncthreads();
+    unsigned long long t = s_ticket[0];
+    // the workgroup stays: it draws the next ticket while it works on the current one (the atomic's round trip is hidden)
+    for (int it = 0; t < (unsigned long long)n_groups; ++it) {
+        const int par = it & 1;
+        unsigned long long nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(ctr, 1ull);
+        const int64_t w = (int64_t)t * kWavesPerBlock + wv;
+
+        int cnt = 0;                       // survivors in the LDS image
+        int64_t kept = 0;                  // survivors of the tile
+        bool over = false;                 // the image is full: chunks from ov_b on are only counted, their keep bytes are in ov_mask
+        int64_t ov_b = 0, ov_e = 0;
+        float carry = from_alpha ? 1.0f : 0.0f;
+        walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, 0,
+            [&](int64_t i0) {
+                VisIn<E> p;
+                ld_vec<E>(dens, i0, n, 0.0f, p.d);
+                ld_vec<E>(ts, i0, n, 0.0f, p.t0);
+                ld_vec<E>(te, i0, n, 0.0f, p.t1);
+                return p;
+            },
+            [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
+                uint8_t keep[E];
+                vis_keep<E>(from_alpha, act, p, s, carry, eps, alpha_thre, keep);
+                if (mask) st_vec<E>(mask, i0, act, keep);
+                // rank of element (lane, e) among the chunk's survivors, in sample order (index = base + lane E + e)
+                int below = 0, chunk_kept = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long b = __ballot(keep[e] != 0);
+                    below += __popcll(b & lanes_lt(lane));
+                    chunk_kept += __popcll(b);
+                }
+                if (!over && cnt + chunk_kept > cap) { over = true; ov_b = i0 - (int64_t)lane * E; }      // (wave-uniform)
+                if (NFA_VIS_EXP & 4) {
+                } else if (!over) {
+                    int r = cnt + below;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (keep[e]) {
+                            L_KEYS(r) = key[e];
+                            L_TS(r) = p.t0[e];
+                            L_TE(r) = p.t1[e];
+                            ++r;
+                        }
+                    }
+                    cnt += chunk_kept;
+                } else {
+                    if (!mask) st_vec<E>(ov_mask, i0, act, keep);
+                    int le = -1;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (act[e]) le = e;
+                    const unsigned long long am = __ballot(le >= 0);
+                    if (am) {
+                        const int l = 63 - __clzll((long long)am);
+                        ov_e = i0 - (int64_t)lane * E + l * E + __builtin_amdgcn_readlane(le, l) + 1;
+                    }
+                }
+                kept += chunk_kept;
+            },
+            [](int64_t) {});
+        if (lane == 0) s_kept[par][wv] = kept;
+        __syncthreads();
+        if (wv == 0) {                      // one state per workgroup: the four tiles' survivors
+            const int64_t tot = s_kept[par][0] + s_kept[par][1] + s_kept[par][2] + s_kept[par][3];
+            if (lane == 0) __hip_atomic_store(st + t, ((uint64_t)kVisStateAgg << 62) | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t excl = (NFA_VIS_EXP & 2) ? (int64_t)((t * kWavesPerBlock * tile) % (uint64_t)(n / 2)) : vis_lookback(st, (int64_t)t, lane);
+            if (lane == 0) {
+                __hip_atomic_store(st + t, ((uint64_t)kVisStatePrefix << 62) | (uint64_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_excl[par] = excl;
+                s_ticket[par ^ 1] = nxt;
+                if ((int64_t)t == n_groups - 1) { *n_out = excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
+            }
+        }
+        __syncthreads();
+        int64_t dst = s_excl[par];
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock - 1; ++k) dst += k < wv ? s_kept[par][k] : 0;
+        if (NFA_VIS_EXP & 4) cnt = 0;
+        for (int j = lane; j < cnt; j += 64) {          // the LDS image leaves as one contiguous copy
+            st_stream(o_keys + dst + j, L_KEYS(j));
+            st_stream(o_ts + dst + j, L_TS(j));
+            st_stream(o_te + dst + j, L_TE(j));
+        }
+        if (over) {                                     // the counted-only remainder, as visibility_compact_kernel does it
+            __threadfence();                            // this wave's keep bytes, stored by other lanes, before they are loaded
+            dst += cnt;
+            for (int64_t base = ov_b; base < ov_e; base += 64) {
+                const int64_t i = base + lane;
+                const bool keepb = i < ov_e && ov_mask[i];
+                const unsigned long long b = __ballot(keepb);
+                if (keepb) {
+                    const int64_t k = dst + __popcll(b & lanes_lt(lane));
+                    st_stream(o_keys + k, keys[i]);
+                    st_stream(o_ts + k, ts[i]);
+                    st_stream(o_te + k, te[i]);
+                }
+                dst += __popcll(b);
+            }
+        }
+        t = s_ticket[par ^ 1];
+    }
+#undef L_KEYS
+#undef L_TS
+#undef L_TE
 }
 
 // ----------------------------------------------------------------------------------------
@@ -412,11 +698,11 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
 }
 
 template <int E>
-struct RenderBwdIn { float w[E], T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E], rgb[E][3]; };
+struct RenderBwdIn { float T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E], rgb[E][3]; };
 template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const float *__restrict__ rgbs, const float *__restrict__ weights, const float *__restrict__ trans,
+    const float *__restrict__ rgbs, const float *__restrict__ trans,
     const float *__restrict__ alphas, const float *__restrict__ opac, const float *__restrict__ depth,
     int64_t n, int64_t tile, int spec, int64_t n_rays, const float *__restrict__ bkgd, int expected_depths,
     const float *__restrict__ g_colors, const float *__restrict__ g_opac, const float *__restrict__ g_depth,
@@ -429,7 +715,8 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     walk_rays_bwd<E, NFA_PF, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0) {
             RenderBwdIn<E> p;
-            ld_vec<E>(weights, i0, n, 0.0f, p.w);
+            // (the weights are not loaded: the forward pass stored w = T * alpha — rendering_fwd_kernel above, one rounding — and the
+            // same product of the same two floats is formed below: 4 of 60 bytes per sample less)
             ld_vec<E>(trans, i0, n, 0.0f, p.T);
             ld_vec<E>(alphas, i0, n, 0.0f, p.a);
             ld_vec<E>(ts, i0, n, 0.0f, p.t0);
@@ -443,10 +730,11 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegBwd<E> &s, const RenderBwdIn<E> &p) {
-            float gw[E], q[E], incl[E], suffix[E], gs[E], grgb[E][3];
+            float gw[E], q[E], incl[E], suffix[E], gs[E], grgb[E][3], w[E];
             bool wr[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
+                w[e] = p.T[e] * p.a[e];
                 gw[e] = p.gw[e];
                 wr[e] = act[e] && key[e] >= 0 && key[e] < n_rays;
                 grgb[e][0] = grgb[e][1] = grgb[e][2] = 0.0f;
@@ -466,9 +754,9 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
                     }
                     if (bkgd) go -= gc0 * bk0 + gc1 * bk1 + gc2 * bk2;
                     gw[e] += gc0 * p.rgb[e][0] + gc1 * p.rgb[e][1] + gc2 * p.rgb[e][2] + go + gacc * ((p.t0[e] + p.t1[e]) / 2.0f);
-                    grgb[e][0] = p.w[e] * gc0; grgb[e][1] = p.w[e] * gc1; grgb[e][2] = p.w[e] * gc2;
+                    grgb[e][0] = w[e] * gc0; grgb[e][1] = w[e] * gc1; grgb[e][2] = w[e] * gc2;
                 }
-                q[e] = act[e] ? gw[e] * p.w[e] + p.gT[e] * p.T[e] : 0.0f;
+                q[e] = act[e] ? gw[e] * w[e] + p.gT[e] * p.T[e] : 0.0f;
             }
             if (g_rgbs) {
 #pragma unroll
@@ -653,11 +941,20 @@ NFA_EXPORT int nfa_render_weight_from_density_bwd(const int64_t *ray_indices, co
     return check_launch("weight_bwd_kernel");
 }
 
-// workspace layout: [ mask: n bytes, padded to 16 ][ tile_cnts: T int64 ][ tile_offs: T int64 ][ tile_rng: 2 T int64 ]
-// (the workspace is sized for the smallest tile any plan of this n can pick: one element per lane)
+// workspace layout: [ front: bit planes of the mask pass (vis_plane_words; 32 bytes per 64 samples) — or, one-pass form, the keep
+// bytes of overflowing tiles: n ][ tile_cnts: T int64 ][ tile_offs: T int64 ][ tile_rng: 2 T int64 ] (one-pass form: its states)
+// (sized for the smallest tile any plan of this n can pick: one element per lane)
 static inline int64_t vis_tiles(int64_t n) { return ceil_div(n > 0 ? n : 1, pick_plan(n, false).tile); }
+static inline int64_t vis_front_bytes(int64_t n) {
+    const int64_t m = n > 0 ? n : 1;
+    const int64_t planes = (ceil_div(m, 64) + 4) * 32;              // (a chunk of 64 E samples: 2 slots x 2 E words; + one chunk of 4 E)
+    return ceil_div(planes > m ? planes : m, 16) * 16;
+}
 NFA_EXPORT int64_t nfa_visibility_workspace_bytes(int64_t n) {
-    return ceil_div(n > 0 ? n : 1, 16) * 16 + 4 * (int64_t)sizeof(int64_t) * vis_tiles(n);
+    // (the one-pass form keeps 1 + n / (2 * 64) words behind the front; the three-kernel form 4 words per tile)
+    const int64_t m = n > 0 ? n : 1;
+    const int64_t three = 4 * (int64_t)sizeof(int64_t) * vis_tiles(n), one = (int64_t)sizeof(uint64_t) * (2 + m / 128);
+    return vis_front_bytes(n) + (three > one ? three : one);
 }
 
 NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
@@ -681,17 +978,38 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { (void)hipMemsetAsync(n_out, 0, sizeof(int64_t), s); return NFA_OK; }
     NFA_REQUIRE(ray_indices && t_starts && t_ends && dens && workspace, "visibility_compact: NULL pointer");
-    uint8_t *mask = out_mask ? out_mask : (uint8_t *)workspace;
-    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, dens, mask}));
+    if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
+    // (the byte mask is only written when the caller asks for it; the compaction reads the bit planes at the head of the workspace)
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, dens, out_mask}));
+    // the one-pass form (see visibility_onepass_kernel): opt-in only — measured SLOWER than the kernels below at every size
+    // (profiles/r05_streaming.md section 3)
+    if (out_ray_indices && pl.e <= 2 && opt(OPT_VIS_ONEPASS, 0) != 0) {
+        const int64_t ch = 64 * pl.e;
+        const int64_t chunks = opt(OPT_VIS_CHUNKS, kVisOnePassChunks);
+        const int64_t otile = chunks * ch, OT = ceil_div(n, otile);
+        const int cap = (int)(otile + ch);
+        // workspace: [ keep bytes of overflowing tiles: n, padded to 16 ][ ticket + tile states: 1 + OT words ]
+        uint64_t *state = (uint64_t *)((uint8_t *)workspace + vis_front_bytes(n));
+        uint8_t *ov_mask = out_mask ? out_mask : (uint8_t *)workspace;
+        if (hipMemsetAsync(state, 0, (size_t)(1 + OT) * sizeof(uint64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "visibility_compact: memset of the tile states failed");
+        const size_t lds = (size_t)kWavesPerBlock * cap * 16;
+        const int64_t resident = (int64_t)kNumCU * std::min<int64_t>(8, std::max<int64_t>(1, (160 * 1024) / (int64_t)(lds + 256)));
+        const dim3 g((unsigned)std::min<int64_t>(ceil_div(OT, kWavesPerBlock), resident)), b(kBlock);
+        if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+                                          early_stop_eps, alpha_thre, out_mask, ov_mask, state, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+        else hipLaunchKernelGGL((visibility_onepass_kernel<1>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+                                early_stop_eps, alpha_thre, out_mask, ov_mask, state, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+        return check_launch("visibility_onepass_kernel");
+    }
     const int64_t tile = pl.tile, T = ceil_div(n, tile);
-    int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + ceil_div(n, 16) * 16);
+    uint64_t *planes = (uint64_t *)workspace;
+    int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + vis_front_bytes(n));
     int64_t *tile_offs = tile_cnts + T, *tile_rng = tile_offs + T;
     const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
     NFA_LAUNCH_TILED(visibility_mask_kernel, pl, n, s, ray_indices, t_starts, t_ends,
-                     dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, mask, tile_cnts, tile_rng,
+                     dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, out_mask, planes, tile_cnts, tile_rng,
                      mode == 1 ? tile_offs : (int64_t *)nullptr);      // (mode 1: the otherwise unused second quarter of the workspace)
     if (int rc = check_launch("visibility_mask_kernel")) return rc;
-    if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
     int64_t *group_sums = tile_offs;                       // (the second half of the workspace; T / 64 <= T entries)
     if (mode == 2) {
         const int64_t groups = ceil_div(T, 64);
@@ -702,9 +1020,9 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
         if (int rc = nfa_exclusive_sum_i64(tile_cnts, T, tile_offs, n_out, stream)) return rc;
         if (!out_ray_indices) return NFA_OK;
     }
-    hipLaunchKernelGGL(visibility_compact_kernel, dim3(tile_blocks(n, tile)), dim3(kBlock), 0, s, ray_indices, t_starts, t_ends,
-                       mask, mode == 0 ? tile_offs : tile_cnts, group_sums, tile_rng, mode, T, n_out, stamp,
-                       out_ray_indices, out_t_starts, out_t_ends);
+    NFA_LAUNCH_TILED(visibility_compact_kernel, pl, n, s, ray_indices, t_starts, t_ends,
+                     (const uint64_t *)planes, (const int64_t *)(mode == 0 ? tile_offs : tile_cnts), (const int64_t *)group_sums,
+                     (const int64_t *)tile_rng, mode, n, tile, T, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
     return check_launch("visibility_compact_kernel");
 }
 
@@ -784,9 +1102,9 @@ NFA_EXPORT int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_star
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && weights && trans && alphas, "rendering_bwd: NULL pointer");
     NFA_REQUIRE(!(g_depths && expected_depths) || (opacities && depths), "rendering_bwd: opacities/depths needed for g_depths");
-    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, weights, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
     NFA_LAUNCH_TILED(rendering_bwd_kernel, pl, n, (hipStream_t)stream,
-                     ray_indices, t_starts, t_ends, rgbs, weights, trans, alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd,
+                     ray_indices, t_starts, t_ends, rgbs, trans, alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd,
                      expected_depths, g_colors, g_opacities, g_depths, g_weights, g_trans, g_alphas, g_sigmas, g_rgbs);
     return check_launch("rendering_bwd_kernel");
 }

@@ -309,6 +309,38 @@ def test_visibility_compact_all_prefix_modes(n_rays):
     assert torch.equal(mask[~near], want[~near])
 
 
+@pytest.mark.parametrize("e", [1, 2, 4])
+def test_visibility_compact_keys_from_ray_heads(force_options, e):
+    """the compaction reads ray_indices only at ray heads (bit planes from the mask pass say where) and hands the key down the ray
+    across lanes, chunks and tiles: rays of thousands of samples, opaque rays whose tails are cut (whole chunks without a
+    survivor), empty rays between (key jumps), keys beyond 2^32, with and without the byte mask"""
+    from nerfacc_amd import cuda as C
+
+    force_options(e=e)
+    g = torch.Generator().manual_seed(100 + e)
+    cnts = torch.randint(0, 40, (3000,), generator=g)
+    cnts[torch.randint(0, 3000, (600,), generator=g)] = 0
+    for pos, length in ((5, 4000), (6, 1), (7, 2500), (1500, 9000), (2999, 700)):
+        cnts[pos] = length
+    ids = torch.arange(3000) * 3 + (1 << 33)                     # sparse, large ray ids
+    ri = torch.repeat_interleave(ids, cnts).to(DEV)
+    N = ri.shape[0]
+    ts = (torch.rand(N, generator=g) * 4).to(DEV)
+    te = ts + 5e-3
+    sig = (torch.rand(N, generator=g) * 20).to(DEV)
+    sig[ri == ids[7].item()] = 400.0                             # opaque after a few samples: ~2500 samples cut
+    sig[ri == ids[1500].item()] = 1e-3                           # everything kept along 9000 samples
+    for eps, thre in ((1e-3, 0.0), (1e-2, 0.03)):
+        o_ri, o_ts, o_te, mask = C.visibility_compact(ri, ts, te, sig, False, eps, thre, True)
+        assert 0 < int(mask.sum()) < N
+        assert torch.equal(o_ri, ri[mask]) and torch.equal(o_ts, ts[mask]) and torch.equal(o_te, te[mask])
+        p_ri, p_ts, p_te, none = C.visibility_compact(ri, ts, te, sig, False, eps, thre, False)
+        assert none is None and torch.equal(p_ri, o_ri) and torch.equal(p_ts, o_ts) and torch.equal(p_te, o_te)
+    # unaligned views (one element per lane whatever the option says)
+    o = C.visibility_compact(ri[1:], ts[1:], te[1:], sig[1:], False, 1e-3, 0.0, True)
+    assert torch.equal(o[0], ri[1:][o[3]]) and torch.equal(o[1], ts[1:][o[3]])
+
+
 @pytest.mark.parametrize("shape", [(4096, 48), (300, 257), (7, 1), (2, 3, 50)])
 def test_batched_inputs_take_the_fused_kernels_and_match_the_torch_composition(shape):
     """(n_rays, n_samples) tensors (PropNetEstimator's layout) go through the flattened fused kernels with cached keys: values and

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+timeout 240 python -m pytest tests/test_gpu_visibility_onepass.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -3
+timeout 100 python tools/experiments/r05_vis_onepass.py 20 22 24 2>&1 | grep "N=" | cut -c1-400
+for k in 2 4; do echo "== exp $k"; NERFACC_AMD_LIB=$PWD/tools/_prof/libvis_exp$k.so timeout 60 python tools/experiments/r05_vis_onepass.py 24 2>&1 | grep "N=" | sed 's/MISMATCH//g' | cut -c1-400; done
+echo "== ctypes baseline"; NERFACC_AMD_BACKEND=ctypes timeout 60 python tools/experiments/r05_vis_onepass.py 24 2>&1 | grep "N=" | cut -c1-400
