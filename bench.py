@@ -627,6 +627,29 @@ def dda_steps(rays_o, rays_d, aabb, res, near, far):
 
 
 def main():
+    """stdout carries the ONE JSON line and nothing else: everything the run prints on file descriptor 1 on the way — RCCL's
+    version banner at the first communicator (C stdio, the rank-step leg creates one even at N = 1), library warnings — goes to
+    stderr; rank 0's line is written when the run is over."""
+    import ctypes
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    line = None
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -1044,6 +1067,7 @@ def main():
             if dist.is_initialized():
                 dist.destroy_process_group()
 
+    line = None
     if rank == 0:
         elapsed = main_run["elapsed"]
         ms_per_step = elapsed / args.steps * 1e3
@@ -1169,9 +1193,10 @@ def main():
                 out["gpu_activity"] = prof
         if not args.no_cpu_baseline and world_size == 1 and args.field == "grid":
             out["cpu_baseline"] = cpu_baseline(field, est, pool_o, pool_d)
-        print(json.dumps(out))
+        line = json.dumps(out)
     if exchanging:
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

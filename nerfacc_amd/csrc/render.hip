@@ -321,16 +321,38 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
 #pragma unroll
             for (int e = 0; e < E; ++e) below += __popcll(kb[e] & lanes_lt(lane));
             int64_t k = dst + below;
+            int64_t okey[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 in_key = head[e] ? key[e] : in_key;
-                if (keep[e]) {
-                    st_stream(o_keys + k, in_key);
-                    st_stream(o_ts + k, t0[e]);
-                    st_stream(o_te + k, t1[e]);
-                    ++k;
-                }
+                okey[e] = in_key;
                 dst += __popcll(kb[e]);
+            }
+            bool all = true;
+#pragma unroll
+            for (int e = 0; e < E; ++e) all = all && keep[e];
+            if (E > 1 && all) {
+                // the lane's E survivors are neighbours in the output: one store per array (the destination is only element-aligned;
+                // global memory takes unaligned vectors), so that a wave's store covers whole lines instead of every E-th element
+                typedef int64_t kvec_t __attribute__((ext_vector_type(E), aligned(8)));
+                typedef float fvec_t __attribute__((ext_vector_type(E), aligned(4)));
+                kvec_t vk;
+                fvec_t v0, v1;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { vk[e] = okey[e]; v0[e] = t0[e]; v1[e] = t1[e]; }
+                *reinterpret_cast<kvec_t *>(o_keys + k) = vk;
+                *reinterpret_cast<fvec_t *>(o_ts + k) = v0;
+                *reinterpret_cast<fvec_t *>(o_te + k) = v1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (keep[e]) {
+                        st_stream(o_keys + k, okey[e]);
+                        st_stream(o_ts + k, t0[e]);
+                        st_stream(o_te + k, t1[e]);
+                        ++k;
+                    }
+                }
             }
         }
         if (any_h) {                                      // the key that leaves the chunk: its last head
@@ -699,6 +721,8 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
 
 template <int E>
 struct RenderBwdIn { float T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E], rgb[E][3]; };
+// (108 VGPRs at E = 2: 4 waves per SIMD.  Forcing 5 or 6 through __launch_bounds__ spills 20 / 89 registers and runs 1.9x / 3x
+// slower, profiles/r05_streaming.md)
 template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,

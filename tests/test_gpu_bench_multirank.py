@@ -45,7 +45,7 @@ def test_two_ranks_on_one_device(extra, launch):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]            # stdout carries the JSON line and NOTHING else (no RCCL banner)
     assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2
@@ -66,7 +66,7 @@ def test_rccl_world_of_one():
            "--warmup", "2", "--windows", "1", "--pretrain", "40", "--pool", "65536", "--no-cpu-baseline", "--no-aux", "--no-profile"]
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]            # stdout carries the JSON line and NOTHING else (no RCCL banner)
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and math.isfinite(out["value"]) and out["value"] > 0
@@ -120,7 +120,7 @@ def test_eight_ranks_multi_tensor_field_on_one_device(mode):
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + bench_args
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]            # stdout carries the JSON line and NOTHING else (no RCCL banner)
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and math.isfinite(out["value"]) and out["value"] > 0 and out["config"]["field"] == "grid+mlp"
