@@ -281,7 +281,10 @@ int nfa_sample_positions(const float *rays_o, const float *rays_d, int64_t n_ray
  * (occ_grid.py:194-220, volrend.py:435-494) in one go: keep sample i iff
  * trans_i >= early_stop_eps and (alpha_thre <= 0 or alpha_i >= alpha_thre).
  * Outputs are compacted into the first *n_out entries of out_* (capacity n each).
- * workspace: nfa_visibility_workspace_bytes(n) bytes.  n_out: [1], device-visible. */
+ * workspace: nfa_visibility_workspace_bytes(n) bytes of scratch (uninitialised is fine; 16-byte aligned; private to the call
+ * until the stream has passed it): keep / head bit planes between the two kernels (0.5 byte per sample), per-tile counts and
+ * ranges.  out_mask (bool bytes) is written only when given.  n_out: [1], device-visible.
+ * ray_indices must be ascending (every producer on this path emits them so): the compaction reads them at ray heads only. */
 int64_t nfa_visibility_workspace_bytes(int64_t n);
 int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                            const float *sigmas /* or alphas when from_alpha */, int32_t from_alpha,

@@ -98,6 +98,13 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.nfa_scan_keyed(None, None, None, 0, 0, 1, 0, None) == 0          # n == 0 is legal and launches nothing
     assert lib.nfa_packed_grid_words(1, 128, 128, 128) == 32768 + 12 + 512 + 512 + 32768 + 32768 // 16      # (+ one nibble per brick: round 5)
     assert lib.nfa_traverse_workspace_bytes(1000) > 0 and lib.nfa_visibility_workspace_bytes(1000) > 1000
+    # the filter's workspace holds its bit planes (two slots of 2 E words per chunk of 64 E samples, E <= 4) plus four words per
+    # wave tile of the smallest plan, or n keep bytes plus a state word per 128 samples for the one-pass form — for every n
+    for n in (0, 1, 63, 64, 65, 1000, 4097, (1 << 17) - 1, 1 << 17, (1 << 20) + 3, 1 << 24):
+        ws = lib.nfa_visibility_workspace_bytes(n)
+        m = max(n, 1)
+        planes = max(-(-m // (64 * e)) * 2 * 2 * e * 8 for e in (1, 2, 4))
+        assert ws % 8 == 0 and ws >= planes + 32 * -(-m // 576) and ws >= m + 8 * (2 + m // 128)
 
 
 def test_native_paths_refuse_cpu_tensors():
