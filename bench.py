@@ -631,12 +631,13 @@ def main():
     version banner at the first communicator (C stdio, the rank-step leg creates one even at N = 1), library warnings — goes to
     stderr; rank 0's line is written when the run is over."""
     import ctypes
+    args = parse_args()          # (`--gpus N` outside a launcher re-launches under torch.distributed.run here, with stdout untouched)
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     line = None
     try:
-        line = run()
+        line = run(args)
     finally:
         sys.stdout.flush()
         try:
@@ -649,7 +650,7 @@ def main():
         print(line, flush=True)
 
 
-def run():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -704,7 +705,10 @@ def run():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    return args
 
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
