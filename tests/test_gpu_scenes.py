@@ -49,3 +49,54 @@ def test_automatic_plan_is_near_the_best_forced_form(name):
         if not worst:
             return
     assert not worst, worst
+
+
+def _noise_call(n_rays):
+    import torch
+
+    import scenes
+    from nerfacc_amd import cuda as C
+
+    occ = torch.from_numpy(scenes.occupancy_grid("noise", 256)).to("cuda:0")
+    aabb = torch.from_numpy(scenes.AABB[None].copy()).to("cuda:0")
+    o, d = (torch.from_numpy(x).to("cuda:0") for x in scenes.rays(n_rays, seed=11))
+    near, far = torch.zeros(n_rays, device="cuda:0"), torch.full((n_rays,), 1e10, device="cuda:0")
+    return lambda: C.sample_occgrid(o, d, occ, aabb, near, far, 5e-3, 0.0)
+
+
+@pytest.mark.parametrize("n_rays", [16384, 65536])
+def test_noise_grid_emit_rays_per_wave_chosen_on_the_device(force_options, n_rays):
+    """the reference's rand > 0.5 grid at 256^3: 30-60 runs per ray.  The tile emit form halves its rays per wave on the device
+    from the call's runs (emit_rays_per_wave_log2); whatever it picks, the tensors are those of every forced
+    rays-per-wave and of the lane-per-sample form"""
+    import torch
+
+    call = _noise_call(n_rays)
+    ref = call()
+    assert ref[0].shape[0] > 100 * n_rays                      # (the long, many-run rays the rule is about)
+    for form in (dict(emit="tiles", emit_rb=0), dict(emit="tiles", emit_rb=2), dict(emit="tiles", emit_rb=4), dict(emit="tiles", emit_rb=6),
+                 dict(emit="samples"), dict(emit="rays")):
+        force_options(emit=None, emit_rb=None)
+        force_options(**form)
+        out = call()
+        assert all(torch.equal(a, b) for a, b in zip(ref, out)), form
+
+
+@pytest.mark.perf
+@pytest.mark.parametrize("n_rays", [16384, 65536])
+def test_noise_grid_emit_auto_within_1_15_of_the_best_rays_per_wave(force_options, n_rays):
+    """item 4a's bar: the device-side choice within 1.15 of the best forced `emit_rb` (wall-clock ratio: re-measured before failing)"""
+    import scene_sweep as SW
+
+    call = _noise_call(n_rays)
+    for attempt in range(3):
+        force_options(emit=None, emit_rb=None)
+        _, _, auto = SW.time_call(call, 10)
+        best = None
+        for rb in range(0, 7):
+            force_options(emit_rb=rb)
+            _, _, e = SW.time_call(call, 10)
+            best = e if best is None or e < best else best
+        if auto <= 1.15 * best + SLACK_US:
+            return
+    assert auto <= 1.15 * best + SLACK_US, (auto, best)
