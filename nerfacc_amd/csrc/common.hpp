@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <initializer_list>
+#include <type_traits>
 
 #include "../../include/nerfacc_hip.h"
 #include "options.hpp"
@@ -62,6 +63,10 @@ inline unsigned blocks_for(int64_t n_threads_needed) {
 // device side: wave64 primitives
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// the wave's index inside its workgroup as a SCALAR (threadIdx.x >> 6 is wave-uniform, but the compiler keeps it in a vector register
+// and then carries every tile base, loop bound and chunk address of a walk as 64-bit VALU arithmetic with vector compares in front of
+// the loop branches; through v_readfirstlane all of that moves to the scalar unit)
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 __device__ __forceinline__ unsigned long long lanes_le(int lane) {  // bits [0, lane]
     return (lane >= 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -240,10 +245,13 @@ struct RayChunk {
 };
 
 // aligned E-wide loads / stores (i0 is a multiple of E by construction; elements at or beyond n are filled / skipped)
-template <int E, class T, bool NT = false>
-__device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int64_t n, T fill, T (&out)[E]) {
+// `full` (std::true_type): the caller knows — wave-uniformly — that the whole chunk lies inside [0, n): no per-lane test, no exec
+// masking, no branch (walk_rays_* decide that once per chunk with a scalar compare; round 5: the per-array `i0 + E <= n` tests were
+// half of the walk loops' ~75 branches)
+template <int E, class T, bool NT = false, class Full = std::false_type>
+__device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int64_t n, T fill, T (&out)[E], Full = Full()) {
     typedef T vec_t __attribute__((ext_vector_type(E)));
-    if (i0 + E <= n) {
+    if (Full::value || i0 + E <= n) {
         const vec_t v = ld_stream<NT>(reinterpret_cast<const vec_t *>(p + i0));
 #pragma unroll
         for (int e = 0; e < E; ++e) out[e] = v[e];
@@ -253,9 +261,9 @@ __device__ __forceinline__ void ld_vec(const T *__restrict__ p, int64_t i0, int6
     }
 }
 // S interleaved channels per element (rgb: S = 3): out[e][c]
-template <int E, int S, bool NT = false>
-__device__ __forceinline__ void ld_vec_strided(const float *__restrict__ p, int64_t i0, int64_t n, float fill, float (&out)[E][S]) {
-    if (E > 1 && i0 + E <= n) {
+template <int E, int S, bool NT = false, class Full = std::false_type>
+__device__ __forceinline__ void ld_vec_strided(const float *__restrict__ p, int64_t i0, int64_t n, float fill, float (&out)[E][S], Full = Full()) {
+    if (E > 1 && (Full::value || i0 + E <= n)) {
         typedef float vec_t __attribute__((ext_vector_type(E)));
         float flat[E * S];
 #pragma unroll
@@ -281,7 +289,12 @@ __device__ __forceinline__ void st_vec(T *__restrict__ p, int64_t i0, const bool
     bool all = true;
 #pragma unroll
     for (int e = 0; e < E; ++e) all = all && act[e];
-    if (E > 1 && all) {
+    if (E > 1 && __ballot(all) == ~0ull) {                 // every lane stores its whole vector (interior chunks): a scalar branch
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = v[e];
+        *reinterpret_cast<vec_t *>(p + i0) = o;
+    } else if (E > 1 && all) {
         vec_t o;
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = v[e];
@@ -359,8 +372,13 @@ template <int E, class P, class Load>
 __device__ __forceinline__ RayChunk<E, P> fetch_chunk(const int64_t *__restrict__ keys, int64_t n, int64_t base, int lane, Load &load) {
     RayChunk<E, P> c;
     const int64_t i0 = base + (int64_t)lane * E;
-    ld_vec<E, int64_t, StreamKeys<P>::value>(keys, i0, n, (int64_t)0, c.key);
-    c.p = load(i0);
+    if (base + 64 * E <= n) {                               // (scalar: `base` derives from wave_in_block()) the chunk is whole
+        ld_vec<E, int64_t, StreamKeys<P>::value>(keys, i0, n, (int64_t)0, c.key, std::true_type());
+        c.p = load(i0, std::true_type());
+    } else {
+        ld_vec<E, int64_t, StreamKeys<P>::value>(keys, i0, n, (int64_t)0, c.key);
+        c.p = load(i0, std::false_type());
+    }
     return c;
 }
 

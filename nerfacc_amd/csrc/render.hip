@@ -22,7 +22,7 @@ namespace {
 
 constexpr float kEpsF32 = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
 
-__device__ __forceinline__ int64_t wave_index() { return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); }
+__device__ __forceinline__ int64_t wave_index() { return (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block(); }
 
 // ----------------------------------------------------------------------------------------
 // weights / transmittance / alpha from density
@@ -37,12 +37,12 @@ __global__ __launch_bounds__(kBlock) void weight_fwd_kernel(
 {
     float carry = 0.0f;
     walk_rays_fwd<E, NFA_PF, WeightFwdIn<E>>(keys, n, wave_index(), tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             WeightFwdIn<E> p;
-            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0);          // non-temporal: common.hpp, ld_stream
-            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1);
-            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg);
-            if (prefix) ld_vec<E, float, true>(prefix, i0, n, 1.0f, p.pf);
+            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0, full);          // non-temporal: common.hpp, ld_stream
+            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1, full);
+            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg, full);
+            if (prefix) ld_vec<E, float, true>(prefix, i0, n, 1.0f, p.pf, full);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const WeightFwdIn<E> &p) {
@@ -77,17 +77,17 @@ __global__ __launch_bounds__(kBlock) void weight_bwd_kernel(
 {
     float carry = 0.0f;
     walk_rays_bwd<E, NFA_PF, WeightBwdIn<E>>(keys, n, wave_index(), tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             WeightBwdIn<E> p;
-            ld_vec<E>(trans, i0, n, 0.0f, p.T);
-            ld_vec<E>(alphas, i0, n, 0.0f, p.a);
-            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
-            ld_vec<E>(te, i0, n, 0.0f, p.t1);
+            ld_vec<E>(trans, i0, n, 0.0f, p.T, full);
+            ld_vec<E>(alphas, i0, n, 0.0f, p.a, full);
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
 #pragma unroll
             for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
-            if (g_w) ld_vec<E>(g_w, i0, n, 0.0f, p.gw);
-            if (g_T) ld_vec<E>(g_T, i0, n, 0.0f, p.gT);
-            if (g_a) ld_vec<E>(g_a, i0, n, 0.0f, p.ga);
+            if (g_w) ld_vec<E>(g_w, i0, n, 0.0f, p.gw, full);
+            if (g_T) ld_vec<E>(g_T, i0, n, 0.0f, p.gT, full);
+            if (g_a) ld_vec<E>(g_a, i0, n, 0.0f, p.ga, full);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegBwd<E> &s, const WeightBwdIn<E> &p) {
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
     float carry = from_alpha ? 1.0f : 0.0f;
     if (w * tile < n)
     walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             VisIn<E> p;
-            ld_vec<E>(dens, i0, n, 0.0f, p.d);
-            if (!from_alpha) { ld_vec<E>(ts, i0, n, 0.0f, p.t0); ld_vec<E>(te, i0, n, 0.0f, p.t1); }
+            ld_vec<E>(dens, i0, n, 0.0f, p.d, full);
+            if (!from_alpha) { ld_vec<E>(ts, i0, n, 0.0f, p.t0, full); ld_vec<E>(te, i0, n, 0.0f, p.t1, full); }
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void visibility_mask_kernel(
 __global__ __launch_bounds__(kBlock) void visibility_group_scan_kernel(int64_t *__restrict__ tile_cnts, int64_t n_tiles,
                                                                        int64_t *__restrict__ group_sums)
 {
-    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int lane = lane_id();
     const int64_t j = g * 64 + lane;
     if (g * 64 >= n_tiles) return;
@@ -476,11 +476,11 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
         int64_t ov_b = 0, ov_e = 0;
         float carry = from_alpha ? 1.0f : 0.0f;
         walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, 0,
-            [&](int64_t i0) {
+            [&](int64_t i0, auto full) {
                 VisIn<E> p;
-                ld_vec<E>(dens, i0, n, 0.0f, p.d);
-                ld_vec<E>(ts, i0, n, 0.0f, p.t0);
-                ld_vec<E>(te, i0, n, 0.0f, p.t1);
+                ld_vec<E>(dens, i0, n, 0.0f, p.d, full);
+                ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
+                ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
                 return p;
             },
             [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
@@ -586,10 +586,10 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(
     // two further chunks requested ahead: this kernel moves only 12 + 4 DC bytes per sample, and with one chunk in
     // flight per wave the bytes in flight per CU (not the HBM) bounded it (Little's law)
     walk_rays_fwd<E, (E == 1 ? 2 : 1), AccumIn<E, DC>>(keys, n, wave_index(), tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             AccumIn<E, DC> p;
-            ld_vec<E>(weights, i0, n, 0.0f, p.w);
-            if (values && D == DC) ld_vec_strided<E, DC>(values, i0, n, 1.0f, p.v);
+            ld_vec<E>(weights, i0, n, 0.0f, p.w, full);
+            if (values && D == DC) ld_vec_strided<E, DC>(values, i0, n, 1.0f, p.v, full);
             else {
 #pragma unroll
                 for (int e = 0; e < E; ++e)
@@ -676,12 +676,12 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
         depth[key] = expected_depths ? sm / fmaxf(sw, kEpsF32) : sm;
     };
     walk_rays_fwd<E, NFA_PF, RenderFwdIn<E>>(keys, n, wave_index(), tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             RenderFwdIn<E> p;
-            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0);          // non-temporal: common.hpp, ld_stream
-            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1);
-            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg);
-            ld_vec_strided<E, 3, true>(rgbs, i0, n, 0.0f, p.rgb);
+            ld_vec<E, float, true>(ts, i0, n, 0.0f, p.t0, full);          // non-temporal: common.hpp, ld_stream
+            ld_vec<E, float, true>(te, i0, n, 0.0f, p.t1, full);
+            ld_vec<E, float, true>(sigmas, i0, n, 0.0f, p.sg, full);
+            ld_vec_strided<E, 3, true>(rgbs, i0, n, 0.0f, p.rgb, full);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&tail)[E], const RenderFwdIn<E> &p) {
@@ -737,20 +737,20 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
     walk_rays_bwd<E, NFA_PF, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
-        [&](int64_t i0) {
+        [&](int64_t i0, auto full) {
             RenderBwdIn<E> p;
             // (the weights are not loaded: the forward pass stored w = T * alpha — rendering_fwd_kernel above, one rounding — and the
             // same product of the same two floats is formed below: 4 of 60 bytes per sample less)
-            ld_vec<E>(trans, i0, n, 0.0f, p.T);
-            ld_vec<E>(alphas, i0, n, 0.0f, p.a);
-            ld_vec<E>(ts, i0, n, 0.0f, p.t0);
-            ld_vec<E>(te, i0, n, 0.0f, p.t1);
-            ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb);
+            ld_vec<E>(trans, i0, n, 0.0f, p.T, full);
+            ld_vec<E>(alphas, i0, n, 0.0f, p.a, full);
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
+            ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb, full);
 #pragma unroll
             for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
-            if (g_w_ext) ld_vec<E>(g_w_ext, i0, n, 0.0f, p.gw);
-            if (g_T_ext) ld_vec<E>(g_T_ext, i0, n, 0.0f, p.gT);
-            if (g_a_ext) ld_vec<E>(g_a_ext, i0, n, 0.0f, p.ga);
+            if (g_w_ext) ld_vec<E>(g_w_ext, i0, n, 0.0f, p.gw, full);
+            if (g_T_ext) ld_vec<E>(g_T_ext, i0, n, 0.0f, p.gT, full);
+            if (g_a_ext) ld_vec<E>(g_a_ext, i0, n, 0.0f, p.ga, full);
             return p;
         },
         [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegBwd<E> &s, const RenderBwdIn<E> &p) {

@@ -29,14 +29,14 @@ __global__ __launch_bounds__(kBlock) void scan_keyed_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ in, const float *__restrict__ mul,
     const float *__restrict__ div, float *__restrict__ out, int64_t n, int64_t tile, int spec)
 {
-    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const float ident = Op::identity();
     float carry = ident;
-    auto load = [&](int64_t i0) {
+    auto load = [&](int64_t i0, auto full) {
         ScanIn<E> p;
-        ld_vec<E>(in, i0, n, ident, p.v);
-        if (mul) ld_vec<E>(mul, i0, n, 1.0f, p.m);
-        if (div) ld_vec<E>(div, i0, n, 1.0f, p.d);
+        ld_vec<E>(in, i0, n, ident, p.v, full);
+        if (mul) ld_vec<E>(mul, i0, n, 1.0f, p.m, full);
+        if (div) ld_vec<E>(div, i0, n, 1.0f, p.d, full);
         return p;
     };
     auto values = [&](const bool (&act)[E], const ScanIn<E> &p, float (&v)[E]) {
