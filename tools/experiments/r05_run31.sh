@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of profiles/r05_streaming.md section 3; the variant libraries are render.hip built with -DNFA_VIS_EXP=<k> and linked with the other
+#  objects into tools/_prof/libvis_exp<k>.so: 2 = no look-back, 4 = nothing staged / copied out; 1, 3, 7 existed for the first, per-wave-state form)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 timeout 240 python -m pytest tests/test_gpu_visibility_onepass.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -3
 timeout 100 python tools/experiments/r05_vis_onepass.py 20 22 24 2>&1 | grep "N=" | cut -c1-400

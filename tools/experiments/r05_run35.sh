@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of profiles/r05_streaming.md section 1: tools/_prof/libold_render.so = render.hip of commit 996dff3 linked with the current objects)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 for v in old new; do
   if [ $v = old ]; then export NERFACC_AMD_LIB=$PWD/tools/_prof/libold_render.so; else unset NERFACC_AMD_LIB; export NERFACC_AMD_BACKEND=ctypes; fi
