@@ -284,7 +284,8 @@ int nfa_sample_positions(const float *rays_o, const float *rays_d, int64_t n_ray
  * workspace: nfa_visibility_workspace_bytes(n) bytes of scratch (uninitialised is fine; 16-byte aligned; private to the call
  * until the stream has passed it): keep / head bit planes between the two kernels (0.5 byte per sample), per-tile counts and
  * ranges.  out_mask (bool bytes) is written only when given.  n_out: [1], device-visible.
- * ray_indices must be ascending (every producer on this path emits them so): the compaction reads them at ray heads only. */
+ * ray_indices grouped by ray (a ray = a run of equal keys, as everywhere on this path): the compaction reads the key at the
+ * head of each run and hands it down the run. */
 int64_t nfa_visibility_workspace_bytes(int64_t n);
 int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                            const float *sigmas /* or alphas when from_alpha */, int32_t from_alpha,
