@@ -336,6 +336,11 @@ def test_visibility_compact_keys_from_ray_heads(force_options, e):
         assert torch.equal(o_ri, ri[mask]) and torch.equal(o_ts, ts[mask]) and torch.equal(o_te, te[mask])
         p_ri, p_ts, p_te, none = C.visibility_compact(ri, ts, te, sig, False, eps, thre, False)
         assert none is None and torch.equal(p_ri, o_ri) and torch.equal(p_ts, o_ts) and torch.equal(p_te, o_te)
+    # keys that are grouped by ray but NOT ascending (a ray is a run of equal keys, as for the reference's scan-by-key)
+    shuffled = ids[torch.randperm(3000, generator=g)]
+    ri2 = torch.repeat_interleave(shuffled, cnts).to(DEV)
+    o2 = C.visibility_compact(ri2, ts, te, sig, False, 1e-3, 0.0, True)
+    assert torch.equal(o2[0], ri2[o2[3]]) and torch.equal(o2[1], ts[o2[3]]) and torch.equal(o2[2], te[o2[3]])
     # unaligned views (one element per lane whatever the option says)
     o = C.visibility_compact(ri[1:], ts[1:], te[1:], sig[1:], False, 1e-3, 0.0, True)
     assert torch.equal(o[0], ri[1:][o[3]]) and torch.equal(o[1], ts[1:][o[3]])
