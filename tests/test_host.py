@@ -68,7 +68,12 @@ def test_options_table_and_environment_seeding():
         with na.options(split_p=16, emit="rays"):
             assert na.get_option("split_p") == 16 and na.get_option("emit") == "rays"
         assert na.get_option("split_p") == 8 and na.get_option("emit") is None
-        for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1)):
+        assert {"skip", "split_thr", "vis_onepass", "vis_chunks", "emit_rb", "split_cap", "chunk_prefetch"} <= set(names)      # rounds 4-5
+        na.set_option("vis_onepass", 1); na.set_option("vis_chunks", 6)
+        assert na.get_option("vis_onepass") == 1 and na.get_option("NFA_VIS_CHUNKS") == 6
+        na.set_option("vis_onepass", None); na.set_option("vis_chunks", None)
+        for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1), ("vis_chunks", 1), ("vis_chunks", 9),
+                            ("vis_onepass", 2), ("skip", 3), ("split_thr", 200)):
             if value == "":
                 na.set_option(name, value)          # "" = auto
                 assert na.get_option(name) is None
