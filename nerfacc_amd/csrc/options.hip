@@ -64,7 +64,7 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"split_thr", "crossing-time form of the count pass: threads launched per workgroup, 192 | 256 | 320 | 384 | 448 | 512", parse_one_of<192, 256, 320, 384, 448, 512>},
     {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps, brick distances from L2, 2 = distances staged in LDS (unset: a wave takes the macro steps when its rays are coherent)", parse_one_of<0, 1, 2>},
     {"vis_onepass", "visibility filter with compacted outputs: 0 = mask / scan / compaction kernels, 1 = one pass with look-back (unset: 0 — the one-pass form measures slower)", parse_bool},
-    {"vis_chunks", "one-pass visibility filter: chunks of 64 e samples per tile, 2 ... 8", parse_one_of<2, 3, 4, 5, 6, 7, 8>},
+    {"vis_chunks", "one-pass visibility filter: chunks of 64 e samples per tile, 2 ... 7 (four waves x (chunks + 1) x 128 x 16 bytes of LDS: 64 KB at 7)", parse_one_of<2, 3, 4, 5, 6, 7>},
 };
 
 int find_option(const char *name) {

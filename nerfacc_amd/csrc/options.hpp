@@ -32,7 +32,7 @@ enum Option : int {
     OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps with the brick distances
                          // read from L2, 2 = with the distances staged in LDS
     OPT_VIS_ONEPASS,     // visibility filter with compacted outputs: 0 = mask / (scan) / compaction kernels, 1 = the one-pass look-back form
-    OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 8 (the LDS image per wave holds one chunk more)
+    OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 7 (the LDS image per wave holds one chunk more: 64 KB per workgroup at 7)
     OPT_COUNT
 };
 
