@@ -1017,6 +1017,7 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
         uint8_t *ov_mask = out_mask ? out_mask : (uint8_t *)workspace;
         if (hipMemsetAsync(state, 0, (size_t)(1 + OT) * sizeof(uint64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "visibility_compact: memset of the tile states failed");
         const size_t lds = (size_t)kWavesPerBlock * cap * 16;
+        NFA_REQUIRE(lds <= 64 * 1024, "visibility_compact: vis_chunks = %lld needs %zu bytes of LDS per workgroup", (long long)chunks, lds);
         const int64_t resident = (int64_t)kNumCU * std::min<int64_t>(8, std::max<int64_t>(1, (160 * 1024) / (int64_t)(lds + 256)));
         const dim3 g((unsigned)std::min<int64_t>(ceil_div(OT, kWavesPerBlock), resident)), b(kBlock);
         if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
