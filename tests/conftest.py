@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: pytest-timeout's marker (registered here too so that a box without the plugin only ignores it)")
     config.addinivalue_line("markers", "randomised: seeded from the clock; collected LAST so that `pytest -x` can never hide a "
                                        "deterministic test behind an unlucky seed")
     config.addinivalue_line("markers", "perf: asserts wall-clock ratios between kernel forms (hardware- and load-dependent); "

@@ -7,7 +7,9 @@ import torch
 
 from gpu_utils import DEV
 
-pytestmark = pytest.mark.gpu
+# (the form spins on other workgroups' state words: provably finite — tickets — but a hung kernel would block the whole suite inside a
+# synchronize, so every test of this module is bounded; pytest-timeout's thread method ends the process instead of waiting)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180, method="thread")]
 
 
 def _ragged(n_rays, max_cnt, seed, long_rays=()):
