@@ -212,6 +212,28 @@ int nfa_traverse_fill(const nfa_traverse_args *args, int32_t skip_empty, int32_t
  * pass are NOT written here: call nfa_traverse_fill(a, 1, 0, workspace, 0, n_overflow, stream) for them. */
 int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const void *workspace, int64_t capacity, void *stream);
 
+/* Sync block of the single-launch forms below (nfa_traverse_sample, nfa_visibility_compact_sync): NFA_SYNC_BYTES of device memory that
+ * is ZERO before the first call that is handed it and is used by the calls of ONE stream at a time; every kernel that uses it leaves it
+ * zero again (a caller allocates it once per stream, zero-filled, and keeps it).  Inside a launch it carries one 64-bit state per
+ * workgroup [status | value]: a workgroup publishes the sum of its part and looks back over the workgroups before it — the hand-off
+ * that otherwise takes a kernel boundary (the reference: cumsum + .item() between its two traversal passes, data_spec.hpp:86-96).
+ * Every wait is bounded (2 ms): a launch that cannot finish its look-back says so in its result and the caller goes on with the
+ * separate kernels; results are identical either way. */
+#define NFA_SYNC_BYTES 16384
+
+/* nfa_traverse_count + nfa_traverse_offsets_stamped + nfa_traverse_emit_speculative (sampling outputs: sm_* / t_starts / t_ends, no
+ * interval outputs) — as ONE launch when `sync` is given and the call has a fused form (nfa_traverse_sample_fused(args) != 0: one
+ * level, step_size > 0, cone_angle = 0, 3072 ... 8192 rays, a grid whose sparse image fits LDS, n_nonempty_bricks given), else as the
+ * three launches in order.  `capacity`: samples the outputs hold (the caller's guess; 0 = count and offsets only); rays flagged as
+ * overflowed are not written (nfa_traverse_fill(a, 1, 0, workspace, 0, n_overflow, stream), as after nfa_traverse_emit_speculative).
+ * totals / stamp as nfa_traverse_offsets_stamped; after a fused launch totals[1] == -1 means its look-back gave up: per-ray counts,
+ * run records and wave sums are complete — call nfa_traverse_offsets[_stamped] and go on as after nfa_traverse_count.  With
+ * totals[1] > capacity nothing useful was stored: call nfa_traverse_fill with outputs of the right size.
+ * *fused (host, nullable) = 1 when the single launch was taken. */
+int nfa_traverse_sample_fused(const nfa_traverse_args *args);
+int nfa_traverse_sample(const nfa_traverse_args *args, void *workspace, int64_t capacity, int64_t stamp, void *sync, int32_t *fused,
+                        void *stream);
+
 /* chunk_starts = cumsum(cnts) - cnts, total -> *total (data_spec.hpp:86-106). total nullable. */
 int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *starts, int64_t *total, void *stream);
 
@@ -302,6 +324,23 @@ int nfa_visibility_compact_stamped(const int64_t *ray_indices, const float *t_st
                                    const float *sigmas, int32_t from_alpha, int64_t n, float early_stop_eps, float alpha_thre,
                                    int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, uint8_t *out_mask,
                                    int64_t *n_out, int64_t stamp, void *workspace, void *stream);
+
+/* nfa_visibility_compact_stamped as ONE launch when `sync` (NFA_SYNC_BYTES, see nfa_traverse_sample) is given, option `fused_vis`
+ * is 1 and the call is small enough for every workgroup to be resident at once (up to ~3 workgroups per CU): one pass over the
+ * samples, the survivors of a tile staged in LDS, a workgroup sums the survivors of the workgroups before it by look-back and
+ * flushes — the hand-off that otherwise takes a kernel boundary.  Opt-in: on MI355X it measures slower than the two kernels
+ * (profiles/r06_small_n.md).  Everything else takes the kernels of nfa_visibility_compact_stamped.  n_out[0] == -1 (behind the stamp)
+ * says the look-back gave up (bounded wait): nothing was stored — call nfa_visibility_compact_resume with the same arguments (it
+ * runs the kernels of nfa_visibility_compact_stamped).  Results are identical. */
+int nfa_visibility_compact_fused(int64_t n, int32_t aligned16_ptrs);     /* 1: the call below takes the single launch (given `sync` and compacted outputs) */
+int nfa_visibility_compact_sync(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                const float *sigmas, int32_t from_alpha, int64_t n, float early_stop_eps, float alpha_thre,
+                                int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, uint8_t *out_mask,
+                                int64_t *n_out, int64_t stamp, void *workspace, void *sync, void *stream);
+int nfa_visibility_compact_resume(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                  const float *sigmas, int32_t from_alpha, int64_t n, float early_stop_eps, float alpha_thre,
+                                  int64_t *out_ray_indices, float *out_t_starts, float *out_t_ends, uint8_t *out_mask,
+                                  int64_t *n_out, int64_t stamp, void *workspace, void *stream);
 
 /* accumulate_along_rays / accumulate_along_rays_ (volrend.py:497-587):
  * outputs[r, :] += sum_{i in r} w_i * values[i, :]  (values NULL: D = 1, values = 1). */

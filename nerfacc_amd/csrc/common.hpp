@@ -143,6 +143,20 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// the same with a wave-uniform lane number that is not a constant
+__device__ __forceinline__ int64_t readlane_i64_dyn(int64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// the first active lane's value as a wave-uniform (scalar) 64-bit integer
+__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // sum over the 64 lanes, result in every lane: four row_shr adds inside each 16-lane row on the
 // DPP path, then the four row totals through v_readlane (no LDS crossbar, no barrier)
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {

@@ -332,20 +332,22 @@ __device__ __forceinline__ int emit_rays_per_wave_log2(int rb_log2, int rb_min, 
     return rb;
 }
 
+// LDS bytes of one wave's segment list (+ its ray bases and run flags)
+__host__ __device__ constexpr int emit_lds_per_wave(int seg_cap, bool iv) { return seg_cap * 4 * (kEmitSegWords + (iv ? 2 : 0)) + kEmitRayBaseBytes; }
+
+// The wave expands ray blocks blk_first, blk_first + blk_step, ... (< n_rb) of 2^rb_log2 rays each.  `lds_wave`: this wave's
+// emit_lds_per_wave bytes.  `n_total`: what has to fit into `capacity` for anything to be stored (a speculative launch: the call's
+// total, requested by the caller and looked at here after the first block's loads have been issued; 0 = no check).
 template <bool IV>
-__device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const RunStore &rs, int rb_log2, int seg_cap, unsigned char *lds_raw,
-                                              const int64_t *__restrict__ n_dev, int64_t capacity, int speculative)
+__device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const RunStore &rs, int rb_log2, int seg_cap, unsigned char *lds_wave,
+                                              int64_t n_total, int64_t capacity, int64_t blk_first, int64_t blk_step, int64_t blk_end = -1)
 {
-    // speculative launch: the true total is requested here and looked at after the first block's loads have been issued — nothing
-    // is stored before the check
-    const int64_t n_total = speculative ? n_dev[1] : 0;
     bool checked = false;
-    const int lane = lane_id(), wib = (int)(threadIdx.x >> 6);
+    const int lane = lane_id();
     const int64_t R = a.n_rays;
     const LatStep L(march_dt(0.0f, 0.0f, a.step_size));
     const float dt = L.dt;
-    const int per_wave = seg_cap * 4 * (kEmitSegWords + (IV ? 2 : 0)) + kEmitRayBaseBytes;
-    int32_t *seg_qpos = (int32_t *)(lds_raw + wib * per_wave);   // first quad of the run (relative to the sub-block)
+    int32_t *seg_qpos = (int32_t *)lds_wave;                      // first quad of the run (relative to the sub-block)
     int32_t *seg_spos = seg_qpos + seg_cap;                       // first sample of the run (relative to the sub-block)
     float *seg_t0 = (float *)(seg_spos + seg_cap);                // lattice point of the run's first sample
     int32_t *seg_j1 = (int32_t *)(seg_t0 + seg_cap);              // index of the first lattice point past t0's binade (INT_MAX: none in the run)
@@ -358,8 +360,9 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
     const int RB = 1 << rb_log2, wshift = 6 - rb_log2, W = 1 << wshift;
     const int ray_l = lane >> wshift, w = lane & (W - 1);
     const bool head = w == 0;
-    const int64_t n_rb = (R + RB - 1) >> rb_log2;
-    for (int64_t blk = (int64_t)blockIdx.x * kWavesPerBlock + wib; blk < n_rb; blk += (int64_t)gridDim.x * kWavesPerBlock) {
+    int64_t n_rb = (R + RB - 1) >> rb_log2;
+    if (blk_end >= 0 && blk_end < n_rb) n_rb = blk_end;
+    for (int64_t blk = blk_first; blk < n_rb; blk += blk_step) {
         const int64_t r0 = blk << rb_log2, r = r0 + ray_l;
         const bool own = r < R;
         int64_t S = 0, cnt = 0, E = 0;
@@ -586,7 +589,12 @@ __global__ __launch_bounds__(kBlock, NFA_EMIT_MINBLOCKS) void traverse_emit_tile
                                                                      const int64_t *__restrict__ n_dev, int speculative, int rb_log2, int rb_min, int seg_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
-    emit_by_tiles<IV>(a, rs, emit_rays_per_wave_log2(rb_log2, rb_min, a.n_rays, n_dev), seg_cap, emit_lds, n_dev, capacity, speculative);
+    // speculative launch: the true total is requested here and looked at after the first block's loads have been issued — nothing
+    // is stored before the check
+    const int64_t n_total = speculative ? n_dev[1] : 0;
+    const int wib = (int)(threadIdx.x >> 6);
+    emit_by_tiles<IV>(a, rs, emit_rays_per_wave_log2(rb_log2, rb_min, a.n_rays, n_dev), seg_cap, emit_lds + wib * emit_lds_per_wave(seg_cap, IV),
+                      n_total, capacity, (int64_t)blockIdx.x * kWavesPerBlock + wib, (int64_t)gridDim.x * kWavesPerBlock);
 }
 
 // pass 2: ONE launch, the form chosen ON THE DEVICE from the totals the offsets kernel left in the workspace (the speculative

@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "lattice.hpp"
 #include "dda_skip.hpp"       // struct Dda, dda_advance and the macro step dda_skip (host-testable)
+#include "lookback.hpp"       // hand-offs between the workgroups of one launch (the fused sampling kernel)
 
 namespace nfa {
 
@@ -1135,6 +1136,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
     publish_wave_sums(sink.n_iv, sink.n_sm, ovf, block_sums);
 }
 
+#include "emit_pass.hpp"
+#include "sample_fused.hpp"
 #include "split_walk.hpp"
 #include "segments_walk.hpp"
 #include "cone_walk.hpp"
@@ -1269,8 +1272,6 @@ __global__ __launch_bounds__(kBlock) void traverse_fill_kernel(nfa_traverse_args
         a.sm_cnts[r] = sink.n_sm;
     }
 }
-
-#include "emit_pass.hpp"
 
 // generic exclusive sum of int64 counts (data_spec.hpp:86-106), single workgroup of 1024:
 // rounds of 1024 coalesced elements with a running carry.  Used for the per-ray count arrays
@@ -1864,20 +1865,20 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
 #define NFA_LAUNCH_SPLIT(LDSO, PP, CAP)                                                                                        \
     do {                                                                                                                       \
         if (int rc = allow_lds(traverse_count_split_kernel<LDSO, PP, CAP>, lds)) return rc;                                     \
-        hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs); \
+        hipLaunchKernelGGL((traverse_count_split_kernel<LDSO, PP, CAP>), dim3(nbs), dim3(kBlock), lds, s, *a, gv, block_sums, rs, FuseArgs{}); \
     } while (0)
         if (plan.l2) {
             // grid image from L2: 16-entry lists, 32 KB of LDS per workgroup
             if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 16);
         } else if (lds_occ && plan.blk == 1024 && P == 32) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 32, 8, 1024, true>, lds)) return rc;
-            hipLaunchKernelGGL((traverse_count_split_kernel<true, 32, 8, 1024, true>), dim3(nbs), dim3(1024), lds, s, *a, gv, block_sums, rs);
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 32, 8, 1024, true>), dim3(nbs), dim3(1024), lds, s, *a, gv, block_sums, rs, FuseArgs{});
         } else if (lds_occ && plan.blk == 512 && plan.xt) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true>, lds)) return rc;
-            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(plan.thr), lds, s, *a, gv, block_sums, rs);
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(plan.thr), lds, s, *a, gv, block_sums, rs, FuseArgs{});
         } else if (lds_occ && plan.blk == 512) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512>, lds)) return rc;
-            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs);
+            hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512>), dim3(nbs), dim3(512), lds, s, *a, gv, block_sums, rs, FuseArgs{});
         } else if (lds_occ) {
             NFA_LAUNCH_SPLIT(true, 16, 16);
         } else if (plan.cap == 24) {
@@ -1968,6 +1969,66 @@ NFA_EXPORT int nfa_traverse_offsets_stamped(const nfa_traverse_args *a, const vo
                        a->sm_starts, a->n_rays, (const int64_t *)workspace, P * kWavesPerBlock, n_sums, a->totals,
                        (int64_t *)((uint8_t *)const_cast<void *>(workspace) + ws_totals_offset(a->n_rays)), stamp);
     return check_launch("traverse_offsets_kernel");
+}
+
+// ---- the whole sampling call as ONE launch (sample_fused.hpp) ------------------------------------------------------------------
+// Exists for the count pass the training step and the eval loop's 8192-ray slices take: one level, constant step, no interval
+// outputs, the 512-thread crossing-time split kernel at full width, one round of workgroups (<= one per CU: every workgroup a
+// look-back could wait for is resident).  `fused_sample` = 0 switches it off.
+static bool sample_fusable(const nfa_traverse_args *a, const SplitPlan &plan) {
+    if (opt(OPT_FUSED_SAMPLE, 1) == 0) return false;
+    if (plan.seg || plan.P != 16 || plan.blk != 512 || !plan.xt || plan.l2 || plan.thr != 512) return false;
+    if (plan.gv.lds_compact_cap <= 0) return false;
+    if (a->iv_cnts || a->iv_vals || !a->totals) return false;
+    const int64_t nb = ceil_div(a->n_rays, 512 / 16);
+    return nb <= kNumCU && nb <= kSyncMaxBlocks;
+}
+
+NFA_EXPORT int nfa_traverse_sample_fused(const nfa_traverse_args *a)
+{
+    if (!a || validate_traverse(a) != NFA_OK || a->n_rays == 0) return 0;
+    return sample_fusable(a, plan_split(a)) ? 1 : 0;
+}
+
+NFA_EXPORT int nfa_traverse_sample(const nfa_traverse_args *a, void *workspace, int64_t capacity, int64_t stamp, void *sync,
+                                   int32_t *fused, void *stream)
+{
+    if (fused) *fused = 0;
+    if (int rc = validate_traverse(a)) return rc;
+    NFA_REQUIRE(a->totals != nullptr, "traverse_sample: totals is NULL");
+    NFA_REQUIRE(capacity >= 0, "traverse_sample: capacity < 0");
+    const bool outputs = a->sm_ray_indices || a->t_starts || a->sm_vals;
+    if (a->t_starts) NFA_REQUIRE(a->t_ends != nullptr, "traverse_sample: t_starts without t_ends");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->n_rays > 0 && sync) {
+        NFA_REQUIRE(workspace != nullptr, "traverse_sample: workspace is NULL");
+        const SplitPlan plan = plan_split(a);
+        if (sample_fusable(a, plan)) {
+            const RunStore rs = make_runs(workspace, a->n_rays);
+            FuseArgs fz;
+            fz.sync = (uint64_t *)sync;
+            fz.capacity = outputs ? capacity : 0;
+            fz.stamp = stamp;
+            fz.totals_dev = (int64_t *)((uint8_t *)workspace + ws_totals_offset(a->n_rays));
+            fz.seg_cap = 128;
+            while (fz.seg_cap < rs.max_runs) fz.seg_cap *= 2;
+            // the emit tail's segment lists take over the workgroup's LDS once its waves have counted
+            const int emit_lds = (512 / kWave) * emit_lds_per_wave(fz.seg_cap, false);
+            const int lds = plan.lds > emit_lds ? plan.lds : emit_lds;
+            if (lds + 256 <= kLdsPerCU) {
+                const unsigned nbs = (unsigned)ceil_div(a->n_rays, 512 / 16);
+                if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true, true>, lds)) return rc;
+                hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true, true>), dim3(nbs), dim3(512), lds, s, *a, plan.gv,
+                                   (int64_t *)workspace, rs, fz);
+                if (fused) *fused = 1;
+                return check_launch("traverse_count_split_kernel<fused>");
+            }
+        }
+    }
+    if (int rc = nfa_traverse_count(a, workspace, stream)) return rc;
+    if (int rc = nfa_traverse_offsets_stamped(a, workspace, stamp, stream)) return rc;
+    if (a->n_rays > 0 && outputs && capacity > 0) return nfa_traverse_emit_speculative(a, workspace, capacity, stream);
+    return NFA_OK;
 }
 
 static int launch_fill(const nfa_traverse_args *a, int skip_empty, int rewrite_counts, const uint16_t *only_overflow, hipStream_t s)
@@ -2096,6 +2157,16 @@ NFA_EXPORT int nfa_exclusive_sum_i64(const int64_t *cnts, int64_t n, int64_t *st
     hipLaunchKernelGGL(excl_sum_add_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, starts, n, chunk);
     return check_launch("excl_sum_chunks_kernel");
 }
+
+#ifdef NFA_FUSE_TRACE
+// instrumentation builds only (tools/fuse_trace.py): the fused sampling kernel's per-workgroup stamps, then cleared
+extern "C" __attribute__((visibility("default"))) int nfa_debug_fuse_trace(unsigned long long *out /* [512][4] */) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nfa::g_fuse_trace), 512 * 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    void *sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(nfa::g_fuse_trace)) != hipSuccess) return 1;
+    return hipMemset(sym, 0, 512 * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 #ifdef NFA_PHASE_CYCLES
 // instrumentation builds only: sum the per-wave slots into out16 (and optionally clear them)

@@ -1,0 +1,113 @@
+// lookback.hpp — hand-offs between the workgroups of ONE launch: block aggregates + decoupled look-back over a caller-owned
+// "sync block" (NFA_SYNC_BYTES of device memory, zero before its first use, left zero by every kernel that uses it).
+//
+// Why it exists (round 6): at the training size (6.5 k rays, 2.5e5 samples) every kernel of the path is
+// latency-bound and the step pays a kernel boundary + a launch for each "a few KB between two kernels" hand-off — the exclusive
+// sum of the per-ray counts between the count and the emit pass (the reference: cumsum + .item(), data_spec.hpp:86-96), the
+// prefix of the per-tile survivor counts between the mask pass and the compaction (the reference: three boolean-mask gathers,
+// occ_grid.py:180-220).  With these helpers a workgroup publishes its aggregate, sums the aggregates of the workgroups BEFORE it
+// (static ids: workgroup b only ever waits for workgroups < b) and goes on with the second half of the work in the same launch.
+//
+// Visibility between CUs / XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility"): the states are single 64-bit words
+// [status:2 | value:62] moved with agent-scope relaxed atomics (sc1 stores / loads: write-through, L1-bypassing) — the value
+// travels IN the word that says it is there, so no fence orders anything.  Totals that only the last workgroup needs are
+// accumulated with agent-scope atomic adds, drained (s_waitcnt vmcnt(0)) before the state word is stored.
+//
+// Forward progress: the hardware dispatches workgroups in id order in practice but HIP promises nothing, and two such kernels on
+// two streams could in principle fill the chip with waiters.  So every wait is BOUNDED (kSpinLimitTicks of the 100 MHz wall
+// clock): a workgroup that gives up publishes ABORT, which every later workgroup inherits; the kernel's host-visible result then
+// says "not done here" and the caller runs the unfused kernels — never a hang, and the results are the same either way.
+#pragma once
+
+#include "common.hpp"
+
+namespace nfa {
+
+constexpr int kSyncHeaderWords = 32;                                       // done | edges | overflow rays | (spare)
+constexpr int kSyncMaxBlocks = NFA_SYNC_BYTES / 8 - kSyncHeaderWords;      // states behind the header
+constexpr uint64_t kStValueMask = (1ull << 62) - 1ull;
+constexpr uint64_t kStAgg = 1, kStPrefix = 2, kStAbort = 3;                // 0 = nothing yet
+constexpr uint64_t kSpinLimitTicks = 200000;                               // 2 ms of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ uint64_t sync_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_add(uint64_t *p, uint64_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every memory operation this wave has issued is complete (inline asm: the compiler's wait-count pass cannot drop it)
+__device__ __forceinline__ void sync_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Sum of the values of states [0, b) — all 64 lanes of a wave call it and get the same answer; -1 = a state before b says ABORT,
+// or the wait ran out.  256 states per round trip, lane l looking at b - 1 - l, b - 65 - l, ... (position 0 = the nearest); the
+// walk stops at the nearest state that carries a PREFIX (the sum of everything up to and including its workgroup).
+__device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st, int64_t b, int lane) {
+    constexpr int U = 4;
+    int64_t excl = 0;
+    const uint64_t t_begin = wall_clock64();
+    for (int64_t j = b - 1; j >= 0; j -= 64 * U) {
+        uint64_t v[U];
+        unsigned long long take[U];
+        bool has_prefix;
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t idx = j - u * 64 - lane;
+                v[u] = idx >= 0 ? sync_load(st + idx) : (kStPrefix << 62);         // before the first workgroup: prefix 0
+            }
+            bool ok = true, aborted = false;
+            has_prefix = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long ready = __ballot((v[u] >> 62) != 0);
+                const unsigned long long pre = __ballot((v[u] >> 62) == kStPrefix);
+                const unsigned long long ab = __ballot((v[u] >> 62) == kStAbort);
+                // positions up to the nearest published prefix are summed; everything nearer must be ready
+                unsigned long long need = has_prefix ? 0ull : ~0ull;
+                if (!has_prefix && pre) { need = ((pre & (0ull - pre)) << 1) - 1ull; has_prefix = true; }
+                take[u] = need;
+                ok = ok && ((ready & need) == need);
+                aborted = aborted || (ab & need) != 0ull;
+            }
+            if (aborted) return -1;
+            if (ok) break;
+            if (wall_clock64() - t_begin > kSpinLimitTicks) return -1;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        int64_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum += ((take[u] >> lane) & 1ull) ? (int64_t)(v[u] & kStValueMask) : (int64_t)0;
+        excl += wave_sum_i64(sum);
+        if (has_prefix) break;
+    }
+    return excl;
+}
+
+// One wave of workgroup b (all 64 lanes): publish the workgroup's aggregate `agg` (>= 0), wait for the sum of the aggregates before
+// it, publish the inclusive prefix.  `extra0` / `extra1` are added to header words 1 / 2 BEFORE the aggregate becomes visible (totals only
+// the last workgroup reads).  Returns the exclusive prefix, or -1 (ABORT published).  The LAST workgroup to leave — whichever it is
+// — zeroes the states and the header again (`done` counts the workgroups that are through with the states).
+__device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane) {
+    uint64_t *st = sync + kSyncHeaderWords;
+    if (lane == 0) {
+        if (extra0) sync_add(sync + 1, (uint64_t)extra0);
+        if (extra1) sync_add(sync + 2, (uint64_t)extra1);
+        sync_drain();
+        sync_store(st + b, (kStAgg << 62) | (uint64_t)agg);
+    }
+    const int64_t excl = sync_lookback(st, b, lane);
+    if (lane == 0) sync_store(st + b, excl < 0 ? (kStAbort << 62) : ((kStPrefix << 62) | (uint64_t)(excl + agg)));
+    return excl;
+}
+// called by the same wave when it no longer needs the states or the header: the last caller of the launch resets them
+__device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane) {
+    unsigned long long d = 0;
+    if (lane == 0) {
+        sync_drain();                                      // this workgroup's state stores have reached memory
+        d = __hip_atomic_fetch_add((unsigned long long *)sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    d = (unsigned long long)readfirstlane_i64((int64_t)d);
+    if ((int64_t)d != n_blocks - 1) return;
+    uint64_t *st = sync + kSyncHeaderWords;
+    for (int64_t i = lane; i < n_blocks; i += 64) sync_store(st + i, 0ull);
+    if (lane < 4) sync_store(sync + lane, 0ull);
+}
+
+}  // namespace nfa

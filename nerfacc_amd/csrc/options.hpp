@@ -33,6 +33,9 @@ enum Option : int {
                          // read from L2, 2 = with the distances staged in LDS
     OPT_VIS_ONEPASS,     // visibility filter with compacted outputs: 0 = mask / (scan) / compaction kernels, 1 = the one-pass look-back form
     OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 7 (the LDS image per wave holds one chunk more: 64 KB per workgroup at 7)
+    OPT_FUSED_SAMPLE,    // 0: nfa_traverse_sample never takes its single-launch form (count + look-back + emit in the count kernel)
+    OPT_FUSED_VIS,       // 1: the visibility filter of small calls as one launch (static one-pass kernel); default 0 (measured slower)
+    OPT_FOLD_FILL,       // 0: nfa_rendering_fwd always fills the rays without a sample with a launch of its own (1: inside its kernel up to 2^20 samples)
     OPT_COUNT
 };
 

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "lookback.hpp"     // hand-offs between the workgroups of one launch (the single-launch form of the filter)
 
 namespace nfa {
 namespace {
@@ -114,11 +115,6 @@ struct VisIn { float d[E], t0[E], t1[E]; };
 // is no read-modify-write and no byte-per-sample mask: 0.5 byte per sample instead of 1 written and 1 read.
 template <int E>
 __device__ __forceinline__ int64_t vis_plane_words(int64_t base, int slot) { return ((base / (64 * E)) * 2 + slot) * (2 * E); }
-__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
 // keep[e] of one chunk: transmittance before the sample >= eps (and alpha >= alpha_thre); `carry` is the walk's scan carry
 template <int E, class P>
 __device__ __forceinline__ void vis_keep(int from_alpha, const bool (&act)[E], const P &p, const SegFwd<E> &s, float &carry,
@@ -236,61 +232,18 @@ __global__ __launch_bounds__(kBlock) void visibility_group_scan_kernel(int64_t *
     if (lane == 63) group_sums[g] = inc;
 }
 
-// 3) stream compaction with ballot ranks.  Where a wave's survivors go:
-//   mode 0  tile_offs[w] is the global exclusive prefix (single-workgroup scan, huge inputs only)
-//   mode 1  fused form for up to kVisFusedTiles tiles (every training-size call): tile_offs holds the
-//           tile COUNTS and each wave sums the ones before its own (<= 64 L2 loads per lane)
-//   mode 2  tile_offs holds the prefix inside the wave's group of 64 tiles (kernel 2) and group_sums the
-//           group totals: the wave adds the totals of the groups before its own
-// The last wave stores the total in modes 1 and 2.
-constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
-constexpr int64_t kVisOnePassChunks = 4;               // chunks (64 E samples) per tile of that form
+// The compaction of ONE wave's range [rb, re) of the mask pass (the samples it owned there), survivors to o_*[dst ...].
+// What is read per sample: the bit planes (0.5 byte), t_starts / t_ends as aligned vectors, and the KEY ONLY AT RAY HEADS (keys are
+// constant along a ray: every other element takes the key of the nearest head before it — from its own lane, from a lower lane
+// through ds_bpermute, or from the previous chunk) instead of 8 bytes for every sample.  Chunks without a survivor (the cut-off
+// tails of opaque rays) are skipped without a load.  `tile_end`: end of the wave's nominal tile (chunks beyond it: the straddler slot).
 template <int E>
-__global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
-    const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
-    const uint64_t *__restrict__ planes, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
-    const int64_t *__restrict__ tile_rng, int mode, int64_t n, int64_t tile, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t stamp,
-    int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
+__device__ __forceinline__ void vis_compact_range(const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
+                                                  const uint64_t *__restrict__ planes, int64_t rb, int64_t re, int64_t tile_end, int64_t dst,
+                                                  int64_t n, int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
-    const int64_t w_ = wave_index();
-    if (w_ >= n_tiles) return;
-    const int lane = lane_id();
-    const int64_t rb = readfirstlane_i64(tile_rng[2 * w_]), re = readfirstlane_i64(tile_rng[2 * w_ + 1]);
-    int64_t dst;
-    if (mode == 1) {
-        // group_sums holds the survivors per WORKGROUP of the mask pass here: add up the workgroups before this wave's, then
-        // the tiles of its own workgroup before it (<= 1024 + 3 loads per wave instead of <= 4096, eight in flight)
-        const int64_t wg = w_ / kWavesPerBlock;
-        int64_t p = 0;
-        int64_t j = lane;
-        for (; j + 7 * 64 < wg; j += 8 * 64) {
-            int64_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = group_sums[j + u * 64];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) p += v[u];
-        }
-        for (; j < wg; j += 64) p += group_sums[j];
-        const int64_t k = wg * kWavesPerBlock + lane;
-        if (lane < kWavesPerBlock && k < w_) p += tile_offs[k];
-        dst = wave_sum_i64(p);
-        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst + tile_offs[w_]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
-    } else if (mode == 2) {
-        const int64_t g = w_ >> 6;
-        int64_t p = 0;
-        for (int64_t j = lane; j < g; j += 64) p += group_sums[j];
-        dst = wave_sum_i64(p) + tile_offs[w_];
-        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst - tile_offs[w_] + group_sums[g]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
-    } else {
-        dst = tile_offs[w_];
-    }
-    if (!o_keys || rb >= re) return;
-    // Walk the mask pass's chunks of this wave's range.  What is read per sample: the bit planes (0.5 byte), t_starts / t_ends as
-    // aligned vectors, and the KEY ONLY AT RAY HEADS (keys are constant along a ray: every other element takes the key of the
-    // nearest head before it — from its own lane, from a lower lane through ds_bpermute, or from the previous chunk) instead of
-    // 8 bytes for every sample.  Chunks without a survivor (the cut-off tails of opaque rays) are skipped without a load.
     constexpr int64_t CH = 64 * E;
-    const int64_t tile_end = (w_ + 1) * tile;
+    const int lane = lane_id();
     int64_t carry_key = 0;
     for (int64_t base = (rb / CH) * CH; base < re; base += CH) {
         const uint64_t *pw = planes + vis_plane_words<E>(base, base < tile_end ? 0 : 1);
@@ -369,6 +322,58 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     }
 }
 
+// 3) stream compaction with ballot ranks.  Where a wave's survivors go:
+//   mode 0  tile_offs[w] is the global exclusive prefix (single-workgroup scan, huge inputs only)
+//   mode 1  fused form for up to kVisFusedTiles tiles (every training-size call): tile_offs holds the
+//           tile COUNTS and each wave sums the ones before its own (<= 64 L2 loads per lane)
+//   mode 2  tile_offs holds the prefix inside the wave's group of 64 tiles (kernel 2) and group_sums the
+//           group totals: the wave adds the totals of the groups before its own
+// The last wave stores the total in modes 1 and 2.
+constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
+constexpr int64_t kVisOnePassChunks = 4;               // chunks (64 E samples) per tile of that form
+template <int E>
+__global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
+    const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
+    const uint64_t *__restrict__ planes, const int64_t *__restrict__ tile_offs, const int64_t *__restrict__ group_sums,
+    const int64_t *__restrict__ tile_rng, int mode, int64_t n, int64_t tile, int64_t n_tiles, int64_t *__restrict__ n_out, int64_t stamp,
+    int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
+{
+    const int64_t w_ = wave_index();
+    if (w_ >= n_tiles) return;
+    const int lane = lane_id();
+    const int64_t rb = readfirstlane_i64(tile_rng[2 * w_]), re = readfirstlane_i64(tile_rng[2 * w_ + 1]);
+    int64_t dst;
+    if (mode == 1) {
+        // group_sums holds the survivors per WORKGROUP of the mask pass here: add up the workgroups before this wave's, then
+        // the tiles of its own workgroup before it (<= 1024 + 3 loads per wave instead of <= 4096, eight in flight)
+        const int64_t wg = w_ / kWavesPerBlock;
+        int64_t p = 0;
+        int64_t j = lane;
+        for (; j + 7 * 64 < wg; j += 8 * 64) {
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = group_sums[j + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p += v[u];
+        }
+        for (; j < wg; j += 64) p += group_sums[j];
+        const int64_t k = wg * kWavesPerBlock + lane;
+        if (lane < kWavesPerBlock && k < w_) p += tile_offs[k];
+        dst = wave_sum_i64(p);
+        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst + tile_offs[w_]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
+    } else if (mode == 2) {
+        const int64_t g = w_ >> 6;
+        int64_t p = 0;
+        for (int64_t j = lane; j < g; j += 64) p += group_sums[j];
+        dst = wave_sum_i64(p) + tile_offs[w_];
+        if (w_ == n_tiles - 1 && lane == 0) { *n_out = dst - tile_offs[w_] + group_sums[g]; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
+    } else {
+        dst = tile_offs[w_];
+    }
+    if (!o_keys || rb >= re) return;
+    vis_compact_range<E>(keys, ts, te, planes, rb, re, (w_ + 1) * tile, dst, n, o_keys, o_ts, o_te);
+}
+
 // ----------------------------------------------------------------------------------------
 // The one-pass form of the filter (option vis_onepass = 1; never chosen automatically: on MI355X it measures 1.3-1.7x SLOWER than
 // the three kernels above although it moves a third fewer bytes — every tile waits for the slowest of the ~1000 tile groups in
@@ -440,7 +445,11 @@ __device__ __forceinline__ int64_t vis_lookback(const uint64_t *__restrict__ st,
 #ifndef NFA_VIS_EXP
 #define NFA_VIS_EXP 0          // timing experiments only (results are wrong): 2 no look-back, 4 no staging / no flush
 #endif
-template <int E>
+// STATIC (round 6, the form small calls take — nfa_visibility_compact_sync): one tile group per workgroup by its id, every
+// workgroup resident at once (the host launches it only then), the states in the caller's sync block (lookback.hpp: bounded waits,
+// left zero) — no ticket counter, no memset in front of the launch, no persistent loop.  n_out[0] = -1: the look-back gave up, nothing
+// was stored.
+template <int E, bool STATIC = false>
 __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, float eps, float alpha_thre,
@@ -460,14 +469,17 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
 #define L_KEYS(j) (*(int64_t *)(vis_smem + img + 8u * (uint32_t)(j)))
 #define L_TS(j) (*(float *)(vis_smem + img + 8u * (uint32_t)cap + 4u * (uint32_t)(j)))
 #define L_TE(j) (*(float *)(vis_smem + img + 12u * (uint32_t)cap + 4u * (uint32_t)(j)))
-    if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ctr, 1ull);
-    __syncthreads();
-    unsigned long long t = s_ticket[0];
+    unsigned long long t = blockIdx.x;
+    if constexpr (!STATIC) {
+        if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ctr, 1ull);
+        __syncthreads();
+        t = s_ticket[0];
+    }
     // the workgroup stays: it draws the next ticket while it works on the current one (the atomic's round trip is hidden)
     for (int it = 0; t < (unsigned long long)n_groups; ++it) {
         const int par = it & 1;
-        unsigned long long nxt = 0;
-        if (threadIdx.x == 0) nxt = atomicAdd(ctr, 1ull);
+        unsigned long long nxt = ~0ull;
+        if constexpr (!STATIC) { if (threadIdx.x == 0) nxt = atomicAdd(ctr, 1ull); }
         const int64_t w = (int64_t)t * kWavesPerBlock + wv;
 
         int cnt = 0;                       // survivors in the LDS image
@@ -525,7 +537,16 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
             [](int64_t) {});
         if (lane == 0) s_kept[par][wv] = kept;
         __syncthreads();
-        if (wv == 0) {                      // one state per workgroup: the four tiles' survivors
+        if (STATIC && wv == 0) {
+            const int64_t tot = s_kept[par][0] + s_kept[par][1] + s_kept[par][2] + s_kept[par][3];
+            const int64_t excl = sync_publish_and_lookback(state, (int64_t)t, tot, 0, 0, lane);
+            if (lane == 0) {
+                s_excl[par] = excl;
+                s_ticket[par ^ 1] = nxt;
+                if ((int64_t)t == n_groups - 1) { *n_out = excl < 0 ? -1 : excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
+            }
+            sync_leave(state, n_groups, lane);
+        } else if (wv == 0) {               // one state per workgroup: the four tiles' survivors
             const int64_t tot = s_kept[par][0] + s_kept[par][1] + s_kept[par][2] + s_kept[par][3];
             if (lane == 0) __hip_atomic_store(st + t, ((uint64_t)kVisStateAgg << 62) | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int64_t excl = (NFA_VIS_EXP & 2) ? (int64_t)((t * kWavesPerBlock * tile) % (uint64_t)(n / 2)) : vis_lookback(st, (int64_t)t, lane);
@@ -538,6 +559,7 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
         }
         __syncthreads();
         int64_t dst = s_excl[par];
+        if (STATIC && dst < 0) return;
 #pragma unroll
         for (int k = 0; k < kWavesPerBlock - 1; ++k) dst += k < wv ? s_kept[par][k] : 0;
         if (NFA_VIS_EXP & 4) cnt = 0;
@@ -654,11 +676,52 @@ __global__ __launch_bounds__(kBlock) void fill_rays_kernel(int64_t n_rays, const
 
 template <int E>
 struct RenderFwdIn { float t0[E], t1[E], sg[E], rgb[E][3]; static constexpr bool kStreamKeys = true; };
+// The rays WITHOUT a sample get (background, 0, 0) in the same launch (round 6; a launch of its own before — fill_rays_kernel, still
+// what calls without samples and calls beyond kFillFoldMaxSamples take): ray_indices ascend (this entry point's contract: the
+// reference builds its chunk starts in ray order, pack.py:38-46), so the rays without a sample are the gaps between consecutive
+// keys, before the first and behind the last.  Workgroups main_blocks ... gridDim.x - 1 of the launch do nothing else: they stream
+// over the keys once more (8 of the call's 60 bytes per sample — why large calls keep the separate launch, whose few microseconds
+// do not matter there), a lane fills a gap of up to two rays in front of its element, the wave together a longer one.  The walk
+// of the other workgroups is untouched: filling the gaps at its ray heads costs 20 VGPRs there (69 -> 89 at two samples per lane).
+constexpr int64_t kFillFoldMaxSamples = (int64_t)1 << 20;
+__device__ __forceinline__ void fill_ray_gaps(const int64_t *__restrict__ keys, int64_t n, int64_t n_rays, int64_t block, int64_t n_blocks,
+                                              float bk0, float bk1, float bk2, float *__restrict__ colors, float *__restrict__ opac,
+                                              float *__restrict__ depth)
+{
+    const int lane = lane_id();
+    auto ray_empty = [&](int64_t r) {
+        colors[3 * r] = bk0; colors[3 * r + 1] = bk1; colors[3 * r + 2] = bk2;
+        opac[r] = 0.0f;
+        depth[r] = 0.0f;
+    };
+    const int64_t stride = n_blocks * kBlock;
+    // element i closes the gap (keys[i - 1], keys[i]); "element n" the one behind the last key
+    for (int64_t i0 = block * kBlock; i0 <= n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        int64_t a = 0, b = 0;
+        if (i <= n) {
+            a = i > 0 ? keys[i - 1] + 1 : 0;
+            b = i < n ? keys[i] : n_rays;
+            a = a < 0 ? 0 : a;
+            b = b > n_rays ? n_rays : b;
+        }
+        if (a < b) ray_empty(a);
+        if (a + 1 < b) ray_empty(a + 1);
+        unsigned long long m = __ballot(a + 2 < b);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t a0 = readlane_i64_dyn(a, l) + 2, b0 = readlane_i64_dyn(b, l);
+            for (int64_t r = a0 + lane; r < b0; r += 64) ray_empty(r);
+        }
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ sigmas, const float *__restrict__ rgbs, int64_t n, int64_t tile, int spec, int64_t n_rays,
-    const float *__restrict__ bkgd, int expected_depths,
+    const float *__restrict__ bkgd, int expected_depths, int main_blocks,
     float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ alphas,
     float *__restrict__ colors, float *__restrict__ opac, float *__restrict__ depth)
 {
@@ -666,6 +729,10 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
     float c_sd = 0.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, c_w = 0.f, c_m = 0.f;
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
+    if ((int)blockIdx.x >= main_blocks) {
+        fill_ray_gaps(keys, n, n_rays, (int64_t)blockIdx.x - main_blocks, (int64_t)gridDim.x - main_blocks, bk0, bk1, bk2, colors, opac, depth);
+        return;
+    }
     auto ray_out = [&](int64_t key, float sr, float sg, float sb, float sw, float sm) {
         if (key < 0 || key >= n_rays) return;
         const float rem = 1.0f - sw;
@@ -991,11 +1058,52 @@ NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t
                                           out_t_starts, out_t_ends, out_mask, n_out, 0, workspace, stream);
 }
 
+static int visibility_compact_impl(const int64_t *ray_indices, const float *t_starts, const float *t_ends, const float *dens, int32_t from_alpha,
+                                   int64_t n, float early_stop_eps, float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
+                                   float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace, void *sync, int resume,
+                                   void *stream);
+
+static bool vis_fusable(int64_t n, const TilePlan &pl) {
+    if (n <= 0 || opt(OPT_FUSED_VIS, 0) == 0 || opt(OPT_VIS_ONEPASS, 0) != 0) return false;
+    const int64_t T = ceil_div(n, pl.tile), n_wg = tile_blocks(n, pl.tile);
+    return T <= kVisFusedTiles && n_wg <= 3 * kNumCU && n_wg <= kSyncMaxBlocks;
+}
+// does nfa_visibility_compact_sync take its single-launch form for n samples (pointers 16-byte aligned or not)?
+NFA_EXPORT int nfa_visibility_compact_fused(int64_t n, int32_t aligned16_ptrs) { return vis_fusable(n, pick_plan(n, aligned16_ptrs != 0)) ? 1 : 0; }
+
 NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                                               const float *dens, int32_t from_alpha, int64_t n, float early_stop_eps,
                                               float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
                                               float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace,
                                               void *stream)
+{
+    return visibility_compact_impl(ray_indices, t_starts, t_ends, dens, from_alpha, n, early_stop_eps, alpha_thre, out_ray_indices, out_t_starts,
+                                   out_t_ends, out_mask, n_out, stamp, workspace, nullptr, 0, stream);
+}
+
+NFA_EXPORT int nfa_visibility_compact_sync(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                           const float *dens, int32_t from_alpha, int64_t n, float early_stop_eps,
+                                           float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
+                                           float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace,
+                                           void *sync, void *stream)
+{
+    return visibility_compact_impl(ray_indices, t_starts, t_ends, dens, from_alpha, n, early_stop_eps, alpha_thre, out_ray_indices, out_t_starts,
+                                   out_t_ends, out_mask, n_out, stamp, workspace, sync, 0, stream);
+}
+
+NFA_EXPORT int nfa_visibility_compact_resume(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                             const float *dens, int32_t from_alpha, int64_t n, float early_stop_eps,
+                                             float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
+                                             float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace, void *stream)
+{
+    return visibility_compact_impl(ray_indices, t_starts, t_ends, dens, from_alpha, n, early_stop_eps, alpha_thre, out_ray_indices, out_t_starts,
+                                   out_t_ends, out_mask, n_out, stamp, workspace, nullptr, 1, stream);
+}
+
+static int visibility_compact_impl(const int64_t *ray_indices, const float *t_starts, const float *t_ends, const float *dens, int32_t from_alpha,
+                                   int64_t n, float early_stop_eps, float alpha_thre, int64_t *out_ray_indices, float *out_t_starts,
+                                   float *out_t_ends, uint8_t *out_mask, int64_t *n_out, int64_t stamp, void *workspace, void *sync, int resume,
+                                   void *stream)
 {
     NFA_REQUIRE(n >= 0, "visibility_compact: n < 0");
     NFA_REQUIRE(n_out != nullptr, "visibility_compact: n_out is NULL");
@@ -1007,7 +1115,7 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
     const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, dens, out_mask}));
     // the one-pass form (see visibility_onepass_kernel): opt-in only — measured SLOWER than the kernels below at every size
     // (profiles/r05_streaming.md section 3)
-    if (out_ray_indices && pl.e <= 2 && opt(OPT_VIS_ONEPASS, 0) != 0) {
+    if (out_ray_indices && pl.e <= 2 && resume == 0 && opt(OPT_VIS_ONEPASS, 0) != 0) {
         const int64_t ch = 64 * pl.e;
         const int64_t chunks = opt(OPT_VIS_CHUNKS, kVisOnePassChunks);
         const int64_t otile = chunks * ch, OT = ceil_div(n, otile);
@@ -1031,6 +1139,29 @@ NFA_EXPORT int nfa_visibility_compact_stamped(const int64_t *ray_indices, const 
     int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + vis_front_bytes(n));
     int64_t *tile_offs = tile_cnts + T, *tile_rng = tile_offs + T;
     const int mode = T <= kVisFusedTiles ? 1 : (T <= kVisGroupedTiles ? 2 : 0);
+    // The single-launch form (`fused_vis` = 1, opt-in): the static one-pass kernel — every workgroup resident at once, a state per
+    // workgroup in the sync block, survivors staged in LDS and flushed behind the look-back.  Measured at the training size
+    // (profiles/r06_small_n.md): 19.5 us against 9.2 + 6.9 for the two kernels below — publishing a count and polling the counts of
+    // the workgroups before it costs two memory-side round trips (agent-scope atomics: the XCDs' L2s are not coherent), more than
+    // the kernel boundary it replaces.  Not taken automatically.
+    if (sync && resume == 0 && out_ray_indices && pl.e <= 2 && vis_fusable(n, pl)) {
+        const int64_t ch = 64 * pl.e;
+        // tiles of one chunk while that keeps the launch at two workgroups per CU or fewer, longer tiles beyond
+        int64_t chunks = ceil_div(n, ch * kWavesPerBlock * 2 * kNumCU);
+        chunks = chunks < 1 ? 1 : (chunks > kVisOnePassChunks ? kVisOnePassChunks : chunks);
+        const int64_t otile = chunks * ch, OT = ceil_div(n, otile), groups = ceil_div(OT, kWavesPerBlock);
+        const int cap = (int)(otile + ch);
+        uint8_t *ov_mask = out_mask ? out_mask : (uint8_t *)workspace;
+        const size_t lds = (size_t)kWavesPerBlock * cap * 16;
+        if (groups <= 3 * kNumCU && groups <= kSyncMaxBlocks) {
+            const dim3 g((unsigned)groups), b(kBlock);
+            if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2, true>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+                                              early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+            else hipLaunchKernelGGL((visibility_onepass_kernel<1, true>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+                                    early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+            return check_launch("visibility_onepass_kernel<static>");
+        }
+    }
     NFA_LAUNCH_TILED(visibility_mask_kernel, pl, n, s, ray_indices, t_starts, t_ends,
                      dens, from_alpha, n, tile, pl.spec, early_stop_eps, alpha_thre, out_mask, planes, tile_cnts, tile_rng,
                      mode == 1 ? tile_offs : (int64_t *)nullptr);      // (mode 1: the otherwise unused second quarter of the workspace)
@@ -1104,13 +1235,22 @@ NFA_EXPORT int nfa_rendering_fwd(const int64_t *ray_indices, const float *t_star
     if (n_rays == 0) return NFA_OK;
     NFA_REQUIRE(colors && opacities && depths, "rendering_fwd: NULL per-ray output");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fill_rays_kernel, dim3(blocks_for(n_rays)), dim3(kBlock), 0, s, n_rays, bkgd, colors, opacities, depths);
-    if (int rc = check_launch("fill_rays_kernel")) return rc;
+    const bool fold = n > 0 && n <= kFillFoldMaxSamples && opt(OPT_FOLD_FILL, 1) != 0;
+    if (!fold) {       // (n = 0: nothing but rays without a sample)
+        hipLaunchKernelGGL(fill_rays_kernel, dim3(blocks_for(n_rays)), dim3(kBlock), 0, s, n_rays, bkgd, colors, opacities, depths);
+        if (int rc = check_launch("fill_rays_kernel")) return rc;
+    }
     if (n == 0) return NFA_OK;
     NFA_REQUIRE(ray_indices && t_starts && t_ends && sigmas && rgbs && weights && trans && alphas, "rendering_fwd: NULL pointer");
     const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, sigmas, rgbs, weights, trans, alphas}));
-    NFA_LAUNCH_TILED(rendering_fwd_kernel, pl, n, s, ray_indices, t_starts, t_ends,
-                     sigmas, rgbs, n, pl.tile, pl.spec, n_rays, bkgd, expected_depths, weights, trans, alphas, colors, opacities, depths);
+    const unsigned main_blocks = tile_blocks(n, pl.tile);
+    // the gap workgroups: four keys per thread, at most one workgroup per CU
+    const unsigned gap_blocks = fold ? (unsigned)std::min<int64_t>(kNumCU, ceil_div(n + 1, 4 * kBlock)) : 0u;
+    const dim3 g_(main_blocks + gap_blocks), b_(kBlock);
+#define NFA_RENDER_FWD(EE) hipLaunchKernelGGL((rendering_fwd_kernel<EE>), g_, b_, 0, s, ray_indices, t_starts, t_ends, sigmas, rgbs, n, pl.tile, pl.spec, n_rays, \
+                                              bkgd, expected_depths, (int)main_blocks, weights, trans, alphas, colors, opacities, depths)
+    if (pl.e == 4) NFA_RENDER_FWD(4); else if (pl.e == 2) NFA_RENDER_FWD(2); else NFA_RENDER_FWD(1);
+#undef NFA_RENDER_FWD
     return check_launch("rendering_fwd_kernel");
 }
 

@@ -251,12 +251,15 @@ constexpr bool kNoLateStage = true;
 #else
 constexpr bool kNoLateStage = false;
 #endif
-template <bool LDS_OCC, int P, int CAP, int BLK = kBlock, bool XT = false>
+// FUSE: the kernel is the whole sampling call — offsets by look-back over the workgroups and the emit pass of every wave's own rays
+// behind the count (sample_fused.hpp; `fz` is only read then).
+template <bool LDS_OCC, int P, int CAP, int BLK = kBlock, bool XT = false, bool FUSE = false>
 __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_args a, GridView gv,
-                                                                   int64_t *__restrict__ block_sums, RunStore rs)
+                                                                   int64_t *__restrict__ block_sums, RunStore rs, FuseArgs fz)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NFA_PHASE_BEGIN();
+    if constexpr (FUSE) { NFA_FUSE_STAMP(0); }
     const int tid = threadIdx.x, part = tid % P;
     const int64_t R = a.n_rays;
     const int64_t r = (int64_t)blockIdx.x * ((int)blockDim.x / P) + tid / P;      // (blockDim.x <= BLK: the crossing-time form may be launched narrower, grid.hip: split_launch_threads)
@@ -669,7 +672,8 @@ __global__ __launch_bounds__(BLK) void traverse_count_split_kernel(nfa_traverse_
         a.sm_cnts[r] = out_sm;
     }
     NFA_PHASE_MARK(7);
-    publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);      // this wave's 64 / P rays
+    if constexpr (FUSE) fused_sample_tail<BLK, P>(a, rs, fz, smem, block_sums, r, ray_ok && part == 0, out_iv, out_sm, out_ovf);
+    else publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);      // this wave's 64 / P rays
     NFA_PHASE_MARK(8);
     NFA_PHASE_END();
 }

@@ -499,6 +499,7 @@ struct Rows {
     Tensor buf;
     int64_t pitch, n;
     Rows(int64_t k, int64_t n_, const at::TensorOptions &o) : pitch((n_ + 3) & ~int64_t(3)), n(n_) { buf = at::empty({k, pitch}, o); }
+    Rows(Tensor adopted, int64_t n_) : buf(std::move(adopted)), pitch(buf.size(1)), n(n_) {}      // a [k, pitch] tensor allocated ahead
     float *p(int64_t r) const { return buf.data_ptr<float>() + r * pitch; }
     Tensor row(int64_t r) const { return buf[r].narrow(0, 0, n); }
 };
@@ -523,6 +524,34 @@ Tensor traverse_workspace(const Tensor &like, hipStream_t s, int64_t bytes) {
 }
 // drops this host thread's retained slabs (and with them any count pass launched ahead: its records lived there)
 void release_workspace();
+
+// The sync block of the single-launch forms (include/nerfacc_hip.h: NFA_SYNC_BYTES, zero before its first use, left zero by every
+// kernel that uses it): one per (host thread, device, stream), allocated zero-filled once.  Everything that touches it is enqueued
+// on that one stream, in order.
+SlabMap &sync_blocks() {
+    thread_local SlabMap blocks;
+    return blocks;
+}
+// Outputs of the NEXT single-launch sampling call of the same kind, allocated while the current call's launch is counting: the
+// single launch needs its outputs to exist before it starts (the three-kernel form allocates them behind the count kernel's launch,
+// for free), and two allocations in front of the launch are 4-5 us on the step's critical path — host wake-up to host wake-up is what
+// bounds a training step at this size (tools/path_ab.py).  One set per (host thread, device, kind of call), at most kNextOutKeep bytes.
+constexpr int64_t kNextOutKeep = 64ll << 20;
+struct NextOut {
+    Tensor ray_indices, rows;      // [cap] int64, [2, pitch] float
+    int64_t cap = 0;
+    hipStream_t stream = nullptr;
+};
+std::map<int, NextOut> &next_outputs() {
+    thread_local std::map<int, NextOut> m;
+    return m;
+}
+
+void *sync_block(const Tensor &like, hipStream_t s) {
+    Tensor &t = sync_blocks()[{(int)like.device().index(), s}];
+    if (!t.defined()) t = at::zeros({(int64_t)NFA_SYNC_BYTES}, opts(like, at::kByte));
+    return t.data_ptr();
+}
 
 // The reference's eval loop (examples/utils.py:80-88) calls `estimator.sampling` on consecutive 8192-ray SLICES of one ray array, and
 // every call has to wait for its count pass before it can size its outputs (~40 us of 205 per chunk with the host idle, profiles/
@@ -573,6 +602,8 @@ ChunkPrefetch &chunk_prefetch(int device, hipStream_t s) {
 void release_workspace() {
     prefetch_slots().clear();
     workspace_slabs().clear();
+    sync_blocks().clear();
+    next_outputs().clear();
 }
 inline bool chunk_prefetch_allowed() {
     int64_t v = 1;
@@ -627,22 +658,10 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         term = near_planes->clone();
         a.terminate_planes = ptr<float>(term);
     }
-    int64_t stamp;
-    if (taken) {
-        stamp = pf_stamp;                             // count and offsets of exactly this call ran behind the previous one
-    } else {
-        {
-            Timed t("traverse_count", s);
-            check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
-        }
-        stamp = next_stamp();
-        h[3] = 0;
-        check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
-    }
-    // The emit pass is launched BEFORE the read-back, into outputs sized from the previous call on this device (training
-    // steps draw about the same number of samples every time): the GPU goes from the offsets kernel straight into it
+    // The emit pass runs BEFORE the read-back, into outputs sized from the previous call on this device (training
+    // steps draw about the same number of samples every time): the GPU goes from counting straight into it
     // instead of idling through the host's wake-up, allocation and launch (16 us, tools/step_timeline.py), and the host —
-    // released by the offsets kernel's stamp, not by the end of the emit pass — prepares the caller's next kernels while it
+    // released by the stamp behind the totals, not by the end of the emit pass — prepares the caller's next kernels while it
     // runs.  A guess that is too small costs nothing but the second launch the old order always needed.
     // The guess is SAMPLES PER RAY of the previous call of the same kind on this device (training batches, eval chunks and
     // marcher rounds differ by orders of magnitude in size but much less in samples per ray), times this call's ray count.
@@ -651,21 +670,84 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
     const bool speculate = R > 0 && last_spr.count(dev) && last_spr[dev] > 0.0 && speculative_emit_allowed();
     int64_t cap = speculate ? (int64_t)(1.25 * last_spr[dev] * (double)R) + 1024 : 0;
     Tensor ray_indices;
-    Rows ts(2, cap, f32);
-    a.terminate_planes = nullptr;                     // written by the count pass only
-    if (speculate) {
+    Rows ts(2, 0, f32);
+    auto speculative_outputs = [&]() {
+        ts = Rows(2, cap, f32);
+        if (!speculate) return;
         ray_indices = at::empty({cap}, i64);
         a.sm_ray_indices = ptr<int64_t>(ray_indices);
         a.t_starts = ts.p(0);
         a.t_ends = ts.p(1);
-        Timed t("traverse_fill", s);
-        check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
+    };
+    int64_t stamp;
+    if (taken) {
+        stamp = pf_stamp;                             // count and offsets of exactly this call ran behind the previous one
+        speculative_outputs();
+        a.terminate_planes = nullptr;
+        if (speculate) {
+            Timed t("traverse_fill", s);
+            check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
+        }
+    } else if (nfa_traverse_sample_fused(&a)) {
+        // ONE launch counts, forms the offsets (look-back over the count kernel's workgroups) and expands every wave's own rays
+        // (round 6; three launches before): the outputs have to exist first — normally they do, allocated behind the previous
+        // call's launch (next_outputs)
+        NextOut &no = next_outputs()[dev];
+        if (speculate && no.ray_indices.defined() && no.stream == s && no.cap >= cap && no.cap <= 2 * cap + 4096) {
+            cap = no.cap;
+            ray_indices = std::move(no.ray_indices);
+            ts = Rows(std::move(no.rows), cap);
+            a.sm_ray_indices = ptr<int64_t>(ray_indices);
+            a.t_starts = ts.p(0);
+            a.t_ends = ts.p(1);
+        } else {
+            speculative_outputs();
+        }
+        no = NextOut{};
+        stamp = next_stamp();
+        h[3] = 0;
+        int32_t did = 0;
+        {
+            Timed t("traverse_sample", s);
+            check_rc(nfa_traverse_sample(&a, ws.data_ptr(), cap, stamp, sync_block(rays_o, s), &did, s));
+        }
+        a.terminate_planes = nullptr;                 // written by the count pass only
+        if (speculate && 16 * cap <= kNextOutKeep) {  // (while the launch counts)
+            no.cap = cap;
+            no.stream = s;
+            no.ray_indices = at::empty({cap}, i64);
+            no.rows = at::empty({2, (cap + 3) & ~int64_t(3)}, f32);
+        }
+    } else {
+        {
+            Timed t("traverse_count", s);
+            check_rc(nfa_traverse_count(&a, ws.data_ptr(), s));
+        }
+        stamp = next_stamp();
+        h[3] = 0;
+        check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
+        speculative_outputs();                        // (allocated while the count pass runs)
+        a.terminate_planes = nullptr;                 // written by the count pass only
+        if (speculate) {
+            Timed t("traverse_fill", s);
+            check_rc(nfa_traverse_emit_speculative(&a, ws.data_ptr(), cap, s));
+        }
     }
     if (R > 0) wait_stamp(h + 3, stamp, s);
     else wait_stream(s);
+    bool emitted = speculate;
+    if (R > 0 && h[1] < 0) {
+        // the fused launch's look-back gave up (a bounded wait: include/nerfacc_hip.h); counts and run records are complete —
+        // offsets by their own kernel, emit pass below
+        stamp = next_stamp();
+        h[3] = 0;
+        check_rc(nfa_traverse_offsets_stamped(&a, ws.data_ptr(), stamp, s));
+        wait_stamp(h + 3, stamp, s);
+        emitted = false;
+    }
     const int64_t n = h[1], n_overflow = h[2];
     last_spr[dev] = R > 0 ? (double)n / (double)R : 0.0;
-    if (speculate && n <= cap) {
+    if (emitted && n <= cap) {
         if (n_overflow > 0) check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), 0, n_overflow, s));     // the rays the count pass flagged
         ray_indices = ray_indices.narrow(0, 0, n);
         ts.n = n;
@@ -700,23 +782,25 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
             return ((int64_t)t.storage().nbytes() - used) / 12;
         };
         const int64_t Rn = std::min<int64_t>(R, std::min(rows_left(rays_o), rows_left(rays_d)));
-        if (continued && Rn > 0 && chunk_prefetch_allowed()) {
-            nfa_traverse_args a2 = a;
-            a2.n_rays = Rn;
-            a2.rays_o = o_end;
-            a2.rays_d = d_end;
-            a2.sm_ray_indices = nullptr; a2.t_starts = nullptr; a2.t_ends = nullptr; a2.terminate_planes = nullptr;
+        nfa_traverse_args a2 = a;
+        a2.n_rays = Rn;
+        a2.rays_o = o_end;
+        a2.rays_d = d_end;
+        a2.sm_ray_indices = nullptr; a2.t_starts = nullptr; a2.t_ends = nullptr; a2.terminate_planes = nullptr;
+        if (Rn > 0) a2.workspace_bytes = nfa_traverse_workspace_bytes_for(&a2);
+        // (a slice whose workspace is beyond what a thread retains gets a per-call allocation: a guess would pin it between calls and
+        //  behind the loop's last slice — exactly what the cap is there to prevent, ADVICE r5: no count pass ahead for such slices)
+        if (continued && Rn > 0 && chunk_prefetch_allowed() && a2.workspace_bytes <= kWorkspaceKeep) {
             pf.packed = at::empty({2, Rn}, i64);
             a2.sm_starts = ptr<int64_t>(pf.packed);
             a2.sm_cnts = ptr<int64_t>(pf.packed) + Rn;
             int64_t *h2 = host_ints(rays_o.device().index(), s, 1);
             a2.totals = h2;
-            a2.workspace_bytes = nfa_traverse_workspace_bytes_for(&a2);
             Tensor ws2 = traverse_workspace(rays_o, s, a2.workspace_bytes);      // (the same slab: this call's kernels are enqueued before)
-            check_rc(nfa_traverse_count(&a2, ws2.data_ptr(), s));
             pf.stamp = next_stamp();
             h2[3] = 0;
-            check_rc(nfa_traverse_offsets_stamped(&a2, ws2.data_ptr(), pf.stamp, s));
+            // count + offsets of the next slice: one launch where the fused form exists (capacity 0: nothing is expanded), else two
+            check_rc(nfa_traverse_sample(&a2, ws2.data_ptr(), 0, pf.stamp, sync_block(rays_o, s), nullptr, s));
             pf.o_ptr = o_end; pf.d_ptr = d_end; pf.R = Rn;
             pf.o_ver = rays_o._version(); pf.d_ver = rays_d._version();
             pf.bin_impl = (const void *)binaries.unsafeGetTensorImpl(); pf.bin_ver = binaries._version();
@@ -1013,12 +1097,22 @@ py::tuple visibility_compact(const Tensor &ray_indices, const Tensor &t_starts, 
     {
         Timed t("visibility", s);
         h[1] = 0;
-        check_rc(nfa_visibility_compact_stamped(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha,
-                                                n, (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
-                                                ptr<uint8_t>(mask), h, stamp, ws.data_ptr(), s));
+        // (one launch at the training size: mask pass, look-back over its workgroups and compaction — include/nerfacc_hip.h)
+        check_rc(nfa_visibility_compact_sync(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha,
+                                             n, (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
+                                             ptr<uint8_t>(mask), h, stamp, ws.data_ptr(), n > 0 ? sync_block(dens, s) : nullptr, s));
     }
     if (n > 0) wait_stamp(h + 1, stamp, s);
     else wait_stream(s);
+    if (n > 0 && h[0] < 0) {
+        // the single launch's look-back gave up (a bounded wait): the compaction kernel over what it left in the workspace
+        const int64_t stamp2 = next_stamp();
+        h[1] = 0;
+        check_rc(nfa_visibility_compact_resume(ptr<int64_t>(ray_indices), ptr<float>(t_starts), ptr<float>(t_ends), ptr<float>(dens), from_alpha,
+                                               n, (float)early_stop_eps, (float)alpha_thre, ptr<int64_t>(o_idx), o_t.p(0), o_t.p(1),
+                                               ptr<uint8_t>(mask), h, stamp2, ws.data_ptr(), s));
+        wait_stamp(h + 1, stamp2, s);
+    }
     const int64_t k = n > 0 ? h[0] : 0;
     py::object m = want_mask ? py::cast(mask) : py::none();
     return py::make_tuple(o_idx.narrow(0, 0, k), o_t.row(0).narrow(0, 0, k), o_t.row(1).narrow(0, 0, k), m);

@@ -87,6 +87,12 @@ def _call(name, fn, *args):
     return _timer.bracket(name, fn, *args)
 
 
+def _missing_entry(name: str):
+    def stub(*_a):
+        raise RuntimeError(f"nerfacc_amd: the library named by NERFACC_AMD_LIB ({LIB_PATH}) does not export {name}")
+    return stub
+
+
 def load_library() -> ctypes.CDLL:
     """dlopen the C-ABI library and attach prototypes.  Raises if it has not been built."""
     global _lib
@@ -99,12 +105,22 @@ def load_library() -> ctypes.CDLL:
                 "`python -m nerfacc_amd.build` (needs hipcc; there is no CPU fallback)."
             )
         lib = ctypes.CDLL(LIB_PATH)
+        missing = []
         for name, (res, args) in _SIGNATURES.items():
             if os.environ.get("NERFACC_AMD_LIB") and not hasattr(lib, name):
-                continue             # an explicitly named variant build (A/B against an older source tree) may predate an entry point
+                # an explicitly named variant build (A/B against an older source tree) may predate an entry point: it loads, says
+                # so once, and a call of the missing entry point fails with its name
+                missing.append(name)
+                setattr(lib, name, _missing_entry(name))
+                continue
             fn = getattr(lib, name)  # AttributeError => the header and the library disagree
             fn.restype = res
             fn.argtypes = args
+        if missing:
+            import warnings
+
+            warnings.warn(f"nerfacc_amd: {LIB_PATH} lacks {len(missing)} entry point(s) declared in include/nerfacc_hip.h "
+                          f"({', '.join(missing[:6])}{' ...' if len(missing) > 6 else ''}): a stale or mismatched build", RuntimeWarning)
         _lib = lib
     return _lib
 
@@ -123,6 +139,23 @@ def _jit_build() -> None:
         build(force=False, verbose=False)
     except Exception as e:      # noqa: BLE001  (the caller raises ImportError with instructions)
         print(f"nerfacc_amd: build failed: {e}", flush=True)
+
+
+# sync blocks of the single-launch forms (include/nerfacc_hip.h: NFA_SYNC_BYTES, zero before first use, left zero): one per
+# (host thread, device, stream), like the extension's
+_NFA_SYNC_BYTES = 16384
+_tls = threading.local()
+_LAST_SPR: dict = {}
+
+
+def _sync_block(dev, stream) -> torch.Tensor:
+    blocks = getattr(_tls, "sync_blocks", None)
+    if blocks is None:
+        blocks = _tls.sync_blocks = {}
+    key = (dev.index, stream)
+    if key not in blocks:
+        blocks[key] = torch.zeros(_NFA_SYNC_BYTES, dtype=torch.uint8, device=dev)
+    return blocks[key]
 
 
 def _check(rc: int) -> None:
@@ -749,15 +782,41 @@ class _CtypesC:
                     raise RuntimeError("with_terminate_planes needs near_planes as a tensor")
                 term = near_planes.clone()
                 a.terminate_planes = _ptr(term)
-            _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
-            _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
-            _, n, n_overflow, _ = _read_ints(totals, dev)
-            ray_indices = torch.empty(n, **i64)
-            ts = _rows(2, n, dev)
-            a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
+            emitted, cap = False, 0
+            if R > 0 and L.nfa_traverse_sample_fused(ctypes.byref(a)):
+                # the whole call as ONE launch (round 6, include/nerfacc_hip.h: nfa_traverse_sample): outputs sized from this
+                # device's previous call (samples per ray), offsets by look-back inside the count kernel, every wave expands its rays
+                spr = _LAST_SPR.get(dev.index, 0.0)
+                cap = int(1.25 * spr * R) + 1024 if spr > 0 else 0
+                if cap:
+                    ray_indices = torch.empty(cap, **i64)
+                    ts = _rows(2, cap, dev)
+                    a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
+                _check(_call("traverse_sample", L.nfa_traverse_sample, ctypes.byref(a), _ptr(ws), cap, 0, _ptr(_sync_block(dev, stream)),
+                             None, stream))
+                _, n, n_overflow, _ = _read_ints(totals, dev)
+                emitted = cap > 0
+                if n < 0:                                # its look-back gave up (bounded wait): offsets by their own kernel
+                    _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
+                    _, n, n_overflow, _ = _read_ints(totals, dev)
+                    emitted = False
+            else:
+                _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
+                _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
+                _, n, n_overflow, _ = _read_ints(totals, dev)
+            if R > 0:
+                _LAST_SPR[dev.index] = n / R
             a.terminate_planes = None                    # written by the count pass only
-            if n > 0:
-                _check(_call("traverse_fill", L.nfa_traverse_fill, ctypes.byref(a), 1, 0, _ptr(ws), n, n_overflow, stream))
+            if emitted and n <= cap:
+                if n_overflow > 0:
+                    _check(L.nfa_traverse_fill(ctypes.byref(a), 1, 0, _ptr(ws), 0, n_overflow, stream))
+                ray_indices, ts = ray_indices[:n], (ts[0][:n], ts[1][:n])
+            else:
+                ray_indices = torch.empty(n, **i64)
+                ts = _rows(2, n, dev)
+                a.sm_ray_indices, a.t_starts, a.t_ends = _ptr(ray_indices), ts[0].data_ptr(), ts[1].data_ptr()
+                if n > 0:
+                    _check(_call("traverse_fill", L.nfa_traverse_fill, ctypes.byref(a), 1, 0, _ptr(ws), n, n_overflow, stream))
         if with_terminate_planes:
             return ray_indices, ts[0], ts[1], packed.t(), term
         return ray_indices, ts[0], ts[1], packed.t()
@@ -843,10 +902,15 @@ class _CtypesC:
         n_out = _host_ints(dev)
         ws = torch.empty(max(L.nfa_visibility_workspace_bytes(n), 16), dtype=torch.uint8, device=dev)
         with _Guard(dens):
-            _check(_call("visibility", L.nfa_visibility_compact, _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n,
-                                            early_stop_eps, alpha_thre, _ptr(o_idx), o_t[0].data_ptr(), o_t[1].data_ptr(),
-                                            _ptr(mask), _ptr(n_out), _ptr(ws), _stream(dens)))
-        k = _read_ints(n_out, dev)[0]
+            stream = _stream(dens)
+            args = (_ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), _ptr(dens), int(from_alpha), n, early_stop_eps, alpha_thre, _ptr(o_idx),
+                    o_t[0].data_ptr(), o_t[1].data_ptr(), _ptr(mask), _ptr(n_out), 0, _ptr(ws))
+            # one launch where the call is small enough (mask pass + look-back + compaction, include/nerfacc_hip.h)
+            _check(_call("visibility", L.nfa_visibility_compact_sync, *args, _ptr(_sync_block(dev, stream)) if n > 0 else None, stream))
+            k = _read_ints(n_out, dev)[0]
+            if k < 0:                                    # its look-back gave up (bounded wait): the compaction kernel alone
+                _check(L.nfa_visibility_compact_resume(*args, stream))
+                k = _read_ints(n_out, dev)[0]
         return o_idx[:k], o_t[0, :k], o_t[1, :k], mask
 
     @staticmethod

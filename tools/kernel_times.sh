@@ -8,5 +8,5 @@ import json
 d = json.loads(open("$D/line.json").read().strip().splitlines()[-1])
 print("ms_per_step", d["ms_per_step"], "rays/iter", d["config"].get("rays_per_iter_timed"), "samples/s", d.get("samples_per_sec"))
 PY
-python tools/kstats_top.py $(find $D -name "*kernel_stats.csv" | head -1) 60 | grep "nfa::"
+python tools/kernel_summary.py $D | grep "nfa::"
 rm -rf $D

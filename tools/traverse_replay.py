@@ -28,7 +28,7 @@ def call():
     return C.sample_occgrid(O, D, binaries, aabbs, None, None, step, 0.0, near_plane=0.0, far_plane=1e10, jitter=jit, jitter_scale=step)
 ri, ts, te, pk = call()
 torch.cuda.synchronize()
-timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill"))
+timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill", "traverse_sample"))
 _backend.set_kernel_timer(timer)
 gap_us = next((float(a.split("=")[1]) for a in sys.argv if a.startswith("--gap-us=")), 0.0)     # idle GPU time between calls (what a host-bound training loop leaves)
 t0 = time.perf_counter()
@@ -43,8 +43,9 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / reps
 summ = timer.summary()
 _backend.set_kernel_timer(None)
+us = lambda k: summ[k][1] * 1e3 if k in summ and summ[k][0] else float("nan")
 print(f"rays {O.shape[0]} candidates {ri.shape[0]} occupied {binaries.float().mean().item():.4f}  "
-      f"count {summ['traverse_count'][1]*1e3:.1f} us  emit {summ['traverse_fill'][1]*1e3:.1f} us  call wall {wall*1e6:.1f} us  "
+      f"count {us('traverse_count'):.1f} us  emit {us('traverse_fill'):.1f} us  fused count+offsets+emit {us('traverse_sample'):.1f} us  call wall {wall*1e6:.1f} us  "
       f"sums {int(ri.sum())} {float(ts.double().sum()):.9e} {float(te.double().sum()):.9e}")
 if "--check" in sys.argv:
     import oracle
