@@ -196,11 +196,17 @@ def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
     return rgb, opacity, depth, t_starts.shape[0]
 
 
+# candidate samples of the most recent estimator.sampling call of render_rays_reference_style (what its sigma_fn was handed: the
+# traversal's output before the visibility filter) — the timed steps add it up, no extra read-back
+LAST_CALL = {"candidates": 0}
+
+
 def render_rays_reference_style(field, est, rays_o, rays_d, bkgd, training: bool):
     """examples/utils.py:87-155 as written there: the user-side closures index the rays with plain torch ops
     (`rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0`); only nerfacc's own
     calls (`estimator.sampling`, `nerfacc.rendering`) reach this package."""
     def sigma_fn(t_starts, t_ends, ray_indices):
+        LAST_CALL["candidates"] = t_starts.shape[0]
         if t_starts.shape[0] == 0:
             return torch.empty((0,), device=t_starts.device)
         positions = rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
@@ -213,6 +219,7 @@ def render_rays_reference_style(field, est, rays_o, rays_d, bkgd, training: bool
         rgb, sigma = field(positions, rays_d[ray_indices])
         return rgb, sigma.squeeze(-1)
 
+    LAST_CALL["candidates"] = 0
     ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
                                                  render_step_size=RENDER_STEP, stratified=training, cone_angle=0.0,
                                                  alpha_thre=0.0)
@@ -770,7 +777,7 @@ def run(args):
     torch.manual_seed(1000 + rank)
 
     state = {"num_rays": fixed_rays or INIT_RAYS, "step": 0, "est": est}     # state["est"]: the estimator the step functions use
-    stats = {"rays": 0, "samples": 0}
+    stats = {"rays": 0, "samples": 0, "candidates": 0}
     side = torch.cuda.Stream(device=device)
 
     def next_num_rays(g_samples, g_rays):
@@ -806,6 +813,7 @@ def run(args):
         next_num_rays(*sharding.allreduce_counts_end(pending))
         stats["rays"] += n
         stats["samples"] += n_samples
+        stats["candidates"] += LAST_CALL["candidates"]
         state["step"] += 1
 
     # ---- same work, the next step's traversal overlapped with this step's backward pass ------------------------------
@@ -863,6 +871,7 @@ def run(args):
             state["proposal"] = propose(state["num_rays"], wait_for_main=False)
         stats["rays"] += n
         stats["samples"] += n_samples
+        stats["candidates"] += prop["ts"].shape[0]
         state["step"] += 1
 
     # ---- the path alone: the same ray draws, sampling and rendering calls (forward + backward), the field replaced by slices of
@@ -890,9 +899,9 @@ def run(args):
         """barrier + synchronize, exactly n_steps steps, synchronize + barrier; max over ranks"""
         timer = None
         if with_timer:
-            timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill"))
+            timer = _backend.KernelTimer(names=("traverse_count", "traverse_fill", "traverse_sample"))
             _backend.set_kernel_timer(timer)
-        stats.update(rays=0, samples=0)
+        stats.update(rays=0, samples=0, candidates=0)
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -911,7 +920,7 @@ def run(args):
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             elapsed = mx[0].item()
         return dict(elapsed=elapsed, rays=tot[1].item(), samples=tot[2].item(), timer=timer,
-                    local_rays=stats["rays"], local_samples=stats["samples"])
+                    local_rays=stats["rays"], local_samples=stats["samples"], local_candidates=stats["candidates"])
 
     # ---- untimed: train from fog into the steady state, then warm up the loop that is timed ---------------------------
     t_pre = time.perf_counter()
@@ -1081,32 +1090,47 @@ def run(args):
         # Algorithmic bytes: 16 B per emitted candidate sample (ray_indices i64 + t_starts + t_ends)
         # + 48 B per ray + the grid once, G*V bool bytes as the API hands it over.
         summ = main_run["timer"].summary()
-        n_launch, ms_count = summ.get("traverse_count", (0, 0.0))
-        _, ms_emit = summ.get("traverse_fill", (0, 0.0))
-        ms = ms_count + ms_emit
-        rays_per_launch = main_run["local_rays"] / max(args.steps, 1)
+        n_count, ms_count = summ.get("traverse_count", (0, 0.0))
+        n_emit, ms_emit = summ.get("traverse_fill", (0, 0.0))
+        n_fused, ms_fused = summ.get("traverse_sample", (0, 0.0))
+        # round 6: the call is ONE launch at this size (count + look-back + emit in traverse_count_split_kernel<..., fused>,
+        # nfa_traverse_sample); steps whose guess of the output size was too small add an emit launch.  Per timed step:
+        steps_t = max(args.steps, 1)
+        fused = n_fused > 0
+        n_launch = n_fused if fused else n_count
+        ms_dominant = ms_fused if fused else ms_count                         # average duration of the dominant kernel's launches
+        ms = (n_fused * ms_fused + n_count * ms_count + n_emit * ms_emit) / steps_t      # traversal kernel time per step
+        rays_per_launch = main_run["local_rays"] / steps_t
+        # candidate samples per launch: what the timed launches produced (the totals every sampling call reads back), not a fresh draw
+        cand = main_run["local_candidates"] / steps_t
+        n_rendered = main_run["local_samples"] / steps_t
+        assert cand >= n_rendered, f"candidates per step ({cand}) < rendered samples per step ({n_rendered}): the counters disagree"
         with torch.no_grad():
             idx = torch.randint(0, args.pool, (int(rays_per_launch),), device=device)
-            cand = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
             walk = dda_steps(pool_o[idx], pool_d[idx], est.aabbs[0], args.occ_res, 0.0, 1e10)
         if args.dump_sampling_state:
+            with torch.no_grad():
+                cand_dump = est.sampling(pool_o[idx], pool_d[idx], render_step_size=RENDER_STEP, stratified=True)[0].shape[0]
             np.savez_compressed(args.dump_sampling_state, binaries_bits=np.packbits(est.binaries.cpu().numpy().ravel()),
                                 res=np.array(est.binaries.shape), aabbs=est.aabbs.cpu().numpy(), rays_o=pool_o[idx].cpu().numpy(),
                                 rays_d=pool_d[idx].cpu().numpy(), jitter=torch.rand(idx.shape[0], device=device).cpu().numpy(),
-                                render_step=np.float32(RENDER_STEP), candidates=np.int64(cand))
+                                render_step=np.float32(RENDER_STEP), candidates=np.int64(cand_dump))
         alg_bytes = 16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {
-            "kernel": "traverse_count_split_kernel + traverse_emit_tiles_kernel (the sampling traversal)",
+            "kernel": ("traverse_count_split_kernel<fused> (the sampling traversal: count, offsets by look-back and emit in one launch)" if fused
+                       else "traverse_count_split_kernel + traverse_emit_tiles_kernel (the sampling traversal)"),
             "bound": "issue/latency", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_source": None,
-            "avg_launch_ms": ms_count, "emit_avg_launch_ms": ms_emit, "launches": n_launch,
+            "avg_launch_ms": ms_dominant, "emit_avg_launch_ms": ms_emit, "emit_launches": n_emit, "launches": n_launch,
+            "traversal_kernel_ms_per_step": ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "candidate_samples_per_sec_of_kernel_time": cand / (ms * 1e-3) if ms > 0 else 0.0,
-            "dda_steps_per_launch": walk, "dda_steps_per_sec_of_kernel_time": walk / (ms_count * 1e-3) if ms_count > 0 else 0.0,
+            "dda_steps_per_launch": walk, "dda_steps_per_sec_of_kernel_time": walk / (ms * 1e-3) if ms > 0 else 0.0,
             "note": "a dependent voxel walk over an LDS-resident bit-packed grid: ~16 B of HBM traffic per sample, so the HBM fraction is small "
                     "by construction; the bound is instruction issue / latency (roofline.issue), the figures of merit are candidate samples/s "
-                    "and DDA steps/s of kernel time.  The HBM-streaming kernels of the path are measured at N >= 2^24 in profiles/.",
+                    "and DDA steps/s of kernel time (round 6: of the whole single launch, emit included).  The HBM-streaming kernels of the "
+                    "path are measured at N >= 2^24 in profiles/.",
         }
         # counter-based figures come from a committed rocprofv3 --pmc run of THIS workload (tools/pmc_bench.py); they are
         # attached only when that run's ray count is within 15 % of this run's
@@ -1176,18 +1200,19 @@ def run(args):
             out.setdefault("aux", {})["configs3_rank_step"] = rank_step
         if prof is not None and "error" not in prof:
             # the PATH's own fraction at this size: algorithmic bytes of every nfa:: kernel of a step
-            # (sampling 16 c + 48 R + the bool grid; filter 21 c + 16 N; rendering forward 44 N + 20 R, backward 60 N + 20 R;
-            # c = candidate samples, N = rendered samples, R = rays) over their summed kernel time from the profiled pass
+            # (sampling 16 c + 48 R + the bool grid; filter 20 c + 16 N; rendering forward 44 N + 20 R, backward 56 N + 20 R —
+            # the backward kernel no longer reads the weights; c = candidate samples, N = rendered samples, R = rays, all of them the
+            # timed steps' own averages) over their summed kernel time from the profiled pass
             n_s = main_run["local_samples"] / max(args.steps, 1)
-            path_bytes = (16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)) + (21.0 * cand + 16.0 * n_s) \
-                + (44.0 * n_s + 20.0 * rays_per_launch) + (60.0 * n_s + 20.0 * rays_per_launch)
+            path_bytes = (16.0 * cand + 48.0 * rays_per_launch + float(args.occ_res**3)) + (20.0 * cand + 16.0 * n_s) \
+                + (44.0 * n_s + 20.0 * rays_per_launch) + (56.0 * n_s + 20.0 * rays_per_launch)
             path_gbs = path_bytes / (prof["nfa_us_per_step"] * 1e-6) / 1e9 if prof["nfa_us_per_step"] > 0 else 0.0
             roof["path"] = {"kernels": "every nfa:: kernel of a step (sampling, visibility filter, rendering forward + backward)",
                             "us_per_step": prof["nfa_us_per_step"], "launches_per_step": prof["nfa_kernels_per_step"],
                             "algorithmic_bytes_per_step": path_bytes, "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": path_gbs / HBM_PEAK_GBS,
                             "path_only_loop_ms_per_step": (path_only["elapsed"] / args.steps * 1e3) if path_only is not None else None,
-                            "note": "latency-bound at this size: ~9 launches of 5-30 us each; the same kernels reach 0.35-0.7 of 8 TB/s at N = 2^24 (profiles/)"}
+                            "note": "latency-bound at this size: 5-6 launches of 9-40 us each; the same kernels reach 0.35-0.7 of 8 TB/s at N = 2^24 (profiles/)"}
         if prof is not None:
             if "error" in prof:
                 out["gpu_activity"] = prof

@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 pytestmark = pytest.mark.gpu
 
-FUSABLE = ["lego_4k", "m1_sphere"]          # one level, a grid whose sparse image fits LDS, 4096 rays: the fused form's window
+FUSABLE = ["m1_sphere"]                     # one level, a grid whose sparse image fits LDS beside the crossing-time arrays, 4096 rays: the fused form's window
+NOT_FUSABLE = ["lego_4k", "m1_noise"]       # 5 636 / 32 768 non-empty bricks: the image does not fit — nfa_traverse_sample takes the three launches
 
 
 @pytest.fixture(scope="module")
@@ -88,6 +89,35 @@ def test_fused_form_is_what_serves_the_case(name, k2, force_options):
     assert _is_fused(c)
     force_options(fused_sample=0)
     assert not _is_fused(c)
+
+
+@pytest.mark.parametrize("name", NOT_FUSABLE)
+def test_calls_outside_the_window_take_the_three_launches(name, k2):
+    c = _case(name, k2)
+    assert not _is_fused(c)
+    _check(name, k2, _sample(c), c["rays_o"].shape[0])
+    _check(name, k2, _sample(c), c["rays_o"].shape[0])
+
+
+def test_fused_sampling_equals_the_oracle():
+    """the bench's kind of scene (a grid whose image fits LDS), 6 564 rays with a stratified start: sample lists bit for bit as the C
+    restatement of grid.cu:68-282 produces them (oracle/nerfacc_oracle.c)"""
+    import torch
+
+    import oracle
+    from gpu_utils import lego_like, n, t
+    from nerfacc_amd import cuda as C
+
+    o, d, aabb, occ = lego_like(3, 6564)
+    rng = np.random.default_rng(1)
+    jit = rng.random(6564, dtype=np.float32)
+    args = (t(o), t(d), t(occ), t(aabb), None, None, 5e-3, 0.0)
+    kw = dict(near_plane=0.0, far_plane=1e10, jitter=t(jit), jitter_scale=5e-3)
+    C.sample_occgrid(*args, **kw)
+    out = C.sample_occgrid(*args, **kw)             # (the second call has a guess: everything in the one launch)
+    torch.cuda.synchronize()
+    r_ri, r_ts, r_te, _ = oracle.sampling(o, d, occ, aabb, near_plane=0.0, far_plane=1e10, render_step_size=5e-3, jitter=jit)
+    assert np.array_equal(n(out[0]), r_ri) and np.array_equal(n(out[1]), r_ts) and np.array_equal(n(out[2]), r_te)
 
 
 @pytest.mark.parametrize("name", FUSABLE)

@@ -75,7 +75,7 @@ except Exception as e:      # noqa: BLE001
     print("ceiling ubench unavailable:", e)
 bench("weight_fwd_kernel (ray_indices)", 32 * N, lambda: C.render_weight_from_density_fwd(ri, ts, te, sig, None))
 bench("weight_bwd_kernel", 36 * N, lambda: C.render_weight_from_density_bwd(ri, ts, te, sig, T, a, gw, None, None))
-bench("rendering_fwd_kernel (+fill_rays)", 44 * N + 20 * R, lambda: C.rendering_fwd(ri, ts, te, sig, rgb, R, bk, True))
+bench("rendering_fwd_kernel (+ rays without samples)", 44 * N + 20 * R, lambda: C.rendering_fwd(ri, ts, te, sig, rgb, R, bk, True))
 bench("rendering_bwd_kernel", 56 * N + 20 * R,
       lambda: C.rendering_bwd(ri, ts, te, sig, rgb, w, T, a, opa, dep, R, bk, True, gc, go, gd, None, None, None))
 bench("accumulate_kernel<3>", 24 * N + 12 * R, lambda: C.accumulate_along_rays(ri, w, rgb, R))
@@ -84,7 +84,11 @@ bench("scan_keyed_kernel (exclusive sum)", 16 * N, lambda: C.exclusive_sum_cub(r
 bench("scan_keyed_kernel (exclusive sum, reverse walk)", 16 * N, lambda: C.exclusive_sum_cub(ri, x, True))
 bench("scan_packed_kernel (exclusive sum)", 8 * N + 16 * R, lambda: C.exclusive_sum(pk[:, 0].contiguous(), pk[:, 1].contiguous(), x, False, False))
 sig_vis = sig * 0.01      # (rounds 1-5 formed this product inside the timed lambda: a 134 MB elementwise kernel, ~25 us of the row)
-bench("visibility mask+scan+compact", 37 * N, lambda: C.visibility_compact(ri, ts, te, sig_vis, False, 1e-4, 0.0))
+# bytes of the filter from what THIS call does: SURVEY 8d's 20 N in (keys 8, t_starts 4, t_ends 4, sigmas 4) + 16 N_out
+# (keys, t_starts, t_ends of the survivors); no byte mask is written unless asked for (want_mask = False)
+n_vis_out = C.visibility_compact(ri, ts, te, sig_vis, False, 1e-4, 0.0)[0].shape[0]
+bench(f"visibility mask+compact ({n_vis_out / N:.3f} of the samples survive)", 20 * N + 16 * n_vis_out,
+      lambda: C.visibility_compact(ri, ts, te, sig_vis, False, 1e-4, 0.0))
 bench("pack_info_kernel", 16 * R, lambda: C.pack_info(ri, R))
 
 if len(sys.argv) > 2:
