@@ -335,14 +335,28 @@ __device__ __forceinline__ int emit_rays_per_wave_log2(int rb_log2, int rb_min, 
 // LDS bytes of one wave's segment list (+ its ray bases and run flags)
 __host__ __device__ constexpr int emit_lds_per_wave(int seg_cap, bool iv) { return seg_cap * 4 * (kEmitSegWords + (iv ? 2 : 0)) + kEmitRayBaseBytes; }
 
+// How a wave of the emit pass learns where its rays' samples go.  EmitPlain: the offsets kernel has run, sm_starts / sm_cnts are in
+// memory.  A hook with kDeferred = true (sample_fused.hpp: the single-launch sampling call) hands over the counts it holds in
+// registers and starts RELATIVE to the wave's first sample (`counts`), and `wait()` — called exactly once per wave, after the first
+// sub-block's segment list has been built and before anything is stored — returns what to add to them (or -1: store nothing): the
+// list is built while the offset of the wave's first sample is still being worked out.
+struct EmitPlain {
+    static constexpr bool kDeferred = false;
+    __device__ __forceinline__ void counts(int64_t, bool, int64_t &, int64_t &) const {}
+    __device__ __forceinline__ int64_t wait() const { return 0; }
+};
+
 // The wave expands ray blocks blk_first, blk_first + blk_step, ... (< n_rb) of 2^rb_log2 rays each.  `lds_wave`: this wave's
 // emit_lds_per_wave bytes.  `n_total`: what has to fit into `capacity` for anything to be stored (a speculative launch: the call's
 // total, requested by the caller and looked at here after the first block's loads have been issued; 0 = no check).
-template <bool IV>
+template <bool IV, class Hook = EmitPlain>
 __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const RunStore &rs, int rb_log2, int seg_cap, unsigned char *lds_wave,
-                                              int64_t n_total, int64_t capacity, int64_t blk_first, int64_t blk_step, int64_t blk_end = -1)
+                                              int64_t n_total, int64_t capacity, int64_t blk_first, int64_t blk_step, int64_t blk_end = -1,
+                                              Hook hook = Hook())
 {
     bool checked = false;
+    bool waited = !Hook::kDeferred;
+    int64_t gbase = 0;                                            // (deferred: added to every sample position at the store; -1: nothing is stored)
     const int lane = lane_id();
     const int64_t R = a.n_rays;
     const LatStep L(march_dt(0.0f, 0.0f, a.step_size));
@@ -373,7 +387,9 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             // ONE round trip: the ray's counts and its first kEmitSpeculate run records (their addresses do not depend on the
             // counts; almost every ray of a NeRF-like scene has fewer runs — requesting all 2 W of the first two rounds read 5 MB
             // of never-written record slots per call at 6.5 k rays, counters of profiles/r04_pmc_traverse.json's first version)
-            cnt = a.sm_cnts[r]; S = a.sm_starts[r]; nr = rs.n_runs[r];
+            if (Hook::kDeferred) hook.counts(r, own, cnt, S);
+            else { cnt = a.sm_cnts[r]; S = a.sm_starts[r]; }
+            nr = rs.n_runs[r];
             if (IV) E = a.iv_starts[r];
             const int lim = rs.max_runs < kEmitSpeculate ? rs.max_runs : kEmitSpeculate;
             if (w < lim) { t0_q = rs.t0[(int64_t)w * R + r]; if (w > 0) first_q = rs.first[(int64_t)w * R + r]; }
@@ -473,8 +489,9 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!waited) { gbase = hook.wait(); waited = true; }
             int seg_lo = 0;                                          // wave-uniform: the run of the chunk's first quad
-            for (int qc = 0; qc < n_quads; qc += 64) {
+            for (int qc = 0; qc < (gbase < 0 ? 0 : n_quads); qc += 64) {
                 const int slot = qc + lane;
                 int seg = seg_lo;
 #if !NFA_EMIT_BISECT
@@ -533,7 +550,7 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
 #pragma unroll
                             for (int k = 0; k < 4; ++k) sv[k + 1] = sv[k] + dt;
                         }
-                        const int64_t s = S_a + sp + j, rr = r0 + ray_s;
+                        const int64_t s = gbase + S_a + sp + j, rr = r0 + ray_s;
                         if (!IV && nv == 4) {
                             typedef float vf4 __attribute__((ext_vector_type(4)));
                             if (a.t_starts) {
@@ -578,6 +595,7 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             a_ray = b_ray;
         }
     }
+    if (!waited) (void)hook.wait();                                  // (a wave without a sample: the hook still runs once)
 }
 
 // the tile form's own kernel: the host launches it for every cone_angle == 0 call (`emit` option: auto or tiles)

@@ -42,6 +42,7 @@ __device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st
     constexpr int U = 4;
     int64_t excl = 0;
     const uint64_t t_begin = wall_clock64();
+    int spins = 0;
     for (int64_t j = b - 1; j >= 0; j -= 64 * U) {
         uint64_t v[U];
         unsigned long long take[U];
@@ -68,8 +69,9 @@ __device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st
             }
             if (aborted) return -1;
             if (ok) break;
-            if (wall_clock64() - t_begin > kSpinLimitTicks) return -1;
-            __builtin_amdgcn_s_sleep(2);
+            // (the clock is a memory-path read: looked at every 16th round; no sleep between rounds — the loads' own round trip is the
+            //  polling period, and one wave per workgroup polls)
+            if ((++spins & 15) == 0 && wall_clock64() - t_begin > kSpinLimitTicks) return -1;
         }
         int64_t sum = 0;
 #pragma unroll
@@ -84,7 +86,7 @@ __device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st
 // it, publish the inclusive prefix.  `extra0` / `extra1` are added to header words 1 / 2 BEFORE the aggregate becomes visible (totals only
 // the last workgroup reads).  Returns the exclusive prefix, or -1 (ABORT published).  The LAST workgroup to leave — whichever it is
 // — zeroes the states and the header again (`done` counts the workgroups that are through with the states).
-__device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane) {
+__device__ __forceinline__ void sync_publish(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane) {
     uint64_t *st = sync + kSyncHeaderWords;
     if (lane == 0) {
         if (extra0) sync_add(sync + 1, (uint64_t)extra0);
@@ -92,9 +94,17 @@ __device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restric
         sync_drain();
         sync_store(st + b, (kStAgg << 62) | (uint64_t)agg);
     }
+}
+// (the two halves of the hand-off, for a caller that has work to do between publishing its aggregate and needing the prefix)
+__device__ __forceinline__ int64_t sync_finish_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int lane) {
+    uint64_t *st = sync + kSyncHeaderWords;
     const int64_t excl = sync_lookback(st, b, lane);
     if (lane == 0) sync_store(st + b, excl < 0 ? (kStAbort << 62) : ((kStPrefix << 62) | (uint64_t)(excl + agg)));
     return excl;
+}
+__device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane) {
+    sync_publish(sync, b, agg, extra0, extra1, lane);
+    return sync_finish_lookback(sync, b, agg, lane);
 }
 // called by the same wave when it no longer needs the states or the header: the last caller of the launch resets them
 __device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane) {

@@ -35,6 +35,61 @@ struct FuseArgs {
     int seg_cap;           // emit pass: segment-list entries per wave
 };
 
+// The emit pass's hook of the single launch (emit_pass.hpp: Hook): counts and wave-relative starts from the count kernel's registers;
+// wait() = the rest of the hand-off — wave 0 finishes the workgroup's look-back, the workgroup meets, every wave learns where its first
+// sample goes and stores its rays' starts.  Runs exactly once per wave.
+template <int NW>
+struct FusedEmitHook {
+    static constexpr bool kDeferred = true;
+    const nfa_traverse_args &a;
+    const FuseArgs &f;
+    int64_t (*s_w)[3];            // [NW][3] in LDS: samples, edges, overflowed rays of every wave
+    int64_t *s_pre;               // LDS: the workgroup's exclusive prefix (-1: the look-back gave up)
+    int64_t r;                    // this lane's ray
+    bool own_first;               // this lane is the first of its ray's lanes and the ray is inside the batch
+    int64_t cnt_ray, rel_ray;     // the lane's ray: samples, first sample relative to the wave's first (the same in all lanes of a ray)
+    int64_t wave_total, b_sm;     // samples of the wave / of the workgroup
+    int lane, wv;
+
+    __device__ __forceinline__ void counts(int64_t, bool own, int64_t &cnt, int64_t &S) const {
+        cnt = own ? cnt_ray : 0;
+        S = own ? rel_ray : 0;
+    }
+    __device__ __forceinline__ int64_t wait() {
+        const int64_t b = blockIdx.x, nb = gridDim.x;
+        int64_t excl = 0;
+        if (wv == 0) {
+            excl = sync_finish_lookback(f.sync, b, b_sm, lane);
+            if (lane == 0) *s_pre = excl;
+            NFA_FUSE_STAMP(2);
+        }
+        __syncthreads();
+        // behind the barrier (the workgroup's other waves are off to their stores): the call's totals and the host's stamp from the
+        // last workgroup, and this workgroup's leave — each a memory round trip the barrier does not have to wait for
+        if (wv == 0) {
+            if (lane == 0 && b == nb - 1) {
+                // (every workgroup before this one added its edges / overflowed rays before its state became visible)
+                const int64_t ed = (int64_t)sync_load(f.sync + 1), ov = (int64_t)sync_load(f.sync + 2);
+                const int64_t n = excl < 0 ? -1 : excl + b_sm;
+                f.totals_dev[0] = ed; f.totals_dev[1] = n; f.totals_dev[2] = ov; f.totals_dev[3] = 0;
+                a.totals[0] = ed; a.totals[1] = n; a.totals[2] = ov;
+                __threadfence_system();
+                a.totals[3] = f.stamp;
+            }
+            sync_leave(f.sync, nb, lane);
+        }
+        const int64_t pre = *s_pre;
+        if (pre < 0) return -1;
+        int64_t base = pre;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) base += w < wv ? s_w[w][0] : 0;
+        if (own_first) a.sm_starts[r] = base + rel_ray;
+        if (f.capacity <= 0 || !(a.sm_ray_indices || a.t_starts || a.sm_vals)) return -1;
+        if (base + wave_total > f.capacity) return -1;      // (wave-uniform) the caller's guess was too small for this wave's samples: it launches the emit pass itself
+        return base;
+    }
+};
+
 // `own`: this lane holds a ray's results (the first of the ray's P lanes, ray inside the batch).  All threads of the workgroup call.
 template <int BLK, int P>
 __device__ __forceinline__ void fused_sample_tail(const nfa_traverse_args &a, const RunStore &rs, const FuseArgs &f, char *smem,
@@ -54,54 +109,37 @@ __device__ __forceinline__ void fused_sample_tail(const nfa_traverse_args &a, co
     }
     __syncthreads();                                    // every wave of the workgroup has counted; its stores are on their way to L2
     NFA_FUSE_STAMP(1);
-    const int64_t b = blockIdx.x, nb = gridDim.x;
+    int64_t b_sm = 0;
     if (wv == 0) {
-        int64_t b_sm = 0, b_iv = 0, b_ov = 0;
+        int64_t b_iv = 0, b_ov = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { b_sm += s_w[w][0]; b_iv += s_w[w][1]; b_ov += s_w[w][2]; }
-        const int64_t excl = sync_publish_and_lookback(f.sync, b, b_sm, b_iv, b_ov, lane);
-        if (lane == 0) {
-            s_pre = excl;
-            if (b == nb - 1) {
-                // the call's totals: every workgroup before this one added its edges / overflowed rays before its state became visible
-                const int64_t ed = (int64_t)sync_load(f.sync + 1), ov = (int64_t)sync_load(f.sync + 2);
-                const int64_t n = excl < 0 ? -1 : excl + b_sm;
-                f.totals_dev[0] = ed; f.totals_dev[1] = n; f.totals_dev[2] = ov; f.totals_dev[3] = 0;
-                a.totals[0] = ed; a.totals[1] = n; a.totals[2] = ov;
-                __threadfence_system();
-                a.totals[3] = f.stamp;
-            }
-        }
-        NFA_FUSE_STAMP(2);
-        sync_leave(f.sync, nb, lane);
+        sync_publish(f.sync, (int64_t)blockIdx.x, b_sm, b_iv, b_ov, lane);      // the others can count on it from here on
     }
-    __syncthreads();
-    const int64_t pre = s_pre;
-    if (pre < 0) return;
-    int64_t S = pre;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) S += w < wv ? s_w[w][0] : 0;
-    // exclusive sum over the wave's rays (their counts sit in the first lane of every P)
+    // the rays of this wave: counts to all lanes of a ray, starts relative to the wave's first sample
     const int64_t mine = own ? out_sm : 0;
     const int ray_l = lane / P;
-    int64_t end = S;
+    int64_t rel = 0;
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
         const int64_t v = __shfl(mine, k * P, 64);
-        S += k < ray_l ? v : 0;
-        end += v;
+        rel += k < ray_l ? v : 0;
     }
-    if (own) a.sm_starts[r] = S;
-    if (f.capacity <= 0 || !(a.sm_ray_indices || a.t_starts || a.sm_vals)) return;
-    if (end > f.capacity) return;                       // (wave-uniform) the caller's guess was too small for this wave's samples: it launches the emit pass itself
-    // the offsets are read back by the emit code below (and the counts / run records were stored by this workgroup's waves before the
-    // barrier above): workgroup-scope release = the stores have reached L2 before the loads are issued
+    const int64_t cnt_ray = __shfl(mine, ray_l * P, 64);
+    FusedEmitHook<NW> hook{a, f, s_w, &s_pre, r, own, cnt_ray, rel, w_sm, b_sm, lane, wv};
+    if (f.capacity <= 0 || !(a.sm_ray_indices || a.t_starts || a.sm_vals)) {      // count + offsets only
+        (void)hook.wait();
+        return;
+    }
+    // the run records and run counts the emit code reads were stored by this workgroup's waves before the barrier above:
+    // workgroup-scope release / acquire = the stores have reached L2 before the loads are issued
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int rb_log2 = 0;
     while ((1 << rb_log2) < RPW) ++rb_log2;
-    const int64_t blk = b * NW + wv;                    // ray block of 2^rb_log2 = RPW rays: exactly this wave's rays
+    const int64_t blk = (int64_t)blockIdx.x * NW + wv;  // ray block of 2^rb_log2 = RPW rays: exactly this wave's rays
+    // the segment lists are built while the look-back is still waiting for the slowest workgroups; only the stores need its result
     emit_by_tiles<false>(a, rs, rb_log2, f.seg_cap, (unsigned char *)smem + wv * emit_lds_per_wave(f.seg_cap, false), (int64_t)0, f.capacity,
-                         blk, (int64_t)1, blk + 1);
+                         blk, (int64_t)1, blk + 1, hook);
     NFA_FUSE_STAMP_MAX(3);
 }
