@@ -941,6 +941,24 @@ def run(args):
     main_run = sorted(windows, key=lambda w: w["elapsed"])[(len(windows) - 1) // 2]      # the median window
     state.pop("proposal", None)
 
+    # replicas stay bit-identical (north_star: every rank holds the field and the grid, its own rays, ONE gradient exchange per step):
+    # a fingerprint of every parameter and of the estimator's state per rank, gathered; rank 0 says whether they agree
+    replicas = None
+    if exchanging and dist.is_initialized():
+        def bits(t):
+            t = t.detach().contiguous().view(-1)
+            return (t.view(torch.int32) if t.dtype == torch.float32 else t.to(torch.int32)).to(torch.int64)
+        fp = torch.zeros(2, dtype=torch.int64, device=device)
+        for t in list(field.parameters()) + [est.occs, est.binaries]:
+            b = bits(t)
+            fp[0] += b.sum()
+            fp[1] += (b * (torch.arange(b.shape[0], device=device, dtype=torch.int64) % 8191 + 1)).sum()      # (position-weighted: wrap-around int64 sums)
+        gathered = [torch.zeros_like(fp) for _ in range(world_size)]
+        dist.all_gather(gathered, fp)
+        prints = [[int(x) for x in g.tolist()] for g in gathered]
+        replicas = {"identical": all(p_ == prints[0] for p_ in prints), "fingerprints": prints,
+                    "of": "every field parameter + the estimator's occs and binaries after the timed steps (int64 sums of the bit patterns, plain and position-weighted)"}
+
     # the OTHER exchange mode for a few steps (every rank takes part): what the design choice costs on this node
     exchange_modes = None
     if exchanging and isinstance(optimizer, sharding.ExchangeAdam) and not args.no_aux:
@@ -1186,6 +1204,8 @@ def run(args):
             po = out["path_only_loop"]
             po["path_us_per_step"] = path_prof["nfa_us_per_step"]
             po["gpu_idle_frac"] = max(0.0, 1.0 - path_prof["busy_us_per_step"] / (po["ms_per_step"] * 1e3))
+        if replicas is not None:
+            out["replicas"] = replicas
         if exchange_modes is not None:
             aux["exchange_modes"] = exchange_modes
         if aux:

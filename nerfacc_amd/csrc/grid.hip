@@ -164,7 +164,7 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
     L.off_prefix = L.off_coarse + (L.n_words + 1) / 2;
     L.off_compact = L.off_prefix + (L.n_words + 1) / 2;
     L.off_dist = L.off_compact + L.n_bricks;     // round 5: 4 bits per brick, distance to the nearest non-empty brick (brick_dist_kernel)
-    L.total_words = L.off_dist + 2 * ((L.n_bricks + 31) / 32);      // (whole 16-byte units: stage_dist copies the nibbles in 16-byte-rounded pieces)
+    L.total_words = L.off_dist + 2 * ((L.n_bricks + 31) / 32);      // (whole 16-byte units)
     return L;
 }
 
@@ -358,8 +358,6 @@ struct GridView {
     int lds_words;        // bitmap (and rank) words staged in LDS (0 = nothing staged)
     int lds_compact_cap;  // compact bricks staged in LDS (0 with lds_words > 0: bitmap only, bricks from L2)
     const uint8_t *__restrict__ dist;   // one nibble per brick: distance to the nearest non-empty brick (brick_dist_kernel)
-    int lds_dist_off;     // byte offset of the staged distances in the kernel's dynamic LDS, -1 = read from L2
-    int lds_dist_bytes;
     int skip_auto;        // 1: a wave takes the empty-space macro steps only when its 64 rays are coherent (wave_rays_coherent)
 };
 
@@ -518,16 +516,9 @@ __device__ __forceinline__ uint64_t brick_bits(const GridView &g, const Occ<LDS_
     return g.bricks[id];
 }
 // distance (in bricks, capped at kDistCap) from brick `id` to the nearest non-empty brick of its level; 0 = non-empty
-template <bool DIST_LDS>
-__device__ __forceinline__ int brick_dist(const GridView &g, const char *smem, int id) {
-    const unsigned v = DIST_LDS ? (unsigned)((const uint8_t *)(smem + g.lds_dist_off))[id >> 1] : (unsigned)g.dist[id >> 1];
+__device__ __forceinline__ int brick_dist(const GridView &g, int id) {
+    const unsigned v = (unsigned)g.dist[id >> 1];
     return (int)((v >> ((id & 1) << 2)) & 15u);
-}
-__device__ __forceinline__ void stage_dist(const GridView &g, char *smem) {
-    const uint32_t *src = (const uint32_t *)g.dist;
-    uint32_t *dst = (uint32_t *)(smem + g.lds_dist_off);
-    for (int i = threadIdx.x; i < (g.lds_dist_bytes >> 2); i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
 }
 // plane crossings a macro step may take per axis BEYOND the pending one (dda_skip's k?1) from voxel c of a brick at distance D >= 1:
 // to the face of the cube of (2 D - 1)^3 empty bricks around the brick, never past the axis' overflow index
@@ -903,7 +894,7 @@ __device__ __forceinline__ void traverse_ray_lattice(const nfa_traverse_args &a,
 // for its neighbour's voxel steps more than once per regime change (a flat "macro step or voxel step" loop body would cost the sum
 // of both at every iteration: P(the 64 lanes of a wave agree) is ~0).  On the bench scene a ray visits 188 voxels, 16 of them in
 // non-empty bricks, and takes ~11 macro steps (tools/experiments/r05_skip_stats.py).  Phase B is unchanged.
-template <int EV, bool LDS_OCC, bool DIST_LDS>
+template <int EV, bool LDS_OCC>
 __device__ __forceinline__ void traverse_ray_lattice_skip(const nfa_traverse_args &a, const GridView &gv, const Occ<LDS_OCC> &occ,
                                                           const char *smem, float *__restrict__ ev_lds /* [kEvCap][blockDim] */,
                                                           int64_t r, bool active, CountSink &sink, float &t_term)
@@ -960,7 +951,7 @@ __device__ __forceinline__ void traverse_ray_lattice_skip(const nfa_traverse_arg
                     const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + id_base;
                     if (id != cur_id) {
                         cur_id = id;
-                        cur_dist = brick_dist<DIST_LDS>(gv, smem, id);
+                        cur_dist = brick_dist(gv, id);
                         cur_bits = brick_bits<LDS_OCC>(gv, occ, id);
                     }
                 }
@@ -984,7 +975,7 @@ __device__ __forceinline__ void traverse_ray_lattice_skip(const nfa_traverse_arg
                             far_ = false;
                         } else {
                             const int id = (int)__umul24(__umul24(w.cx >> 2, gv.nby) + (w.cy >> 2), gv.nbz) + (w.cz >> 2) + id_base;
-                            if (id != cur_id) { cur_id = id; cur_dist = brick_dist<DIST_LDS>(gv, smem, id); }
+                            if (id != cur_id) { cur_id = id; cur_dist = brick_dist(gv, id); }
                             far_ = cur_dist > 0;
                         }
                     }
@@ -1012,7 +1003,7 @@ __device__ __forceinline__ void traverse_ray_lattice_skip(const nfa_traverse_arg
                             const int id = (int)__umul24(__umul24(s.cx >> 2, gv.nby) + (s.cy >> 2), gv.nbz) + (s.cz >> 2) + id_base;
                             if (id != cur_id) {
                                 cur_id = id;
-                                cur_dist = brick_dist<DIST_LDS>(gv, smem, id);
+                                cur_dist = brick_dist(gv, id);
                                 cur_bits = brick_bits<LDS_OCC>(gv, occ, id);
                             }
                             near_ = !(sane && cur_dist > 0) && n_ev < kEvCap - 1;
@@ -1095,15 +1086,13 @@ __device__ __forceinline__ bool wave_rays_coherent(const nfa_traverse_args &a, i
     return __ballot(active && !ok) == 0ull;
 }
 
-// SKIP (lattice form only): 0 = voxel by voxel, 1 = empty-space macro steps with the brick distances read from L2, 2 = with the
-// distances staged in LDS behind the boundary lists (gv.lds_dist_off)
+// SKIP (lattice form only): 0 = voxel by voxel, 1 = empty-space macro steps (brick distances read from L2)
 template <int EV, bool LATTICE, bool LDS_OCC, int SKIP = 0>
 __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_args a, GridView gv,
                                                                 int64_t *__restrict__ block_sums, RunStore rs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
-    if (SKIP == 2) stage_dist(gv, smem);
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = r < a.n_rays && !(a.rays_mask && !a.rays_mask[r]);
     CountSink sink{rs, r, a.n_rays};
@@ -1115,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_kernel(nfa_traverse_arg
         // regime change is paid at the slowest lane's length in both loops; profiles/r05_count_pass.md).  Which of the two a wave is
         // can be read off its rays: same origin region, directions within a few degrees of lane 0's.
         const bool use_skip = !gv.skip_auto || wave_rays_coherent(a, r, active);
-        if (use_skip) traverse_ray_lattice_skip<EV, LDS_OCC, SKIP == 2>(a, gv, occ, smem, ev_lds, r, active, sink, t_term);
+        if (use_skip) traverse_ray_lattice_skip<EV, LDS_OCC>(a, gv, occ, smem, ev_lds, r, active, sink, t_term);
         else traverse_ray_lattice<EV, LDS_OCC>(a, gv, occ, ev_lds, r, active, sink, t_term);
     } else if (LATTICE) {
         // the boundary lists sit behind the occupancy image in LDS
@@ -1387,8 +1376,6 @@ GridView make_view(const nfa_traverse_args *a, int ev_bytes, int *lds_bytes, int
     const PackedLayout L = packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]);
     gv.bricks = a->bricks;
     gv.dist = (const uint8_t *)(a->bricks + L.off_dist);
-    gv.lds_dist_off = -1;
-    gv.lds_dist_bytes = 0;
     gv.skip_auto = 0;
     gv.header = (const int64_t *)(a->bricks + L.off_header);
     gv.coarse = (const uint32_t *)(a->bricks + L.off_coarse);
@@ -1649,7 +1636,6 @@ static int count_lanes_per_ray(const nfa_traverse_args *a, bool sparse) {
         }
         if (opt_is_set(OPT_SPLIT_P)) {                        // tuning knob: 1, 2, 4, 8 or 16
             P = (int)opt(OPT_SPLIT_P, P);
-            if (P == 32) P = 16;                              // (32 = the widened crossing-time form: plan_split decides whether it applies)
             if (sparse && (P == 2 || P == 4)) P = 8;          // (no 2- / 4-lane instances for sparse grids: they never won)
         }
     }
@@ -1683,39 +1669,13 @@ static int segment_lanes_per_ray(const nfa_traverse_args *a) {
     { const int v = (int)opt(OPT_SEG_P, 0); if (v == 8 && P == 32) P = 8; else if (v == 32 && P == 8 && room) P = 32; }
     return P;
 }
-// The 512-thread crossing-time form is one workgroup per CU (its LDS).  6 564 rays at 32 rays per workgroup are 206 workgroups: 50
-// CUs idle while the others hold two waves per SIMD.  The workgroup CAN therefore be launched with fewer threads than its LDS layout's
-// stride (`split_thr` = 192 ... 512 in steps of 64: e.g. 448 puts 235 workgroups of 28 rays on the chip).
-static int split_launch_threads(const nfa_traverse_args *a, int P, int blk, int xt) {
-    if (!(blk == 512 && xt && P == 16)) return blk;
-    const int per_wave = kWave / P;
-    (void)per_wave;
-    // Measured (profiles/r05_count_pass.md section 5): no gain — 29.0 us at 448 threads against 29.1 at 512 for 6 564 rays, 30.2 against
-    // 28.9 at 3 500 rays (narrower workgroups), and 46-49 us as soon as a second round of workgroups is needed.  The launch's time does
-    // not depend on how the rays are spread: it is the dependent chain of a wave.  Kept as an option only.
-    int thr = blk;
-    { const int v = (int)opt(OPT_SPLIT_THR, 0); if (v >= 192 && v <= 512 && v % 64 == 0) thr = v; }
-    return thr;
-}
 static SplitPlan plan_split_(const nfa_traverse_args *a);
 static SplitPlan plan_split(const nfa_traverse_args *a) {
+    // (rounds 4-5 tried two more shapes of the crossing-time form here — workgroups launched narrower than their LDS stride,
+    //  `split_thr`, and 32 lanes per ray in 1024-thread workgroups, `split_p = 32`: neither was ever faster than this one at any ray
+    //  count (profiles/r05_count_pass.md section 5: the launch's time is one wave's dependent chain), removed in round 6)
     SplitPlan p = plan_split_(a);
-    p.thr = p.seg ? p.blk : split_launch_threads(a, p.P, p.blk, p.xt && p.gv.lds_compact_cap > 0);
-    // 32 lanes per ray (round 5): the launch's time is its slowest WAVE's dependent chain whatever the ray count between 3 k and 8 k
-    // (29 us at 3 500 and at 8 192 rays) — so the chain is what to shorten: parts half as long (walk, boundary positions, stitch), 1024-thread
-    // workgroups of 32 rays (the same LDS: image + 8-entry lists + crossing-time arrays), two rays per wave.  `split_p = 32` / `16` force.
-    if (!p.seg && p.P == 16 && p.blk == 512 && p.xt && p.gv.lds_compact_cap > 0 && !p.l2) {
-        // Measured: 29.3-29.7 us against 28.6-30.1 with 16 lanes between 3.5 k and 8 k rays — the halved parts are paid for by four waves
-        // per SIMD instead of two (a 1024-thread workgroup; tools/ubench/launch_floor.hip: a dependent ALU chain runs 30 % slower at that
-        // occupancy).  Bit-exact (fixtures under `split_p = 32`), off unless asked for.
-        const int64_t want = opt(OPT_SPLIT_P, 16);
-        int lds32 = 0;
-        const int xt_bytes = 32 * (a->res[0] + a->res[1] + a->res[2] + 3) * 4;
-        GridView gv32 = make_view(a, 8 * 1024 * 8 + xt_bytes, &lds32, 156 * 1024);
-        if (want == 32 && gv32.lds_compact_cap > 0 && ceil_div(a->n_rays, (int64_t)32) <= kNumCU) {
-            p.P = 32; p.cap = 8; p.blk = 1024; p.thr = 1024; p.lds = lds32; p.gv = gv32;
-        }
-    }
+    p.thr = p.blk;
     return p;
 }
 static SplitPlan plan_split_(const nfa_traverse_args *a) {
@@ -1870,9 +1830,6 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (plan.l2) {
             // grid image from L2: 16-entry lists, 32 KB of LDS per workgroup
             if (P == 8) NFA_LAUNCH_SPLIT(false, 8, 16); else NFA_LAUNCH_SPLIT(false, 16, 16);
-        } else if (lds_occ && plan.blk == 1024 && P == 32) {
-            if (int rc = allow_lds(traverse_count_split_kernel<true, 32, 8, 1024, true>, lds)) return rc;
-            hipLaunchKernelGGL((traverse_count_split_kernel<true, 32, 8, 1024, true>), dim3(nbs), dim3(1024), lds, s, *a, gv, block_sums, rs, FuseArgs{});
         } else if (lds_occ && plan.blk == 512 && plan.xt) {
             if (int rc = allow_lds(traverse_count_split_kernel<true, 16, 16, 512, true>, lds)) return rc;
             hipLaunchKernelGGL((traverse_count_split_kernel<true, 16, 16, 512, true>), dim3(nbs), dim3(plan.thr), lds, s, *a, gv, block_sums, rs, FuseArgs{});
@@ -1902,27 +1859,16 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
         if (l2) gv = make_view(a, kEvBytes, &lds, 0);
     }
     const bool lds_occ = gv.lds_compact_cap > 0;
-    // empty-space skipping (lattice form): the brick distances (half a byte per brick) staged in LDS behind the lists when they are
-    // at most 16 KB (128^3: every workgroup-per-CU count stays as it was with 16-entry... lists + image), else read from L2 —
-    // next to the brick word they replace for every empty brick.  NFA_SKIP = 0 | 1 | 2 overrides (2 falls back to 1 when they do not fit)
+    // empty-space skipping (lattice form), the brick distances (half a byte per brick) read from L2 next to the brick word they
+    // replace for every empty brick.  Measured (profiles/r05_count_pass.md): on incoherent rays — training batches, the replay's tiled
+    // batch — the wave pays the longest far phase AND the longest near phase of its 64 lanes at every regime change and the macro steps
+    // lose: 10^6 rays 621 us voxel by voxel, 728 with them; on the pixel-ordered rays of a frame they win, 276 -> 189.  So: unset =
+    // every WAVE decides from its rays (wave_rays_coherent); `skip` = 0 never, 1 always.  (Round 5 also staged the distances in LDS,
+    // `skip = 2`: 208 us on the frame, 828 on the tiled batch — slower than L2 in both; removed in round 6.)
     int skip = 0;
     if (lattice) {
-        const int64_t dist_bytes = (((packed_layout(a->n_grids, a->res[0], a->res[1], a->res[2]).n_bricks + 1) / 2) + 15) & ~15ll;
-        const bool fits = dist_bytes <= 16 * 1024 && lds + dist_bytes <= 80 * 1024;
-        (void)fits;
-        // Measured (profiles/r05_count_pass.md): on incoherent rays — training batches, the replay's tiled batch — the wave pays the
-        // longest far phase AND the longest near phase of its 64 lanes at every regime change and the macro steps lose: 10^6 rays
-        // 621 us voxel by voxel, 728 with the distances from L2, 828 from LDS (three workgroups per CU instead of five); on the
-        // pixel-ordered rays of a frame they win, 276 -> 189 (L2) / 208 (LDS).  So: unset = every WAVE decides from its rays
-        // (wave_rays_coherent), distances from L2; 0 = never; 1 / 2 = always, distances from L2 / LDS.
         skip = (int)opt(OPT_SKIP, 1);
         gv.skip_auto = opt_is_set(OPT_SKIP) ? 0 : 1;
-        if (skip == 2 && !(dist_bytes + lds <= 80 * 1024)) skip = 1;
-        if (skip == 2) {
-            gv.lds_dist_off = lds;
-            gv.lds_dist_bytes = (int)dist_bytes;
-            lds += (int)dist_bytes;
-        }
     }
 #define NFA_LAUNCH_COUNT(EVM, LAT, LDSO, SK)                                                                                    \
     do {                                                                                                                        \
@@ -1931,8 +1877,7 @@ NFA_EXPORT int nfa_traverse_count(const nfa_traverse_args *a, void *workspace, v
     } while (0)
 #define NFA_COUNT_LAT(EVM, LDSO)                                                      \
     do {                                                                              \
-        if (skip == 2) NFA_LAUNCH_COUNT(EVM, true, LDSO, 2);                          \
-        else if (skip == 1) NFA_LAUNCH_COUNT(EVM, true, LDSO, 1);                     \
+        if (skip == 1) NFA_LAUNCH_COUNT(EVM, true, LDSO, 1);                          \
         else NFA_LAUNCH_COUNT(EVM, true, LDSO, 0);                                    \
     } while (0)
 #define NFA_COUNT_EV(EVM)                                                              \

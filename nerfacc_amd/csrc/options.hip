@@ -46,7 +46,7 @@ bool parse_emit(const char *s, int64_t *out) {
 const OptionSpec kSpecs[OPT_COUNT] = {
     {"e", "samples per lane of the tiled streaming kernels: 1 | 2 | 4", parse_one_of<1, 2, 4>},
     {"tile", "nominal tile of the tiled streaming kernels (a multiple of 64 * e)", parse_tile},
-    {"split_p", "lanes per ray of the one-level count pass: 1 | 2 | 4 | 8 | 16 | 32 (32: the crossing-time form, 3 k - 8 k rays on a grid that fits LDS)", parse_one_of<1, 2, 4, 8, 16, 32>},
+    {"split_p", "lanes per ray of the one-level count pass: 1 | 2 | 4 | 8 | 16", parse_one_of<1, 2, 4, 8, 16>},
     {"seg_p", "several levels, cone_angle = 0: lanes per ray of the segment count pass: 8 | 32", parse_one_of<8, 32>},
     {"cone_p", "lanes per ray of the cone-angle count pass: 8 | 16 | 32 | 64", parse_one_of<8, 16, 32, 64>},
     {"cone", "0: cone_angle != 0 takes the general lane-per-ray kernel", parse_bool},
@@ -61,8 +61,7 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"emit_rb", "tile form of the emit pass: log2 of the rays per wave, 0 ... 6", parse_one_of<0, 1, 2, 3, 4, 5, 6>},
     {"chunk_prefetch", "0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call", parse_bool},
     {"speculative_emit", "0: sample_occgrid of the torch extension launches the emit pass after the read-back", parse_bool},
-    {"split_thr", "crossing-time form of the count pass: threads launched per workgroup, 192 | 256 | 320 | 384 | 448 | 512", parse_one_of<192, 256, 320, 384, 448, 512>},
-    {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps, brick distances from L2, 2 = distances staged in LDS (unset: a wave takes the macro steps when its rays are coherent)", parse_one_of<0, 1, 2>},
+    {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps (brick distances from L2) (unset: a wave takes the macro steps when its rays are coherent)", parse_bool},
     {"vis_onepass", "visibility filter with compacted outputs: 0 = mask / scan / compaction kernels, 1 = one pass with look-back (unset: 0 — the one-pass form measures slower)", parse_bool},
     {"vis_chunks", "one-pass visibility filter: chunks of 64 e samples per tile, 2 ... 7 (four waves x (chunks + 1) x 128 x 16 bytes of LDS: 64 KB at 7)", parse_one_of<2, 3, 4, 5, 6, 7>},
     {"fused_sample", "0: nfa_traverse_sample never takes its single-launch form (count, look-back over the workgroups and emit pass in the count kernel; up to 8192 rays of a one-level grid that fits LDS)", parse_bool},

@@ -28,9 +28,7 @@ enum Option : int {
     OPT_EMIT_RB,         // tile form of the emit pass: log2 of the rays a wave takes (0 ... 6)
     OPT_CHUNK_PREFETCH,  // 0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call
     OPT_SPECULATIVE_EMIT,// 0: the extension's sample_occgrid launches the emit pass after the read-back
-    OPT_SPLIT_THR,       // crossing-time form of the count pass: threads launched per workgroup, 192 ... 512 in steps of 64
-    OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps with the brick distances
-                         // read from L2, 2 = with the distances staged in LDS
+    OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps (brick distances from L2)
     OPT_VIS_ONEPASS,     // visibility filter with compacted outputs: 0 = mask / (scan) / compaction kernels, 1 = the one-pass look-back form
     OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 7 (the LDS image per wave holds one chunk more: 64 KB per workgroup at 7)
     OPT_FUSED_SAMPLE,    // 0: nfa_traverse_sample never takes its single-launch form (count + look-back + emit in the count kernel)

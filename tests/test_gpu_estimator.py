@@ -261,7 +261,7 @@ def test_pixel_ordered_frame_macro_steps_match_the_voxel_walk(force_options):
     est.binaries = t(occ)
     O, D = t(o), t(d)
     outs = {}
-    for tag, f in (("auto", {}), ("skip0", dict(skip=0)), ("skip1", dict(skip=1)), ("skip2", dict(skip=2)), ("lds", dict(count_l2=0)),
+    for tag, f in (("auto", {}), ("skip0", dict(skip=0)), ("skip1", dict(skip=1)), ("lds", dict(count_l2=0)),
                    ("lds skip1", dict(count_l2=0, skip=1))):
         with nerfacc_amd.options(**f):
             outs[tag] = est.sampling(O, D, render_step_size=5e-3)

@@ -68,12 +68,14 @@ def test_options_table_and_environment_seeding():
         with na.options(split_p=16, emit="rays"):
             assert na.get_option("split_p") == 16 and na.get_option("emit") == "rays"
         assert na.get_option("split_p") == 8 and na.get_option("emit") is None
-        assert {"skip", "split_thr", "vis_onepass", "vis_chunks", "emit_rb", "split_cap", "chunk_prefetch"} <= set(names)      # rounds 4-5
+        assert {"skip", "vis_onepass", "vis_chunks", "emit_rb", "split_cap", "chunk_prefetch"} <= set(names)      # rounds 4-5
+        assert {"fused_sample", "fused_vis", "fold_fill"} <= set(names)                                                # round 6
+        assert "split_thr" not in names                                                                                # (pruned in round 6)
         na.set_option("vis_onepass", 1); na.set_option("vis_chunks", 6)
         assert na.get_option("vis_onepass") == 1 and na.get_option("NFA_VIS_CHUNKS") == 6
         na.set_option("vis_onepass", None); na.set_option("vis_chunks", None)
         for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1), ("vis_chunks", 1), ("vis_chunks", 8),
-                            ("vis_onepass", 2), ("skip", 3), ("split_thr", 200)):
+                            ("vis_onepass", 2), ("skip", 2), ("split_p", 32), ("fused_vis", 2)):
             if value == "":
                 na.set_option(name, value)          # "" = auto
                 assert na.get_option(name) is None

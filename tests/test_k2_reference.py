@@ -143,21 +143,21 @@ _ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}
               # boundary-list capacities of the forms that read the grid from L2 (lego_256, m1_noise; ignored where the image fits LDS)
               {"split_p": 16, "split_l2": 1, "split_cap": 16}, {"split_p": 16, "split_l2": 1, "split_cap": 24},
               {"split_p": 16, "split_l2": 1, "split_cap": 32}, {"split_p": 8, "split_cap": 24},
-              # round 5: 32 lanes per ray and narrower launches of the crossing-time form (lego_4k: 4096 rays on a grid that fits LDS)
-              {"split_p": 32}, {"split_p": 16, "split_thr": 448}, {"split_p": 16, "split_thr": 192},
-              # round 5: the lane-per-ray walk with and without empty-space macro steps (brick distances from L2 / staged in LDS)
+              # round 5: the lane-per-ray walk with and without empty-space macro steps
               {"split_p": 1, "count_l2": 0, "skip": 0}, {"split_p": 1, "count_l2": 1, "skip": 0}, {"split_p": 1, "count_l2": 0, "skip": 1},
-              {"split_p": 1, "count_l2": 1, "skip": 1}, {"split_p": 1, "count_l2": 0, "skip": 2}, {"split_p": 1, "count_l2": 1, "skip": 2}]
+              {"split_p": 1, "count_l2": 1, "skip": 1},
+              # round 6: the single-launch sampling call switched off (m1_sphere is inside its window)
+              {"fused_sample": 0}]
 _LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"},
-           {"segments": 0, "skip": 0}, {"segments": 0, "skip": 1}, {"segments": 0, "skip": 2}]
+           {"segments": 0, "skip": 0}, {"segments": 0, "skip": 1}]
 _CONE_ONE = [{}, {"cone": 0}, {"cone": 1, "emit": "rays"}, {"cone": 1, "emit": "samples"}, {"cone": 0, "emit": "rays"}]
 _CONE_LEVELS = _CONE_ONE + [{"cone": 1, "cone_p": p} for p in (8, 16, 32, 64)] + [{"cone_p": 64, "emit": "samples"}]
 SAMPLING_FORMS = {
     "m1_sphere": _ONE_LEVEL, "m1_noise": _ONE_LEVEL, "lego_4k": _ONE_LEVEL, "lego_12k": _ONE_LEVEL, "lego_256": _ONE_LEVEL,
     "lego_70k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 1}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"},
-                 {"split_p": 1, "count_l2": 1, "skip": 0}, {"split_p": 1, "count_l2": 1, "skip": 1}, {"split_p": 1, "count_l2": 0, "skip": 2}],
+                 {"split_p": 1, "count_l2": 1, "skip": 0}, {"split_p": 1, "count_l2": 1, "skip": 1}, {"split_p": 1, "count_l2": 0, "skip": 1}],
     "lego_160k": [{}, {"split_p": 8}, {"split_p": 1, "count_l2": 0}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"},
-                  {"skip": 0}, {"skip": 1}, {"skip": 2}],
+                  {"skip": 0}, {"skip": 1}],
     "near_far": _LEVELS, "degenerate": _LEVELS, "two_level_256": _LEVELS, "non_cubic": _LEVELS, "levels4_inside": _LEVELS,
     "cone_angle": _CONE_ONE, "cone_angle_levels": _CONE_LEVELS,
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r06_fused5; mkdir -p $O
+O=gpurun_out/r06_fused_sample; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_fused_sampling.py tests/test_k2_reference.py -x -q 2>&1 | tail -8 > $O/tests.log
 timeout 300 python tools/fuse_trace.py profiles/r02_sampling_state.npz 20 > $O/fuse_trace.log 2>&1
 for f in 1 0; do
