@@ -59,173 +59,10 @@ sys.path.insert(0, ROOT)
 import nerfacc_amd as nerfacc  # noqa: E402
 from nerfacc_amd import sharding  # noqa: E402
 from nerfacc_amd.cuda import _backend  # noqa: E402
-
-AABB = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
-RENDER_STEP = 5e-3
-TARGET_SAMPLES = 1 << 18
-INIT_RAYS = 1024
-GRID_RES = 128
-HBM_PEAK_GBS = 8000.0
-
-
-# ------------------------------------------------------------------------------------------
-# procedural scene + torch-native field (stand-ins for nerf_synthetic/lego and tiny-cuda-nn)
-# ------------------------------------------------------------------------------------------
-def lego_like_density(x: torch.Tensor) -> torch.Tensor:
-    """analytic occupancy of a bulldozer-ish union of boxes; x [..., 3] in world units -> bool"""
-    def box(c, h):
-        c = torch.tensor(c, device=x.device)
-        h = torch.tensor(h, device=x.device)
-        return ((x - c).abs() <= h).all(-1)
-
-    body = box([0.0, 0.0, -0.25], [0.75, 0.45, 0.2])
-    cabin = box([-0.25, 0.0, 0.2], [0.3, 0.35, 0.25]) & ~box([-0.25, 0.0, 0.25], [0.22, 0.4, 0.12])
-    plate = box([0.0, 0.0, -0.55], [0.95, 0.7, 0.06])
-    arm = box([0.65, 0.0, 0.1], [0.35, 0.08, 0.08]) | box([0.95, 0.0, -0.1], [0.06, 0.4, 0.25])
-    studs = (torch.sin(x[..., 0] * 24.0) * torch.sin(x[..., 1] * 24.0) > 0.5) & box([0.0, 0.0, -0.45], [0.9, 0.65, 0.05])
-    return body | cabin | plate | arm | studs
-
-
-class DenseGridField(torch.nn.Module):
-    """sigma = exp(g[0](x)), rgb = sigmoid(g[1:4](x)); one 4-channel voxel grid, trilinear lookups
-    (one gather pass forward, one scatter pass backward per query)."""
-
-    def __init__(self, aabb, res=128, occ_fn=None):
-        super().__init__()
-        self.register_buffer("aabb", torch.tensor(aabb, dtype=torch.float32))
-        g = (torch.arange(res, dtype=torch.float32) + 0.5) / res
-        lo, hi = self.aabb[:3], self.aabb[3:]
-        X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
-        pts = torch.stack([X, Y, Z], -1) * (hi - lo) + lo
-        occ = (occ_fn or lego_like_density)(pts)
-        dens = torch.where(occ, math.log(50.0), math.log(1e-4)).float()
-        gen = torch.Generator().manual_seed(42)
-        col = torch.randn((3, res, res, res), generator=gen) * 0.5 + (pts.permute(3, 0, 1, 2) * 1.5)
-        # stored [1, 4, Z, Y, X] so that grid_sample's (x, y, z) coordinate order needs no shuffle
-        vol = torch.cat([dens[None], col], 0).permute(0, 3, 2, 1)
-        self.grid = torch.nn.Parameter(vol[None].contiguous())
-        self.register_buffer("u_scale", 2.0 / (hi - lo))
-        self.register_buffer("u_shift", -2.0 * lo / (hi - lo) - 1.0)
-
-    def _lookup(self, grid, x):
-        u = torch.addcmul(self.u_shift, x, self.u_scale).view(1, 1, 1, -1, 3)
-        out = F.grid_sample(grid, u, mode="bilinear", padding_mode="border", align_corners=False)
-        return out.view(grid.shape[1], -1).t()
-
-    def query_density(self, x):
-        return torch.exp(self._lookup(self.grid[:, :1], x))
-
-    def forward(self, x, dirs=None):
-        f = self._lookup(self.grid, x)
-        return torch.sigmoid(f[:, 1:4]), torch.exp(f[:, :1])
-
-
-class GridMlpField(torch.nn.Module):
-    """`--field grid+mlp`: a dense FEATURE grid (8 channels) decoded by a two-layer MLP — the shape of the reference's NGP
-    field (examples/radiance_fields/ngp.py:79-163: encoding + small MLPs) as far as the gradient exchange is concerned: seven
-    parameter tensors from 4 floats to 8 x res^3, reached by autograd in reverse order.  Not the headline field: it exists so that
-    the multi-GPU path (ExchangeAdam's hooks, chunk order, both exchange modes) is exercised on a multi-tensor graph."""
-
-    def __init__(self, aabb, res=64, feat=8, hidden=32):
-        super().__init__()
-        self.register_buffer("aabb", torch.tensor(aabb, dtype=torch.float32))
-        lo, hi = self.aabb[:3], self.aabb[3:]
-        gen = torch.Generator().manual_seed(7)
-        self.grid = torch.nn.Parameter(0.1 * torch.randn((1, feat, res, res, res), generator=gen))
-        self.l1, self.l2, self.l3 = torch.nn.Linear(feat, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, 4)
-        with torch.no_grad():                       # starts as fog and grey, like the dense-grid student
-            self.l3.weight.mul_(0.1)
-            self.l3.bias.copy_(torch.tensor([math.log(0.5), 0.0, 0.0, 0.0]))
-        self.register_buffer("u_scale", 2.0 / (hi - lo))
-        self.register_buffer("u_shift", -2.0 * lo / (hi - lo) - 1.0)
-
-    def _decode(self, x):
-        u = torch.addcmul(self.u_shift, x, self.u_scale).view(1, 1, 1, -1, 3)
-        f = F.grid_sample(self.grid, u, mode="bilinear", padding_mode="border", align_corners=False).view(self.grid.shape[1], -1).t()
-        return self.l3(torch.relu(self.l2(torch.relu(self.l1(f)))))
-
-    def query_density(self, x):
-        return torch.exp(self._decode(x)[:, :1].clamp(max=8.0))
-
-    def forward(self, x, dirs=None):
-        f = self._decode(x)
-        return torch.sigmoid(f[:, 1:4]), torch.exp(f[:, :1].clamp(max=8.0))
-
-
-def make_ray_pool(n_pool: int, seed: int, device) -> tuple:
-    """random pixels of 100 cameras on a radius-4 sphere looking at the origin (OpenGL camera,
-    800x800, focal 1111.1)."""
-    gen = torch.Generator(device="cpu").manual_seed(seed)
-    n_cams, W, focal = 100, 800, 0.5 * 800 / math.tan(0.5 * 0.6911112070083618)
-    cam_pos = torch.randn((n_cams, 3), generator=gen)
-    cam_pos[:, 2] = cam_pos[:, 2].abs() * 0.7 + 0.2                 # upper hemisphere like the dataset
-    cam_pos = 4.0 * cam_pos / cam_pos.norm(dim=-1, keepdim=True)
-    fwd = -cam_pos / cam_pos.norm(dim=-1, keepdim=True)
-    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
-    right = torch.linalg.cross(fwd, up)
-    right = right / right.norm(dim=-1, keepdim=True)
-    true_up = torch.linalg.cross(right, fwd)
-    cam = torch.randint(0, n_cams, (n_pool,), generator=gen)
-    px = torch.randint(0, W, (n_pool, 2), generator=gen).float() + 0.5
-    dx, dy = (px[:, 0] - W / 2) / focal, -(px[:, 1] - W / 2) / focal
-    d = fwd[cam] + dx[:, None] * right[cam] + dy[:, None] * true_up[cam]
-    d = d / d.norm(dim=-1, keepdim=True)
-    return cam_pos[cam].contiguous().to(device), d.contiguous().to(device)
-
-
-def render_rays(field, est, rays_o, rays_d, bkgd, training: bool):
-    """examples/utils.py:54-167 (render_image_with_occgrid), one chunk."""
-    def sigma_fn(t_starts, t_ends, ray_indices):
-        if t_starts.shape[0] == 0:
-            return torch.empty((0,), device=t_starts.device)
-        pos = nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
-        return field.query_density(pos).squeeze(-1)
-
-    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        if t_starts.shape[0] == 0:
-            return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
-        pos = nerfacc.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
-        rgb, sigma = field(pos)            # (this stand-in field has no view dependence)
-        return rgb, sigma.squeeze(-1)
-
-    ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
-                                                 render_step_size=RENDER_STEP, stratified=training, cone_angle=0.0,
-                                                 alpha_thre=0.0)
-    rgb, opacity, depth, _ = nerfacc.rendering(t_starts, t_ends, ray_indices, n_rays=rays_o.shape[0],
-                                               rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
-    return rgb, opacity, depth, t_starts.shape[0]
-
-
-# candidate samples of the most recent estimator.sampling call of render_rays_reference_style (what its sigma_fn was handed: the
-# traversal's output before the visibility filter) — the timed steps add it up, no extra read-back
-LAST_CALL = {"candidates": 0}
-
-
-def render_rays_reference_style(field, est, rays_o, rays_d, bkgd, training: bool):
-    """examples/utils.py:87-155 as written there: the user-side closures index the rays with plain torch ops
-    (`rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0`); only nerfacc's own
-    calls (`estimator.sampling`, `nerfacc.rendering`) reach this package."""
-    def sigma_fn(t_starts, t_ends, ray_indices):
-        LAST_CALL["candidates"] = t_starts.shape[0]
-        if t_starts.shape[0] == 0:
-            return torch.empty((0,), device=t_starts.device)
-        positions = rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
-        return field.query_density(positions).squeeze(-1)
-
-    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        if t_starts.shape[0] == 0:
-            return torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device)
-        positions = rays_o[ray_indices] + rays_d[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
-        rgb, sigma = field(positions, rays_d[ray_indices])
-        return rgb, sigma.squeeze(-1)
-
-    LAST_CALL["candidates"] = 0
-    ray_indices, t_starts, t_ends = est.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=0.0, far_plane=1e10,
-                                                 render_step_size=RENDER_STEP, stratified=training, cone_angle=0.0,
-                                                 alpha_thre=0.0)
-    rgb, opacity, depth, _ = nerfacc.rendering(t_starts, t_ends, ray_indices, n_rays=rays_o.shape[0],
-                                               rgb_sigma_fn=rgb_sigma_fn, render_bkgd=bkgd)
-    return rgb, opacity, depth, t_starts.shape[0]
+from benchlib.scene import (AABB, GRID_RES, HBM_PEAK_GBS, INIT_RAYS, LAST_CALL, RENDER_STEP, TARGET_SAMPLES, DenseGridField, GridMlpField,  # noqa: E402,F401
+                            lego_like_density, make_ray_pool, render_rays, render_rays_reference_style)
+from benchlib.aux_legs import DensityGrid, propnet_step_leg, scene_sweep_leg  # noqa: E402,F401
+from benchlib.profiler import dda_steps, profile_steps  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------
@@ -409,228 +246,6 @@ def cpu_baseline(field, est, pool_o, pool_d, budget_s=24.0):
         "host_cores_available": cores,
         "reference_host_build": ref_leg,
     }
-
-
-# ------------------------------------------------------------------------------------------
-# auxiliary leg: one PropNet training step (BASELINE.json configs[2]; examples/train_ngp_nerf_prop.py:150-245 with
-# examples/utils.py:170-264).  Not the metric: a few steps so that the pdf path is driver-measured too.
-# ------------------------------------------------------------------------------------------
-class DensityGrid(torch.nn.Module):
-    """proposal network stand-in (NGPDensityField is tiny-cuda-nn): sigma = exp(trilinear lookup in one res^3 grid)"""
-
-    def __init__(self, aabb, res):
-        super().__init__()
-        a = torch.tensor(aabb, dtype=torch.float32)
-        self.register_buffer("u_scale", 2.0 / (a[3:] - a[:3]))
-        self.register_buffer("u_shift", -2.0 * a[:3] / (a[3:] - a[:3]) - 1.0)
-        self.grid = torch.nn.Parameter(torch.full((1, 1, res, res, res), math.log(0.5)))
-
-    def forward(self, x):
-        u = torch.addcmul(self.u_shift, x.reshape(-1, 3), self.u_scale).view(1, 1, 1, -1, 3)
-        out = F.grid_sample(self.grid, u, mode="bilinear", padding_mode="border", align_corners=False)
-        return torch.exp(out.view(*x.shape[:-1], 1))
-
-
-def propnet_step_leg(field, pool_o, pool_d, pool_rgb, bkgd, n_steps, n_warmup, n_rays=4096,
-                     num_samples=48, num_samples_per_prop=(256, 96), near_plane=2.0, far_plane=6.0):
-    """configs[2]'s shapes (4096 rays, proposal levels of 256 and 96 samples, 48 final samples, lindisp, opaque background, two
-    proposal networks) on the bench scene; the radiance field is a copy of the bench's field, the proposal networks are 64^3 /
-    128^3 density grids.  A step = PropNetEstimator.sampling (2 x importance_sampling + transmittance per level, proposal
-    gradients on the reference's schedule: every 5th step after its first 1000) + batched rendering + update_every_n_steps
-    (searchsorted-based histogram loss, proposal optimizer) + smooth-L1 loss, backward, Adam."""
-    import copy
-
-    device = pool_o.device
-    rf = copy.deepcopy(field)
-    props = [DensityGrid(AABB, 64).to(device), DensityGrid(AABB, 128).to(device)]
-    prop_opt = torch.optim.Adam([q for m in props for q in m.parameters()], lr=1e-2, eps=1e-15, fused=True)
-    est = nerfacc.PropNetEstimator(prop_opt, None).to(device)
-    opt = torch.optim.Adam(rf.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
-    wants_grad = nerfacc.estimators.prop_net.get_proposal_requires_grad_fn()
-    counter = {"step": 1000}                      # the schedule's steady state: proposal gradients every 5th step
-
-    def step():
-        idx = torch.randint(0, pool_o.shape[0], (n_rays,), device=device)
-        o, d, pixels = pool_o[idx], pool_d[idx], pool_rgb[idx]
-
-        def prop_sigma_fn(t_starts, t_ends, net):
-            sig = net(o[:, None, :] + d[:, None, :] * (t_starts + t_ends)[..., None] / 2.0).clone()
-            sig[..., -1, :] = torch.inf                                  # opaque_bkgd
-            return sig.squeeze(-1)
-
-        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-            pos = o[:, None, :] + d[:, None, :] * (t_starts + t_ends)[..., None] / 2.0
-            rgb, sig = rf(pos.reshape(-1, 3))
-            rgb, sig = rgb.reshape(*pos.shape[:-1], 3), sig.reshape(*pos.shape[:-1], 1).clone()
-            sig[..., -1, :] = torch.inf
-            return rgb, sig.squeeze(-1)
-
-        req = wants_grad(counter["step"])
-        t_starts, t_ends = est.sampling(prop_sigma_fns=[lambda *a, n=n: prop_sigma_fn(*a, n) for n in props],
-                                        prop_samples=list(num_samples_per_prop), num_samples=num_samples, n_rays=n_rays,
-                                        near_plane=near_plane, far_plane=far_plane, sampling_type="lindisp", stratified=True,
-                                        requires_grad=req)
-        rgb, _, _, extras = nerfacc.rendering(t_starts, t_ends, ray_indices=None, n_rays=None, rgb_sigma_fn=rgb_sigma_fn,
-                                              render_bkgd=bkgd)
-        est.update_every_n_steps(extras["trans"], req, loss_scaler=1024)
-        loss = F.smooth_l1_loss(rgb, pixels)
-        opt.zero_grad()
-        (loss * 1024.0).backward()
-        opt.step()
-        counter["step"] += 1
-
-    for _ in range(n_warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    prof = profile_steps(step, min(n_steps, 10))
-    per_ray = num_samples + sum(num_samples_per_prop)
-    out = {"workload": f"configs[2] shapes on the bench scene: {n_rays} rays x proposal levels {list(num_samples_per_prop)} -> {num_samples} "
-                       "samples, lindisp, opaque background, 2 proposal density grids (64^3, 128^3) + the bench's field; proposal "
-                       "gradients every 5th step (the reference schedule's steady state)",
-           "steps": n_steps, "ms_per_step": el / n_steps * 1e3, "rays_per_sec": n_rays * n_steps / el,
-           "samples_per_sec": n_rays * num_samples * n_steps / el, "field_queries_per_sec": n_rays * per_ray * n_steps / el}
-    if prof is not None and "error" not in prof:
-        out["path_us_per_step"] = prof["nfa_us_per_step"]
-        out["gpu_busy_us_per_step"] = prof["busy_us_per_step"]
-        out["top_kernels_us_per_step"] = prof["top_kernels_us_per_step"]
-    return out
-
-
-# ------------------------------------------------------------------------------------------
-# GPU activity of a few profiled steps: union of kernel intervals (idle fraction) and the nfa:: share
-# ------------------------------------------------------------------------------------------
-def scene_sweep_leg(pool_o, pool_d, bkgd, n_steps, n_warmup, pretrain=300, occ_res=256, n_pool=1 << 18):
-    """BASELINE.json configs[4] (the reference's 8-scene nerf_synthetic sweep with a 256^3 occupancy grid, PSNR + rays/s per scene,
-    docs/source/examples/static/ngp.rst:36-42) on stand-ins: the eight procedural scenes of tools/scenes.py — thin structures, a
-    dense slab, a hollow shell, a near-empty grid, the reference's rand > 0.5 noise, ... — each with its own teacher field, a student
-    trained from fog for `pretrain` steps of the configs[1] loop (256^3 occupancy grid, adaptive batch towards 2^18 samples), then
-    `n_steps` timed steps: rays/s, samples/s, samples per ray, PSNR on held-out rays.  Not the metric: what it guards is that the
-    data-dependent plan switches of the sampling call (tools/scene_sweep.py checks them kernel by kernel) hold up across scenes."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import scenes as S
-
-    device = pool_o.device
-    n_pool = min(n_pool, pool_o.shape[0])
-    n_held = min(16384, n_pool // 4)
-    pool_o, pool_d = pool_o[:n_pool], pool_d[:n_pool]
-    held = slice(n_pool - n_held, n_pool)                    # rays the students never train on
-    out = {}
-    for name, occ_fn in S.SCENES.items():
-        torch.manual_seed(7)
-        teacher = DenseGridField(AABB, GRID_RES, occ_fn=lambda x, f=occ_fn: f(torch, x)).to(device).eval()
-        student = DenseGridField(AABB, GRID_RES).to(device)
-        with torch.no_grad():
-            student.grid[:, :1].fill_(math.log(0.5))
-            student.grid[:, 1:].zero_()
-        est_t = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=occ_res, levels=1).to(device)
-        est = nerfacc.OccGridEstimator(roi_aabb=AABB, resolution=occ_res, levels=1).to(device)
-        est_t.train()
-        for _ in range(4):
-            est_t._update(step=0, occ_eval_fn=lambda x: teacher.query_density(x) * RENDER_STEP, occ_thre=1e-2)
-        est_t.eval()
-        with torch.no_grad():
-            rgb_pool = torch.cat([render_rays(teacher, est_t, pool_o[i:i + (1 << 16)], pool_d[i:i + (1 << 16)], bkgd, False)[0]
-                                  for i in range(0, n_pool, 1 << 16)])
-        opt = torch.optim.Adam(student.parameters(), lr=1e-2, eps=1e-15, weight_decay=1e-6, fused=True)
-        est.train()
-        st = {"rays": INIT_RAYS, "step": 0, "n": 0, "s": 0}
-
-        def step():
-            est.update_every_n_steps(step=st["step"], occ_eval_fn=lambda x: student.query_density(x) * RENDER_STEP, occ_thre=1e-2)
-            idx = torch.randint(0, n_pool - n_held, (st["rays"],), device=device)
-            rgb, _, _, n_s = render_rays_reference_style(student, est, pool_o[idx], pool_d[idx], bkgd, True)
-            opt.zero_grad()
-            if n_s > 0:
-                (F.smooth_l1_loss(rgb, rgb_pool[idx]) * 1024.0).backward()
-                opt.step()
-                st["rays"] = min(max(int(st["rays"] * (TARGET_SAMPLES / n_s)), 64), n_pool - n_held)      # train_ngp_nerf_occ.py:187-194
-            st["n"] += idx.shape[0]
-            st["s"] += n_s
-            st["step"] += 1
-
-        for _ in range(pretrain + n_warmup):
-            step()
-        st.update(n=0, s=0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        est.eval()
-        with torch.no_grad():
-            pred = render_rays(student, est, pool_o[held], pool_d[held], bkgd, False)[0]
-            mse = F.mse_loss(pred, rgb_pool[held]).item()
-        out[name] = {"ms_per_step": dt / n_steps * 1e3, "rays_per_sec": st["n"] / dt, "samples_per_sec": st["s"] / dt,
-                     "rays_per_iter": st["n"] / n_steps, "samples_per_ray": st["s"] / max(st["n"], 1),
-                     "occupied_fraction": est.binaries.float().mean().item(), "psnr_heldout": -10.0 * math.log10(max(mse, 1e-12))}
-    return {"workload": f"configs[4] stand-in: eight procedural scenes (tools/scenes.py), {occ_res}^3 occupancy grid, the configs[1] step; "
-                        f"{pretrain} training steps from fog, then {n_steps} timed steps; PSNR against the scene's teacher on {n_held} held-out rays",
-            "scenes": out}
-
-
-def profile_steps(step_fn, n_steps):
-    """{'busy_us_per_step', 'nfa_us_per_step', 'kernels_per_step', 'nfa_kernels_per_step', 'top'} from torch.profiler's
-    device-kernel events, or None when the profiler is unavailable"""
-    try:
-        from torch.profiler import ProfilerActivity, profile
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            for _ in range(n_steps):
-                step_fn()
-            torch.cuda.synchronize()
-        ivals, nfa_us, n_nfa, per_name = [], 0.0, 0, {}
-        for ev in prof.events():
-            if getattr(ev, "device_type", None) is None or "cuda" not in str(ev.device_type).lower():
-                continue
-            dur = float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
-            if dur <= 0.0:
-                continue
-            start = float(ev.time_range.start)
-            ivals.append((start, start + dur))
-            short = ev.name.split("(")[0].replace("void ", "")[:70]
-            c = per_name.setdefault(short, [0, 0.0])
-            c[0] += 1
-            c[1] += dur
-            if "nfa::" in ev.name:
-                nfa_us += dur
-                n_nfa += 1
-        if not ivals:
-            return None
-        ivals.sort()
-        busy, (cs, ce) = 0.0, ivals[0]
-        for a, b in ivals[1:]:
-            if a > ce:
-                busy += ce - cs
-                cs, ce = a, b
-            else:
-                ce = max(ce, b)
-        busy += ce - cs
-        top = sorted(per_name.items(), key=lambda kv: -kv[1][1])[:8]
-        return {"busy_us_per_step": busy / n_steps, "nfa_us_per_step": nfa_us / n_steps,
-                "kernels_per_step": len(ivals) / n_steps, "nfa_kernels_per_step": n_nfa / n_steps,
-                "top_kernels_us_per_step": {k: round(v[1] / n_steps, 2) for k, v in top}}
-    except Exception as e:      # noqa: BLE001  (a missing profiler must not cost the bench line)
-        return {"error": repr(e)[:200]}
-
-
-def dda_steps(rays_o, rays_d, aabb, res, near, far):
-    """voxels a ray's DDA walk visits in a one-level grid without early termination: 1 + L1 distance between the
-    first and the last voxel (utils_grid.cuh:58-142: the walk ends when an index passes final_index)"""
-    lo, hi = aabb[:3], aabb[3:]
-    inv = 1.0 / rays_d
-    t0, t1 = (lo - rays_o) * inv, (hi - rays_o) * inv
-    tmin = torch.minimum(t0, t1).amax(-1).clamp_min(near)
-    tmax = torch.maximum(t0, t1).amin(-1).clamp_max(far)
-    ok = tmax > tmin
-    cell = lambda t: (((rays_o + rays_d * t[:, None]) - lo) / (hi - lo) * res).floor().clamp(0, res - 1)
-    steps = 1 + (cell(tmax - 1e-6) - cell(tmin + 1e-6)).abs().sum(-1)
-    return int(steps[ok].sum().item())
 
 
 def main():

@@ -119,6 +119,12 @@ int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_thre, void 
  * binaries: the same number of bytes; bricks: nfa_packed_grid_words(...) words; workspace as nfa_grid_threshold. */
 int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int32_t rx, int32_t ry, int32_t rz, float occ_thre,
                               void *workspace, uint8_t *binaries, float *threshold_out, uint64_t *bricks, void *stream);
+/* The occupied cells of one level in ascending order — `torch.nonzero(binaries[lvl].flatten())[:, 0]` of
+ * OccGridEstimator._sample_uniform_and_occupied_cells (occ_grid.py:356) — in one launch: out[k] = the k-th flat index c with
+ * cells[c] != 0.  cells: the level's n_cells bool bytes (0 / 1, 16-byte aligned); capacity: entries `out` holds (the count is in the
+ * packed grid's header, nfa_pack_binaries: no read-back on this path; indices beyond it are not stored).  sync: NFA_SYNC_BYTES of
+ * zeroed device memory, left zero (see nfa_traverse_sample).  Up to 2^27 cells per call. */
+int nfa_grid_occupied_cells(const uint8_t *cells, int64_t n_cells, int64_t *out, int64_t capacity, void *sync, void *stream);
 
 /* Arguments of traverse_grids (nerfacc.cpp:71-98, grid.cu:320-474).  The reference does
  * count -> cumsum + .item() -> allocate -> fill inside one C++ call; a C ABI cannot allocate
@@ -362,8 +368,9 @@ int nfa_rendering_fwd(const int64_t *ray_indices, const float *t_starts, const f
                       float *alphas, float *colors, float *opacities, float *depths, void *stream);
 /* VJP of the above w.r.t. sigmas and rgbs.  g_colors/g_opacities/g_depths per ray,
  * g_weights/g_trans/g_alphas per sample; all six nullable.  opacities/depths: forward outputs.
- * weights / trans / alphas must be the forward pass's outputs for the same inputs: the kernel forms weights as
- * trans * alphas (exactly what the forward pass stored) and does not read the weights array. */
+ * trans / alphas must be the forward pass's outputs for the same inputs: the kernel forms the weights as trans * alphas (exactly
+ * what the forward pass stored).  `weights` (and `sigmas`) are NOT read and may be NULL — the parameters stay for the callers written
+ * against rounds 1-4; passing weights that are not trans * alphas of the same forward pass changes nothing. */
 int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                       const float *sigmas, const float *rgbs, const float *weights,
                       const float *trans, const float *alphas, const float *opacities,

@@ -12,6 +12,7 @@
 // element per lane; arithmetic order follows the torch expressions (no contraction: the
 // library is built with -ffp-contract=off).
 #include "common.hpp"
+#include "lookback.hpp"
 
 namespace nfa {
 namespace {
@@ -148,6 +149,85 @@ __global__ __launch_bounds__(kBlock) void grid_mark_invisible_kernel(
     }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// The occupied cells of one level, ascending — what `torch.nonzero(binaries[lvl].flatten())[:, 0]` returns (occ_grid.py:356) — as ONE
+// launch.  A thread takes CPT consecutive cells (16-byte loads of the bool bytes), the wave and the workgroup rank them with ballots'
+// cousins (popcounts + the DPP sum), the workgroups hand their counts on through the caller's sync block (lookback.hpp: static ids,
+// every workgroup resident, bounded waits) and every thread stores the indices of its cells.  A look-back that gives up is not
+// reported to the host (this path has no read-back: the count comes from the packed grid's header): the workgroup counts the cells
+// before its own itself — slow, correct, and it has never been seen to happen.
+// ----------------------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(kBlock) void occupied_cells_kernel(const uint8_t *__restrict__ cells, int64_t n_cells, int64_t *__restrict__ out,
+                                                                int64_t capacity, uint64_t *__restrict__ sync)
+{
+    static_assert(CPT % 16 == 0, "whole 16-byte loads");
+    __shared__ int64_t s_w[kWavesPerBlock];
+    __shared__ int64_t s_pre;
+    const int lane = lane_id(), wv = wave_in_block();
+    const int64_t b = blockIdx.x, nb = gridDim.x;
+    const int64_t c0 = (b * kBlock + threadIdx.x) * CPT;
+    uint32_t w[CPT / 4];
+#pragma unroll
+    for (int k = 0; k < CPT / 16; ++k) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int64_t c = c0 + 16 * k;
+        if (c + 16 <= n_cells) v = *reinterpret_cast<const uint4 *>(cells + c);
+        else {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; ++j) if (c + j < n_cells && cells[c + j]) t[j >> 2] |= 1u << (8 * (j & 3));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < CPT / 4; ++k) {
+        // a bool byte is 0 or 1 (torch): the four bytes of a word add up in its popcount
+        mine += __popc(w[k] & 0x01010101u);
+    }
+    // exclusive rank inside the wave (DPP scan of the lane counts), wave totals through LDS
+    int64_t incl = mine;
+    { const int64_t u = dpp_i64<kDppRowShr + 1>(incl); if ((lane & 15) >= 1) incl += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 2>(incl); if ((lane & 15) >= 2) incl += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 4>(incl); if ((lane & 15) >= 4) incl += u; }
+    { const int64_t u = dpp_i64<kDppRowShr + 8>(incl); if ((lane & 15) >= 8) incl += u; }
+    { const int64_t u = dpp_i64<kDppRowBcast15>(incl); if (lane & 16) incl += u; }
+    { const int64_t u = dpp_i64<kDppRowBcast31>(incl); if (lane & 32) incl += u; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        const int64_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        int64_t excl = sync_publish_and_lookback(sync, b, tot, 0, 0, lane);
+        if (excl < 0) {                                   // (bounded wait ran out: count the cells before this workgroup directly)
+            int64_t cnt = 0;
+            const int64_t end = b * kBlock * CPT;
+            for (int64_t c = (int64_t)lane * 16; c < end; c += 64 * 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cells + c);        // (end is a multiple of 16 and <= n_cells here)
+                cnt += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+            }
+            excl = wave_sum_i64(cnt);
+        }
+        if (lane == 0) s_pre = excl;
+        sync_leave(sync, nb, lane);
+    }
+    __syncthreads();
+    int64_t dst = s_pre + (incl - mine);
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock - 1; ++k) dst += k < wv ? s_w[k] : 0;
+#pragma unroll
+    for (int k = 0; k < CPT / 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((w[k] >> (8 * j)) & 1u) {
+                if (dst < capacity) out[dst] = c0 + 4 * k + j;
+                ++dst;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace nfa
 
@@ -215,4 +295,26 @@ NFA_EXPORT int nfa_grid_threshold(const float *occs, int64_t n_cells, float occ_
     hipLaunchKernelGGL(grid_threshold_kernel, dim3(blocks_for(n_cells)), dim3(kBlock), 0, s, occs, n_cells,
                        (const double *)workspace, nb, occ_thre, binaries, threshold_out);
     return check_launch("grid_threshold");
+}
+
+// occupied cells of one level in ascending order: out[0 .. count) = the flat indices c with cells[c] != 0 (what torch.nonzero
+// returns for the flattened level, occ_grid.py:356).  `capacity`: entries `out` holds (the caller knows the count from the packed
+// grid's header; cells beyond it are not stored).  `sync`: NFA_SYNC_BYTES, zero, left zero (include/nerfacc_hip.h).
+NFA_EXPORT int nfa_grid_occupied_cells(const uint8_t *cells, int64_t n_cells, int64_t *out, int64_t capacity, void *sync, void *stream)
+{
+    NFA_REQUIRE(n_cells >= 0 && capacity >= 0, "grid_occupied_cells: negative size");
+    if (n_cells == 0 || capacity == 0) return NFA_OK;
+    NFA_REQUIRE(cells && out && sync, "grid_occupied_cells: NULL pointer");
+    NFA_REQUIRE((reinterpret_cast<uintptr_t>(cells) & 15u) == 0, "grid_occupied_cells: cells must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    // cells per thread: 16 while that keeps the launch inside the sync block's states and on the chip at once, else 64 / 256
+    const int64_t per16 = ceil_div(n_cells, (int64_t)kBlock * 16), per64 = ceil_div(n_cells, (int64_t)kBlock * 64), per256 = ceil_div(n_cells, (int64_t)kBlock * 256);
+    const int64_t limit = std::min<int64_t>(kSyncMaxBlocks, (int64_t)kNumCU * 4);
+    if (per16 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<16>), dim3((unsigned)per16), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
+    else if (per64 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<64>), dim3((unsigned)per64), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
+    else {
+        NFA_REQUIRE(per256 <= limit, "grid_occupied_cells: %lld cells are more than one launch ranks (%lld)", (long long)n_cells, (long long)(limit * kBlock * 256));
+        hipLaunchKernelGGL((occupied_cells_kernel<256>), dim3((unsigned)per256), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
+    }
+    return check_launch("occupied_cells_kernel");
 }

@@ -1265,7 +1265,8 @@ NFA_EXPORT int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_star
     (void)sigmas;
     NFA_REQUIRE(n >= 0 && n_rays >= 0, "rendering_bwd: negative size");
     if (n == 0) return NFA_OK;
-    NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && weights && trans && alphas, "rendering_bwd: NULL pointer");
+    (void)weights;      // (not read since round 5: the kernel forms w = trans * alphas, exactly what the forward pass stored; nullable)
+    NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && trans && alphas, "rendering_bwd: NULL pointer");
     NFA_REQUIRE(!(g_depths && expected_depths) || (opacities && depths), "rendering_bwd: opacities/depths needed for g_depths");
     const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
     NFA_LAUNCH_TILED(rendering_bwd_kernel, pl, n, (hipStream_t)stream,

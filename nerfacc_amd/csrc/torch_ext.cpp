@@ -285,6 +285,24 @@ std::vector<int64_t> grid_occupied_counts(const Tensor &binaries) {
     TORCH_CHECK(false, "nerfacc_amd: packed grid vanished from the cache");
 }
 
+void *sync_block(const Tensor &like, hipStream_t s);
+
+// the occupied cells of level `lvl`, ascending (torch.nonzero(binaries[lvl].flatten())[:, 0], occ_grid.py:356) without rocprim's
+// partition and without a read-back: the count comes from the packed grid's header
+Tensor grid_occupied_cells(const Tensor &binaries, int64_t lvl) {
+    check_input(binaries, "binaries", at::kBool);
+    TORCH_CHECK(binaries.dim() == 4 && lvl >= 0 && lvl < binaries.size(0), "binaries must be [levels, rx, ry, rz] and lvl one of its levels");
+    const std::vector<int64_t> counts = grid_occupied_counts(binaries);
+    TORCH_CHECK(lvl < (int64_t)counts.size(), "grid_occupied_cells: level counts are kept for the first 8 levels");
+    const int64_t n_cells = binaries.size(1) * binaries.size(2) * binaries.size(3), cnt = counts[lvl];
+    Tensor out = at::empty({cnt}, opts(binaries, at::kLong));
+    if (cnt == 0) return out;
+    Guard g(device_of(binaries));
+    hipStream_t s = stream_of(binaries);
+    check_rc(nfa_grid_occupied_cells((const uint8_t *)binaries.data_ptr() + lvl * n_cells, n_cells, ptr<int64_t>(out), cnt, sync_block(binaries, s), s));
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RaySegmentsSpec (data_spec.hpp:6-14; nerfacc.cpp:128-137): seven optional tensors
 // ---------------------------------------------------------------------------------------------------
@@ -881,9 +899,10 @@ std::vector<RaySegmentsSpec> importance_sampling(const RaySegmentsSpec &seg, con
         Tensor cnts = n_intervals.cast<Tensor>();
         TORCH_CHECK(cnts.is_cuda() && cnts.device() == cdfs.device(), "n_intervals_per_ray must live on the device of cdfs");
         nfa_ray_segments view = seg.view();
+        TORCH_CHECK(at::isIntegralType(cnts.scalar_type(), /*includeBool=*/false), "n_intervals_per_ray must be an integer tensor, got ",
+                    cnts.scalar_type(), " (a float count would be truncated silently)");
         cnts = cnts.to(at::kLong).reshape({-1}).contiguous();
         TORCH_CHECK(cnts.numel() == view.n_rays, "n_intervals_per_ray must hold one count per ray (", view.n_rays, "), got ", cnts.numel());
-        TORCH_CHECK(cnts.numel() == 0 || cnts.min().item<int64_t>() >= 0, "n_intervals_per_ray must not be negative");
         RaySegmentsSpec samples, intervals;
         samples.chunk_cnts = cnts;
         Tensor cs = at::cumsum(cnts, 0);
@@ -891,7 +910,15 @@ std::vector<RaySegmentsSpec> importance_sampling(const RaySegmentsSpec &seg, con
         intervals.chunk_cnts = (cnts + 1) * (cnts > 0).to(at::kLong);
         Tensor ics = at::cumsum(*intervals.chunk_cnts, 0);
         intervals.chunk_starts = ics - *intervals.chunk_cnts;
-        const int64_t n_s = cnts.numel() ? cs[-1].item<int64_t>() : 0, n_e = cnts.numel() ? ics[-1].item<int64_t>() : 0;
+        // ONE read-back: the smallest count and the two totals together (three blocking .item() calls before)
+        int64_t n_s = 0, n_e = 0;
+        if (cnts.numel()) {
+            const Tensor three = at::stack({cnts.min(), cs[-1], ics[-1]}).cpu();
+            const int64_t *h3 = three.data_ptr<int64_t>();
+            TORCH_CHECK(h3[0] >= 0, "n_intervals_per_ray must not be negative");
+            n_s = h3[1];
+            n_e = h3[2];
+        }
         const auto i64 = opts(cdfs, at::kLong), b8 = opts(cdfs, at::kBool);
         samples.vals = at::empty({n_s}, cdfs.options());
         samples.ray_indices = at::empty({n_s}, i64);
@@ -1451,6 +1478,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("grid_mark_invisible", &grid_mark_invisible);
     m.def("packed_bricks", &packed_bricks);
     m.def("grid_occupied_counts", &grid_occupied_counts);
+    m.def("grid_occupied_cells", &grid_occupied_cells);
     m.def("set_timing", &set_timing, "names"_a = py::none());
     m.def("timing_summary", &timing_summary);
 }

@@ -39,7 +39,7 @@ _FUSED_NAMES = (
     "render_weight_from_density_fwd", "render_weight_from_density_bwd",
     "visibility_compact", "accumulate_along_rays", "accumulate_along_rays_bwd",
     "rendering_fwd", "rendering_bwd",
-    "grid_cell_points", "grid_ema_update", "grid_threshold", "grid_mark_invisible", "grid_occupied_counts", "sample_positions",
+    "grid_cell_points", "grid_ema_update", "grid_threshold", "grid_mark_invisible", "grid_occupied_counts", "grid_occupied_cells", "sample_positions",
     "transform_stot", "edge_cdfs_fwd", "edge_cdfs_bwd", "pdf_loss_fwd", "pdf_loss_bwd",
 )
 

@@ -613,13 +613,13 @@ class _CtypesC:
             raise RuntimeError("cdfs and ray_segments.vals must have the same number of elements")
         if isinstance(n_intervels_per_ray, torch.Tensor):
             view = ray_segments._view()
+            if n_intervels_per_ray.dtype.is_floating_point or n_intervels_per_ray.dtype == torch.bool:
+                raise RuntimeError(f"n_intervals_per_ray must be an integer tensor, got {n_intervels_per_ray.dtype}")
             cnts = n_intervels_per_ray.to(torch.int64).reshape(-1).contiguous()
             if cnts.device != cdfs.device or not cnts.is_cuda:
                 raise RuntimeError("n_intervals_per_ray must live on the device of cdfs")
             if cnts.numel() != int(view.n_rays):
                 raise RuntimeError(f"n_intervals_per_ray must hold one count per ray ({int(view.n_rays)}), got {cnts.numel()}")
-            if cnts.numel() and int(cnts.min()) < 0:
-                raise RuntimeError("n_intervals_per_ray must not be negative")
             dev = cdfs.device
             samples, intervals = _PyRaySegmentsSpec(), _PyRaySegmentsSpec()
             samples.chunk_cnts = cnts
@@ -628,7 +628,11 @@ class _CtypesC:
             intervals.chunk_cnts = (cnts + 1) * (cnts > 0).to(torch.int64)
             ics = torch.cumsum(intervals.chunk_cnts, 0)
             intervals.chunk_starts = ics - intervals.chunk_cnts
-            n_s, n_e = (int(cs[-1]), int(ics[-1])) if cnts.numel() else (0, 0)
+            n_s = n_e = 0
+            if cnts.numel():            # one read-back: the smallest count and the two totals together
+                lo, n_s, n_e = torch.stack([cnts.min(), cs[-1], ics[-1]]).tolist()
+                if lo < 0:
+                    raise RuntimeError("n_intervals_per_ray must not be negative")
             samples.vals = torch.empty(n_s, dtype=torch.float32, device=dev)
             samples.ray_indices = torch.empty(n_s, dtype=torch.int64, device=dev)
             intervals.vals = torch.empty(n_e, dtype=torch.float32, device=dev)
@@ -1005,6 +1009,21 @@ class _CtypesC:
         """occupied voxels per level (what nonzero(binaries[level]) would count), from the packed grid's header"""
         _nonempty_bricks(binaries)
         return list(_brick_entry(binaries)["level_counts"])
+
+    @staticmethod
+    def grid_occupied_cells(binaries, lvl: int):
+        """the occupied cells of level `lvl`, ascending — torch.nonzero(binaries[lvl].flatten())[:, 0] (occ_grid.py:356) — one launch,
+        no read-back (the count is in the packed grid's header)"""
+        _check_input(binaries, "binaries", torch.bool)
+        cnt = _CtypesC.grid_occupied_counts(binaries)[lvl]
+        out = torch.empty(cnt, dtype=torch.int64, device=binaries.device)
+        if cnt:
+            n_cells = binaries[lvl].numel()
+            with _Guard(binaries):
+                stream = _stream(binaries)
+                _check(load_library().nfa_grid_occupied_cells(binaries.data_ptr() + lvl * n_cells, n_cells, _ptr(out), cnt,
+                                                              _ptr(_sync_block(binaries.device, stream)), stream))
+        return out
 
     @staticmethod
     def grid_threshold(occs, occ_thre: float, shape=None):

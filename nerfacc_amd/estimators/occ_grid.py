@@ -203,11 +203,11 @@ class OccGridEstimator(AbstractEstimator):
         for lvl in range(self.levels):
             uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
             uniform = uniform[self.occs[lvl * self.cells_per_lvl + uniform] >= 0.0]
-            if self.binaries.is_cuda and self.levels <= 8 and hasattr(torch, "nonzero_static"):
+            if self.binaries.is_cuda and self.levels <= 8 and self.binaries.is_contiguous():
                 # the number of occupied cells is in the header of the packed grid (read back once per grid state, together
-                # with what the traversal needs): `nonzero` can size its output without its own host sync
-                cnt = _C.grid_occupied_counts(self.binaries)[lvl]
-                occupied = torch.nonzero_static(self.binaries[lvl].flatten(), size=cnt)[:, 0]
+                # with what the traversal needs): the list is one launch of this library (round 6; torch.nonzero_static —
+                # rocprim's partition — before), no host sync, the same ascending order as `nonzero`
+                occupied = _C.grid_occupied_cells(self.binaries, lvl)
             else:
                 occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
             if n < len(occupied):

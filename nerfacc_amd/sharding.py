@@ -343,7 +343,18 @@ class ExchangeAdam:
             self._step()
         finally:
             # whatever happened (a world-size assert, a failed collective, a replaced gradient): the exchange is over as far as the
-            # module's other collectives are concerned, and the next backward() starts from a clean slate
+            # module's other collectives are concerned, and the next backward() starts from a clean slate.  Handles that
+            # are still in flight — _step() raised between launching a chunk and waiting for it — are waited for first: RCCL is using
+            # self.grad until then, and the next backward would write into it
+            for w in self._works:
+                if w is None:
+                    continue
+                for h in (w if isinstance(w, (list, tuple)) else (w,)):
+                    try:
+                        if h is not None and hasattr(h, "wait"):
+                            h.wait()
+                    except Exception:      # noqa: BLE001  (the exception that brought us here is the one to report)
+                        pass
             self._first_launch = None
             self._works = [None] * len(self.bounds)
             self._have = [0] * len(self.bounds)

@@ -244,6 +244,28 @@ def test_update_cell_selection_without_nonzero_sync_matches_reference_compositio
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,p", [((1, 128, 128, 128), 0.06), ((2, 20, 28, 12), 0.5), ((1, 5, 7, 3), 0.9), ((3, 64, 64, 64), 0.001),
+                                     ((1, 256, 256, 256), 0.02), ((4, 32, 32, 32), 1.0), ((2, 16, 16, 16), 0.0)])
+def test_occupied_cells_equal_nonzero(shape, p):
+    """round 6: the list of a level's occupied cells (OccGridEstimator._sample_uniform_and_occupied_cells, occ_grid.py:356) is one
+    launch of the library — ranks by popcount + a look-back over the workgroups, C ABI nfa_grid_occupied_cells — instead of
+    torch.nonzero_static: exactly `torch.nonzero(binaries[lvl].flatten())[:, 0]`, level after level, twenty times in a row (the sync
+    block is shared with the sampling call), in both host faces"""
+    from nerfacc_amd import cuda as C
+    from nerfacc_amd.cuda import _backend
+
+    g = torch.Generator().manual_seed(sum(shape))
+    binaries = (torch.rand(shape, generator=g) < p).to(DEV)
+    want = [torch.nonzero(binaries[l].flatten())[:, 0] for l in range(shape[0])]
+    for rep in range(20 if shape[1] <= 64 else 3):
+        for l in range(shape[0]):
+            got = C.grid_occupied_cells(binaries, l)
+            assert got.dtype == torch.int64 and torch.equal(got, want[l])
+    for l in range(shape[0]):
+        assert torch.equal(_backend._CtypesC.grid_occupied_cells(binaries, l), want[l])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 20, 28, 12), (1, 5, 7, 3), (3, 64, 64, 64)])
 def test_brick_distance_field(shape):
     """round 5: the packed grid carries, per 4^3 brick, the Chebyshev distance (in bricks, within its level, capped at 4) to the nearest
