@@ -375,7 +375,7 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
     const int ray_l = lane >> wshift, w = lane & (W - 1);
     const bool head = w == 0;
     int64_t n_rb = (R + RB - 1) >> rb_log2;
-    if (blk_end >= 0 && blk_end < n_rb) n_rb = blk_end;
+    if (Hook::kDeferred && blk_end >= 0 && blk_end < n_rb) n_rb = blk_end;      // (only the single-launch call bounds the blocks of a wave)
     for (int64_t blk = blk_first; blk < n_rb; blk += blk_step) {
         const int64_t r0 = blk << rb_log2, r = r0 + ray_l;
         const bool own = r < R;

@@ -168,17 +168,23 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
     return L;
 }
 
-// one lane per brick: gather its 4x4x4 voxels (16 loads of 4 contiguous bytes along z); the
-// wave's ballot of "non-empty" is the coarse bitmap (two u32 words per wave).
+// Sixteen lanes per brick — one per (dx, dy) row of its 4 x 4 x 4 voxels, ONE 16-byte (floats) or 4-byte (bools) load each — and a
+// 512-thread workgroup per coarse word (32 bricks).  The sixteen nibbles of a brick meet by OR over DPP row rotations (a brick's
+// lanes are one DPP row); the workgroup's eight waves put their four "non-empty" bits together in LDS.  (Rounds 1-5: one lane per
+// brick with 64 scalar loads and 64 byte stores — 128 workgroups of dependent loads: 24 us per 128^3 grid update in the bench's
+// trace, 8 MB in 24 us; round 6: ~2 k workgroups of one load per lane.)
 // FROM_OCCS: the voxels come from the float occupancies (`occs > min(mean, occ_thre)`, occ_grid.py:392-404) and the
 // bool grid is an OUTPUT — threshold and bit-pack in one pass (nfa_grid_threshold_packed).
+constexpr int kPackBlock = 512;
 template <bool FROM_OCCS>
-__global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
+__global__ __launch_bounds__(kPackBlock) void pack_bricks_kernel(
     const uint8_t *__restrict__ binaries, int n_grids, int rx, int ry, int rz,
     int nbx, int nby, int nbz, uint64_t *__restrict__ bricks, uint32_t *__restrict__ coarse, int64_t *__restrict__ level_counts,
     const float *__restrict__ occs, const double *__restrict__ partials, int n_partials, float occ_thre,
     uint8_t *__restrict__ binaries_out, float *__restrict__ thre_out)
 {
+    __shared__ uint32_t s_any[kPackBlock / 64];
+    __shared__ int s_cnt[kPackBlock / 64];
     float thre = 0.0f;
     if (FROM_OCCS) {
         __shared__ float s_thre;
@@ -194,9 +200,12 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
     }
     const int64_t per_grid = (int64_t)nbx * nby * nbz;
     const int64_t total = per_grid * n_grids;
-    const int64_t rounded = (total + 63) / 64 * 64;
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < rounded; b += (int64_t)gridDim.x * kBlock) {
-        uint64_t bits = 0;
+    const int64_t n_words = (total + 31) / 32;
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int lb = (int)(threadIdx.x >> 4), dx = (int)((threadIdx.x >> 2) & 3), dy = (int)(threadIdx.x & 3);
+    for (int64_t w = blockIdx.x; w < n_words; w += gridDim.x) {
+        const int64_t b = w * 32 + lb;
+        uint32_t nib = 0;
         int64_t g = 0;
         if (b < total) {
             g = b / per_grid;
@@ -204,45 +213,68 @@ __global__ __launch_bounds__(kBlock) void pack_bricks_kernel(
             const int bx = (int)(rem / ((int64_t)nby * nbz));
             rem -= (int64_t)bx * nby * nbz;
             const int by = (int)(rem / nbz), bz = (int)(rem - (int64_t)by * nbz);
-            const int64_t grid_off = g * (int64_t)rx * ry * rz;
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int x = bx * 4 + dx;
-#pragma unroll
-                for (int dy = 0; dy < 4; ++dy) {
-                    const int y = by * 4 + dy;
-                    if (x >= rx || y >= ry) continue;
-                    const int64_t row = grid_off + ((int64_t)x * ry + y) * rz + bz * 4;
+            const int x = bx * 4 + dx, y = by * 4 + dy;
+            if (x < rx && y < ry) {
+                const int64_t row = g * (int64_t)rx * ry * rz + ((int64_t)x * ry + y) * rz + bz * 4;
+                if (bz * 4 + 4 <= rz && (row & 3) == 0) {               // a whole, aligned row of four voxels: one load, one store
+                    if (FROM_OCCS) {
+                        const float4 v = *reinterpret_cast<const float4 *>(occs + row);
+                        nib = (v.x > thre ? 1u : 0u) | (v.y > thre ? 2u : 0u) | (v.z > thre ? 4u : 0u) | (v.w > thre ? 8u : 0u);
+                        *reinterpret_cast<uint32_t *>(binaries_out + row) = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+                    } else {
+                        const uint32_t v = *reinterpret_cast<const uint32_t *>(binaries + row);
+                        nib = ((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) | ((v & 0xff000000u) ? 8u : 0u);
+                    }
+                } else {
 #pragma unroll
                     for (int dz = 0; dz < 4; ++dz) {
                         if (bz * 4 + dz >= rz) continue;
                         bool on;
                         if (FROM_OCCS) { on = occs[row + dz] > thre; binaries_out[row + dz] = on ? 1 : 0; }
                         else on = binaries[row + dz] != 0;
-                        if (on) bits |= 1ull << (dx * 16 + dy * 4 + dz);
+                        if (on) nib |= 1u << dz;
                     }
                 }
             }
-            bricks[b] = bits;
         }
-        const unsigned long long any = __ballot(bits != 0ull);
-        const int lane = lane_id();
-        // occupied voxels per level (integer atomics: deterministic): lets OccGridEstimator size `nonzero` without a sync.
-        // One atomic per wave — every brick adding to the same word serialises in the L2 (105 us for 32 k bricks) —
-        // unless the wave straddles two levels.
-        if (any) {
-            const int64_t g0 = __builtin_amdgcn_readfirstlane((int)g);
-            if (__ballot(b < total && g != g0) == 0ull) {
-                const int64_t cnt = wave_sum_i64(__popcll(bits));
-                if (lane == 0) atomicAdd((unsigned long long *)(level_counts + g0), (unsigned long long)cnt);
-            } else if (bits) {
-                atomicAdd((unsigned long long *)(level_counts + g), (unsigned long long)__popcll(bits));
-            }
+        // the brick's word: bit dx * 16 + dy * 4 + dz — OR over the brick's sixteen lanes (row rotations by 1, 2, 4, 8)
+        const int sh = dx * 16 + dy * 4;
+        uint32_t lo = sh < 32 ? nib << sh : 0u, hi = sh >= 32 ? nib << (sh - 32) : 0u;
+#define NFA_ROW_OR(N)                                                                                          \
+        lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x120 + N, 0xf, 0xf, false);                      \
+        hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x120 + N, 0xf, 0xf, false);
+        NFA_ROW_OR(1) NFA_ROW_OR(2) NFA_ROW_OR(4) NFA_ROW_OR(8)
+#undef NFA_ROW_OR
+        const uint64_t bits = ((uint64_t)hi << 32) | lo;
+        const bool leader = (threadIdx.x & 15) == 0;
+        if (leader && b < total) bricks[b] = bits;
+        // the wave's four bricks: non-empty flags (bits 4 wv ... 4 wv + 3 of the coarse word) and occupied voxels
+        const unsigned long long any = __ballot(leader && bits != 0ull);
+        const uint32_t four = (uint32_t)((any & 1ull) | ((any >> 15) & 2ull) | ((any >> 30) & 4ull) | ((any >> 45) & 8ull));
+        const int cnt = (int)wave_sum_i64(leader ? (int64_t)__popcll(bits) : (int64_t)0);
+        // occupied voxels per level (integer atomics: deterministic): lets OccGridEstimator size its list of occupied cells without
+        // a sync.  One atomic per workgroup (every brick adding to the same word serialises in the L2: 105 us for 32 k bricks)
+        // unless its 32 bricks straddle two levels.
+        const int64_t g_first = (w * 32) / per_grid, g_last = ((w * 32 + 31 < total ? w * 32 + 31 : total - 1)) / per_grid;
+        if (lane == 0) { s_any[wv] = four; s_cnt[wv] = cnt; }
+        if (g_first != g_last && leader && bits) atomicAdd((unsigned long long *)(level_counts + g), (unsigned long long)__popcll(bits));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t word = 0;
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < kPackBlock / 64; ++k) { word |= s_any[k] << (4 * k); tot += s_cnt[k]; }
+            coarse[w] = word;
+            if (g_first == g_last && tot) atomicAdd((unsigned long long *)(level_counts + g_first), (unsigned long long)tot);
         }
-        const int64_t w = b >> 5;                       // coarse word of this lane's brick
-        if ((lane & 31) == 0 && (b < total))
-            coarse[w] = (uint32_t)(lane ? (any >> 32) : any);
+        __syncthreads();
     }
+}
+
+// one workgroup per coarse word, at most 16 per CU (the kernel loops beyond)
+inline unsigned pack_blocks(int64_t n_bricks) {
+    const int64_t w = (n_bricks + 31) / 32;
+    return (unsigned)(w < 1 ? 1 : (w > (int64_t)kNumCU * 16 ? (int64_t)kNumCU * 16 : w));
 }
 
 // rank prefix over the coarse words (single workgroup; n_words is 1024 for 128^3)
@@ -299,11 +331,20 @@ constexpr int kDistCap = 4;
 // One lane per brick (the two nibbles of an output byte meet through a lane shuffle); per (dx, dy) the 7 bits of the neighbouring
 // z-row around bz come out of the bitmap with two word loads and a funnel shift, and the nearest set bit of the window is four mask
 // tests — 49 windows instead of 343 single-bit probes (round 5, second form: 47 -> ~10 us at 128^3 in the bench's kernel trace).
-__global__ __launch_bounds__(kBlock) void brick_dist_kernel(const uint32_t *__restrict__ coarse, int n_grids, int nbx, int nby, int nbz,
+// LDS_MAP (round 6): the whole bitmap (4 KB at 128^3, 32 KB at 256^3) is staged in LDS first — the ~100 window reads of a lane are a
+// dependent chain (`best` prunes the loops), and from L2 that chain was the kernel's 11.5 us at 128^3 in the bench's trace.
+template <bool LDS_MAP>
+__global__ __launch_bounds__(kBlock) void brick_dist_kernel(const uint32_t *__restrict__ coarse_g, int n_grids, int nbx, int nby, int nbz,
                                                             uint8_t *__restrict__ dist)
 {
+    extern __shared__ uint32_t s_coarse[];
     const int64_t per_grid = (int64_t)nbx * nby * nbz, total = per_grid * n_grids;
     const int64_t rounded = (total + 63) / 64 * 64, n_words = (total + 31) / 32;
+    if (LDS_MAP) {
+        for (int64_t i = threadIdx.x; i < n_words; i += kBlock) s_coarse[i] = coarse_g[i];
+        __syncthreads();
+    }
+    const uint32_t *const coarse = LDS_MAP ? (const uint32_t *)s_coarse : coarse_g;
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < rounded; b += (int64_t)gridDim.x * kBlock) {
         int best = kDistCap;
         if (b < total) {
@@ -1522,8 +1563,13 @@ static int rank_and_compact(uint64_t *bricks, const PackedLayout &L, hipStream_t
     hipLaunchKernelGGL(compact_bricks_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
                        bricks, L.n_bricks, coarse, prefix, bricks + L.off_compact);
     if (int rc = check_launch("compact_bricks_kernel")) return rc;
-    hipLaunchKernelGGL(brick_dist_kernel, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s, coarse, n_grids, (rx + 3) / 4, (ry + 3) / 4,
-                       (rz + 3) / 4, (uint8_t *)(bricks + L.off_dist));
+    const size_t map_bytes = (size_t)L.n_words * 4;
+    if (map_bytes <= 64 * 1024)
+        hipLaunchKernelGGL(brick_dist_kernel<true>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), map_bytes, s, coarse, n_grids, (rx + 3) / 4,
+                           (ry + 3) / 4, (rz + 3) / 4, (uint8_t *)(bricks + L.off_dist));
+    else
+        hipLaunchKernelGGL(brick_dist_kernel<false>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s, coarse, n_grids, (rx + 3) / 4,
+                           (ry + 3) / 4, (rz + 3) / 4, (uint8_t *)(bricks + L.off_dist));
     return check_launch("brick_dist_kernel");
 }
 
@@ -1539,7 +1585,7 @@ NFA_EXPORT int nfa_pack_binaries(const uint8_t *binaries, int32_t n_grids, int32
     uint32_t *coarse = (uint32_t *)(bricks + L.off_coarse);
     int64_t *header = (int64_t *)(bricks + L.off_header);
     if (hipMemsetAsync(header, 0, 12 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "pack_binaries: memset failed");
-    hipLaunchKernelGGL(pack_bricks_kernel<false>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(pack_bricks_kernel<false>, dim3(pack_blocks(L.n_bricks)), dim3(kPackBlock), 0, s,
                        binaries, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
                        (const float *)nullptr, (const double *)nullptr, 0, 0.0f, (uint8_t *)nullptr, (float *)nullptr);
     if (int rc = check_launch("pack_bricks_kernel")) return rc;
@@ -1562,7 +1608,7 @@ NFA_EXPORT int nfa_grid_threshold_packed(const float *occs, int32_t n_grids, int
     if (hipMemsetAsync(header, 0, 12 * sizeof(int64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "grid_threshold_packed: memset failed");
     const int64_t n_cells = (int64_t)n_grids * rx * ry * rz;
     const int nb = launch_grid_mean_partials(occs, n_cells, (double *)workspace, s);
-    hipLaunchKernelGGL(pack_bricks_kernel<true>, dim3(blocks_for(L.n_bricks)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(pack_bricks_kernel<true>, dim3(pack_blocks(L.n_bricks)), dim3(kPackBlock), 0, s,
                        (const uint8_t *)nullptr, n_grids, rx, ry, rz, (rx + 3) / 4, (ry + 3) / 4, (rz + 3) / 4, bricks, coarse, header + 1,
                        occs, (const double *)workspace, nb, occ_thre, binaries, threshold_out);
     if (int rc = check_launch("pack_bricks_kernel<occs>")) return rc;

@@ -786,11 +786,13 @@ __global__ __launch_bounds__(kBlock) void rendering_fwd_kernel(
         [&](int64_t key) { if (lane == 0) ray_out(key, c_r, c_g, c_b, c_w, c_m); });
 }
 
-template <int E>
-struct RenderBwdIn { float T[E], a[E], gw[E], gT[E], ga[E], t0[E], t1[E], rgb[E][3]; };
-// (108 VGPRs at E = 2: 4 waves per SIMD.  Forcing 5 or 6 through __launch_bounds__ spills 20 / 89 registers and runs 1.9x / 3x
-// slower, profiles/r05_streaming.md)
-template <int E>
+// EXT: the caller has gradients w.r.t. the per-sample extras (weights / trans / alphas — a loss on extras["weights"], e.g. the
+// distortion loss).  The usual training step has none, and their three payload slots per element and queued chunk were what kept
+// the kernel at 98 VGPRs (4 waves per SIMD; forcing 5 through __launch_bounds__ spilled 20 registers and ran 1.9x slower,
+// profiles/r05_streaming.md): without them (round 6) it fits 5.
+template <int E, bool EXT>
+struct RenderBwdIn { float T[E], a[E], gw[EXT ? E : 1], gT[EXT ? E : 1], ga[EXT ? E : 1], t0[E], t1[E], rgb[E][3]; };
+template <int E, bool EXT>
 __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ rgbs, const float *__restrict__ trans,
@@ -803,9 +805,9 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
     float carry = 0.0f;
     float bk0 = 0.f, bk1 = 0.f, bk2 = 0.f;
     if (bkgd) { bk0 = bkgd[0]; bk1 = bkgd[1]; bk2 = bkgd[2]; }
-    walk_rays_bwd<E, NFA_PF, RenderBwdIn<E>>(keys, n, wave_index(), tile, spec,
+    walk_rays_bwd<E, NFA_PF, RenderBwdIn<E, EXT>>(keys, n, wave_index(), tile, spec,
         [&](int64_t i0, auto full) {
-            RenderBwdIn<E> p;
+            RenderBwdIn<E, EXT> p;
             // (the weights are not loaded: the forward pass stored w = T * alpha — rendering_fwd_kernel above, one rounding — and the
             // same product of the same two floats is formed below: 4 of 60 bytes per sample less)
             ld_vec<E>(trans, i0, n, 0.0f, p.T, full);
@@ -813,20 +815,22 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
             ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
             ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
             ld_vec_strided<E, 3>(rgbs, i0, n, 0.0f, p.rgb, full);
+            if constexpr (EXT) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
-            if (g_w_ext) ld_vec<E>(g_w_ext, i0, n, 0.0f, p.gw, full);
-            if (g_T_ext) ld_vec<E>(g_T_ext, i0, n, 0.0f, p.gT, full);
-            if (g_a_ext) ld_vec<E>(g_a_ext, i0, n, 0.0f, p.ga, full);
+                for (int e = 0; e < E; ++e) p.gw[e] = p.gT[e] = p.ga[e] = 0.0f;
+                if (g_w_ext) ld_vec<E>(g_w_ext, i0, n, 0.0f, p.gw, full);
+                if (g_T_ext) ld_vec<E>(g_T_ext, i0, n, 0.0f, p.gT, full);
+                if (g_a_ext) ld_vec<E>(g_a_ext, i0, n, 0.0f, p.ga, full);
+            }
             return p;
         },
-        [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegBwd<E> &s, const RenderBwdIn<E> &p) {
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegBwd<E> &s, const RenderBwdIn<E, EXT> &p) {
             float gw[E], q[E], incl[E], suffix[E], gs[E], grgb[E][3], w[E];
             bool wr[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 w[e] = p.T[e] * p.a[e];
-                gw[e] = p.gw[e];
+                gw[e] = EXT ? p.gw[EXT ? e : 0] : 0.0f;
                 wr[e] = act[e] && key[e] >= 0 && key[e] < n_rays;
                 grgb[e][0] = grgb[e][1] = grgb[e][2] = 0.0f;
                 if (wr[e]) {
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
                     gw[e] += gc0 * p.rgb[e][0] + gc1 * p.rgb[e][1] + gc2 * p.rgb[e][2] + go + gacc * ((p.t0[e] + p.t1[e]) / 2.0f);
                     grgb[e][0] = w[e] * gc0; grgb[e][1] = w[e] * gc1; grgb[e][2] = w[e] * gc2;
                 }
-                q[e] = act[e] ? gw[e] * w[e] + p.gT[e] * p.T[e] : 0.0f;
+                q[e] = act[e] ? (EXT ? gw[e] * w[e] + p.gT[EXT ? e : 0] * p.T[e] : gw[e] * w[e]) : 0.0f;
             }
             if (g_rgbs) {
 #pragma unroll
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
             }
             seg_scan_bwd<OpSum, E>(q, s, carry, incl, suffix);
 #pragma unroll
-            for (int e = 0; e < E; ++e) gs[e] = ((gw[e] * p.T[e] + p.ga[e]) * (1.0f - p.a[e]) - suffix[e]) * (p.t1[e] - p.t0[e]);
+            for (int e = 0; e < E; ++e) gs[e] = ((EXT ? gw[e] * p.T[e] + p.ga[EXT ? e : 0] : gw[e] * p.T[e]) * (1.0f - p.a[e]) - suffix[e]) * (p.t1[e] - p.t0[e]);
             if (g_sigmas) st_vec<E>(g_sigmas, i0, act, gs);
         });
 }
@@ -1269,9 +1273,13 @@ NFA_EXPORT int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_star
     NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && trans && alphas, "rendering_bwd: NULL pointer");
     NFA_REQUIRE(!(g_depths && expected_depths) || (opacities && depths), "rendering_bwd: opacities/depths needed for g_depths");
     const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
-    NFA_LAUNCH_TILED(rendering_bwd_kernel, pl, n, (hipStream_t)stream,
-                     ray_indices, t_starts, t_ends, rgbs, trans, alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd,
-                     expected_depths, g_colors, g_opacities, g_depths, g_weights, g_trans, g_alphas, g_sigmas, g_rgbs);
+    const dim3 g_(tile_blocks(n, pl.tile)), b_(kBlock);
+#define NFA_RENDER_BWD(EE, XX) hipLaunchKernelGGL((rendering_bwd_kernel<EE, XX>), g_, b_, 0, (hipStream_t)stream, ray_indices, t_starts, t_ends, rgbs, trans, \
+                                                  alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd, expected_depths, g_colors, g_opacities, g_depths, \
+                                                  g_weights, g_trans, g_alphas, g_sigmas, g_rgbs)
+    if (g_weights || g_trans || g_alphas) { if (pl.e == 4) NFA_RENDER_BWD(4, true); else if (pl.e == 2) NFA_RENDER_BWD(2, true); else NFA_RENDER_BWD(1, true); }
+    else { if (pl.e == 4) NFA_RENDER_BWD(4, false); else if (pl.e == 2) NFA_RENDER_BWD(2, false); else NFA_RENDER_BWD(1, false); }
+#undef NFA_RENDER_BWD
     return check_launch("rendering_bwd_kernel");
 }
 

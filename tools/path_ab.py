@@ -1,7 +1,7 @@
 """The path-only training step (bench.py: path_only_loop — estimator.sampling with the visibility filter, nerfacc.rendering forward and
 backward, the field replaced by slices of constant tensors) on the bench's recorded steady state (profiles/r02_sampling_state.npz:
 128^3 grid, 6 564 rays), with round 6's single-launch forms switched on and off one at a time: wall microseconds per step.
-    python tools/path_ab.py [steps] [--forms=000,100,010,001,111]      digits: fused_sample fused_vis (0 | 1 one-pass | 2 two-phase) fold_fill"""
+    python tools/path_ab.py [steps] [--forms=000,100,010,001,111]      digits: fused_sample fused_vis fold_fill (the defaults are 101)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ import nerfacc_amd as nerfacc
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 steps = int(args[0]) if args else 400
-forms = next((a.split("=")[1] for a in sys.argv if a.startswith("--forms=")), "000,100,010,020,001,111,101").split(",")
+forms = next((a.split("=")[1] for a in sys.argv if a.startswith("--forms=")), "000,100,010,001,101,111").split(",")
 dev = torch.device("cuda:0")
 st = np.load(os.path.join(ROOT, "profiles", "r02_sampling_state.npz"))
 res = tuple(int(x) for x in st["res"])
@@ -34,7 +34,9 @@ def step():
     rgb.sum().backward()
     tot["k"] = k
 
-for rep in range(2):
+reps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--reps=")), 5)
+wall = {f: [] for f in forms}
+for rep in range(reps):                      # (round-robin over the forms: a drifting host clock hits every form alike)
     for f in forms:
         with nerfacc.options(fused_sample=int(f[0]), fused_vis=int(f[1]), fold_fill=int(f[2])):
             for _ in range(30):
@@ -44,5 +46,8 @@ for rep in range(2):
             for _ in range(steps):
                 step()
             torch.cuda.synchronize()
-            us = (time.perf_counter() - t0) / steps * 1e6
-        print(f"forms {f} (fused_sample fused_vis fold_fill)  {us:7.1f} us/step   rendered samples {tot['k']}", flush=True)
+            wall[f].append((time.perf_counter() - t0) / steps * 1e6)
+for f in forms:
+    w = sorted(wall[f])
+    print(f"forms {f} (fused_sample fused_vis fold_fill)  median {w[len(w) // 2]:7.1f}  min {w[0]:7.1f}  max {w[-1]:7.1f} us/step over {reps} x {steps} steps   "
+          f"rendered samples {tot['k']}", flush=True)
