@@ -230,7 +230,8 @@ int nfa_traverse_emit_speculative(const nfa_traverse_args *a, const void *worksp
 /* nfa_traverse_count + nfa_traverse_offsets_stamped + nfa_traverse_emit_speculative (sampling outputs: sm_* / t_starts / t_ends, no
  * interval outputs) — as ONE launch when `sync` is given and the call has a fused form (nfa_traverse_sample_fused(args) != 0: one
  * level, step_size > 0, cone_angle = 0, 3072 ... 8192 rays, a grid whose sparse image fits LDS, n_nonempty_bricks given), else as the
- * three launches in order.  `capacity`: samples the outputs hold (the caller's guess; 0 = count and offsets only); rays flagged as
+ * three launches in order (also when `capacity` is more than 80 samples per ray: with rays that long the emit kernel's spread over the
+ * chip beats the launch's one wave per four rays).  `capacity`: samples the outputs hold (the caller's guess; 0 = count and offsets only); rays flagged as
  * overflowed are not written (nfa_traverse_fill(a, 1, 0, workspace, 0, n_overflow, stream), as after nfa_traverse_emit_speculative).
  * totals / stamp as nfa_traverse_offsets_stamped; after a fused launch totals[1] == -1 means its look-back gave up: per-ray counts,
  * run records and wave sums are complete — call nfa_traverse_offsets[_stamped] and go on as after nfa_traverse_count.  With

@@ -1994,7 +1994,11 @@ NFA_EXPORT int nfa_traverse_sample(const nfa_traverse_args *a, void *workspace, 
     if (a->n_rays > 0 && sync) {
         NFA_REQUIRE(workspace != nullptr, "traverse_sample: workspace is NULL");
         const SplitPlan plan = plan_split(a);
-        if (sample_fusable(a, plan)) {
+        // (long rays: the emit half of the single launch is ONE wave per four rays, and beyond ~64 samples per ray — a capacity, the
+        //  caller's guess with its margin, of more than 80 per ray — the emit kernel's spread over the whole chip wins: SURVEY 8d's M1
+        //  sphere, 4096 rays x 84 samples, 49.5 us fused against 47.2 in three launches; the training step's 39 per ray: 36 against 42)
+        const bool long_rays = outputs && capacity > 80 * a->n_rays && opt(OPT_FUSED_SAMPLE, 1) != 2;      // (`fused_sample` = 2: whatever the rays' length)
+        if (!long_rays && sample_fusable(a, plan)) {
             const RunStore rs = make_runs(workspace, a->n_rays);
             FuseArgs fz;
             fz.sync = (uint64_t *)sync;

@@ -230,9 +230,11 @@ SPLIT_P_FORMS = ("", "1", "2", "4", "8", "16")
 # lane-per-ray kernel from LDS / L2
 IMAGE_FORMS = ("NFA_SPLIT_L2=0,NFA_SPLIT_P=16", "NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_P=8", "NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_COUNT_L2=1,NFA_SPLIT_P=1",
                "NFA_SPLIT_CAP=24,NFA_SPLIT_L2=1,NFA_SPLIT_P=16", "NFA_SPLIT_CAP=24,NFA_SPLIT_P=8", "NFA_SPLIT_CAP=16,NFA_SPLIT_L2=1,NFA_SPLIT_P=16",      # (+ list capacities: grids read from L2)
-               # round 5: the lane-per-ray walk voxel by voxel / with empty-space macro steps, brick distances from L2 / in LDS
+               # round 5: the lane-per-ray walk voxel by voxel / with empty-space macro steps
                "NFA_SKIP=0,NFA_COUNT_L2=1,NFA_SPLIT_P=1", "NFA_SKIP=1,NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_SKIP=1,NFA_COUNT_L2=1,NFA_SPLIT_P=1",
-               "NFA_SKIP=2,NFA_COUNT_L2=0,NFA_SPLIT_P=1", "NFA_SKIP=2,NFA_COUNT_L2=1,NFA_SPLIT_P=1")
+               # round 6: the single-launch sampling call (count + look-back + emit in the count kernel) switched off / on
+               "NFA_FUSED_SAMPLE=0", "NFA_FUSED_SAMPLE=2,NFA_FUSED_VIS=1")
+FUSED_FORMS = ("2", "2", "1", "0")     # NFA_FUSED_SAMPLE: the sampling call as one launch whatever the rays' length (twice: the second call has a guess of the output size) / automatic / as three
 EMIT_FORMS = ("rays", "samples", "tiles")     # NFA_EMIT: 16 lanes per ray walking its run records / a lane per sample with searches
 SEGMENT_FORMS = ("1", "0")
 SEG_P_FORMS = ("8", "32")        # NFA_SEG_P: one lane per level segment / four (parts), cone_angle = 0, up to 4 levels

@@ -99,7 +99,7 @@ def test_calls_outside_the_window_take_the_three_launches(name, k2):
     _check(name, k2, _sample(c), c["rays_o"].shape[0])
 
 
-def test_fused_sampling_equals_the_oracle():
+def test_fused_sampling_equals_the_oracle(force_options):
     """the bench's kind of scene (a grid whose image fits LDS), 6 564 rays with a stratified start: sample lists bit for bit as the C
     restatement of grid.cu:68-282 produces them (oracle/nerfacc_oracle.c)"""
     import torch
@@ -108,6 +108,7 @@ def test_fused_sampling_equals_the_oracle():
     from gpu_utils import lego_like, n, t
     from nerfacc_amd import cuda as C
 
+    force_options(fused_sample=2)
     o, d, aabb, occ = lego_like(3, 6564)
     rng = np.random.default_rng(1)
     jit = rng.random(6564, dtype=np.float32)
@@ -125,6 +126,7 @@ def test_fused_sampling_reproduces_reference_k2(name, k2, force_options):
     """every guess regime, back to back, against the reference's fixture"""
     c = _case(name, k2)
     R = c["rays_o"].shape[0]
+    force_options(fused_sample=2)                # (m1_sphere has 84 samples per ray: beyond what the automatic choice fuses)
     # 1. a call on a handful of rays leaves a samples-per-ray guess that is far too SMALL for the next one only if those rays are
     #    short — take the rays with the fewest samples: the next call's waves mostly end beyond the guess
     ref_cnts = k2[f"{name}/cnts/sm_chunk_cnts"] if f"{name}/cnts/sm_chunk_cnts" in k2 else k2[f"{name}/full/sm_chunk_cnts"]
@@ -139,7 +141,10 @@ def test_fused_sampling_reproduces_reference_k2(name, k2, force_options):
     _check(name, k2, _sample(c), R)
     force_options(speculative_emit=1)
     _check(name, k2, _sample(c), R)
-    # 3. the three-kernel form gives the same tensors
+    # 3. the automatic choice (long rays: three launches once there is a guess) and the three-kernel form give the same tensors
+    force_options(fused_sample=1)
+    _check(name, k2, _sample(c), R)
+    _check(name, k2, _sample(c), R)
     force_options(fused_sample=0)
     _check(name, k2, _sample(c), R)
 
@@ -165,13 +170,14 @@ def test_fused_sampling_equals_unfused_on_ragged_batches(force_options):
         tmin = torch.rand(R, device=O.device) * 2.0
         outs = {}
         for fused in (1, 0):
-            with nerfacc_amd.options(fused_sample=fused):
+            with nerfacc_amd.options(fused_sample=2 if fused else 0):
                 for _ in range(3 if fused else 1):
                     outs[fused] = C.sample_occgrid(O[:R].contiguous(), D[:R].contiguous(), B, A, None, None, 5e-3, 0.0, near_plane=0.0,
                                                    far_plane=1e10, t_min=tmin, jitter=jit, jitter_scale=5e-3)
         torch.cuda.synchronize()
         for x, y in zip(outs[1], outs[0]):
             assert x.shape == y.shape and torch.equal(x, y), f"R = {R}"
+    force_options(fused_sample=2)
     for _ in range(40):
         out = C.sample_occgrid(O[:6564].contiguous(), D[:6564].contiguous(), B, A, None, None, 5e-3, 0.0, near_plane=0.0, far_plane=1e10)
         with nerfacc_amd.options(fused_sample=0):
@@ -190,6 +196,7 @@ def test_fused_sampling_on_two_streams(force_options):
     from gpu_utils import lego_like, t
     from nerfacc_amd import cuda as C
 
+    force_options(fused_sample=2)
     o, d, aabb, occ = lego_like(5, 8192)
     O, D, B, A = t(o), t(d), t(occ), t(aabb)
     ref = C.sample_occgrid(O, D, B, A, None, None, 5e-3, 0.0, near_plane=0.0, far_plane=1e10)

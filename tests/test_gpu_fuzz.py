@@ -146,8 +146,10 @@ def test_randomised_fuzz_time_boxed():
     bad, total, cases = [], 0, 0
     t0 = time.time()
     while time.time() - t0 < budget and not bad:
-        which = cases % 9
-        if which == 8:      # both emit kernels, with and without a cone angle
+        which = cases % 10
+        if which == 9:      # round 6: ray counts inside the single-launch sampling call's window (3 072 ... 8 192), the call fused / in three launches
+            b, k = F.check_fused(F.fused_single_case(g, ray_counts=(3072, 3105, 4097, 6564, 8191, 8192)), "NFA_FUSED_SAMPLE", F.FUSED_FORMS)
+        elif which == 8:      # both emit kernels, with and without a cone angle
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000), cones=(0.0, 0.004, 0.3)), "NFA_EMIT", F.EMIT_FORMS)
         elif which == 7:      # one level, grid image read from LDS / L2 / L2 + staged bitmap
             b, k = F.check_fused(F.fused_single_case(g, ray_counts=(1, 7, 64, 500, 3000, 9000)), None, F.IMAGE_FORMS)

@@ -75,7 +75,7 @@ def test_options_table_and_environment_seeding():
         assert na.get_option("vis_onepass") == 1 and na.get_option("NFA_VIS_CHUNKS") == 6
         na.set_option("vis_onepass", None); na.set_option("vis_chunks", None)
         for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1), ("vis_chunks", 1), ("vis_chunks", 8),
-                            ("vis_onepass", 2), ("skip", 2), ("split_p", 32), ("fused_vis", 2)):
+                            ("vis_onepass", 2), ("skip", 2), ("split_p", 32), ("fused_vis", 2), ("fused_sample", 3)):
             if value == "":
                 na.set_option(name, value)          # "" = auto
                 assert na.get_option(name) is None

@@ -147,7 +147,7 @@ _ONE_LEVEL = [{}, {"split_p": 16, "split_l2": 0}, {"split_p": 16, "split_l2": 1}
               {"split_p": 1, "count_l2": 0, "skip": 0}, {"split_p": 1, "count_l2": 1, "skip": 0}, {"split_p": 1, "count_l2": 0, "skip": 1},
               {"split_p": 1, "count_l2": 1, "skip": 1},
               # round 6: the single-launch sampling call switched off (m1_sphere is inside its window)
-              {"fused_sample": 0}]
+              {"fused_sample": 0}, {"fused_sample": 2}]
 _LEVELS = [{}, {"segments": 0}, {"segments": 1, "seg_p": 8}, {"segments": 1, "seg_p": 32}, {"emit": "rays"}, {"emit": "samples"}, {"emit": "tiles"},
            {"segments": 0, "skip": 0}, {"segments": 0, "skip": 1}]
 _CONE_ONE = [{}, {"cone": 0}, {"cone": 1, "emit": "rays"}, {"cone": 1, "emit": "samples"}, {"cone": 0, "emit": "rays"}]

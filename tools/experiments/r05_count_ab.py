@@ -88,7 +88,7 @@ if "--coherent" in sys.argv or True:
         row("frame 1000x1000 128^3", n, out2, c2, e2, form=form)
     # one round of the test-time marcher's shape: a step limit of 4 samples per ray and a mask (lane-per-ray lattice kernel)
     mask = torch.ones(n, dtype=torch.bool, device=dev)
-    for form, f in ([("limit4 skip0", dict(skip=0)), ("limit4 skip1", dict(skip=1)), ("limit4 skip2", dict(skip=2))] if HAS_SKIP else [("limit4", {})]):
+    for form, f in ([("limit4 skip0", dict(skip=0)), ("limit4 skip1", dict(skip=1))] if HAS_SKIP else [("limit4", {})]):
         with nerfacc_amd.options(**f):
             out3, c3, e3 = timed(lambda: C.sample_occgrid(O, D, binaries, aabbs, NEAR, FAR, step, 0.0, mask, 4), 6)
         row("frame 1000x1000 128^3", n, out3, c3, e3, form=form)

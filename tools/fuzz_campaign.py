@@ -28,6 +28,11 @@ for case in range(n_cases):
     bad += len(b); total += n
     for line in b:
         print("MISMATCH (emit)", f"case {case}", line, flush=True)
+    # round 6: ray counts inside the window of the single-launch sampling call, fused (twice) / in three launches
+    b, n = F.check_fused(F.fused_single_case(np.random.default_rng(seed0 * 100003 + case + 97), ray_counts=(3072, 3105, 4097, 6564, 8191, 8192)), "NFA_FUSED_SAMPLE", F.FUSED_FORMS)
+    bad += len(b); total += n
+    for line in b:
+        print("MISMATCH (fused)", f"case {case}", line, flush=True)
     if case % 3 == 0:      # one level with a cone angle: the two-phase kernel with a lane per ray vs the general kernel
         b, n = F.check_fused(F.fused_single_case(np.random.default_rng(seed0 * 100003 + case + 77), cones=(0.004, 0.05, 0.3)), "NFA_CONE", F.CONE_FORMS)
         bad += len(b); total += n
