@@ -62,8 +62,6 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"chunk_prefetch", "0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call", parse_bool},
     {"speculative_emit", "0: sample_occgrid of the torch extension launches the emit pass after the read-back", parse_bool},
     {"skip", "lane-per-ray lattice count pass: 0 = voxel by voxel, 1 = empty-space macro steps (brick distances from L2) (unset: a wave takes the macro steps when its rays are coherent)", parse_bool},
-    {"vis_onepass", "visibility filter with compacted outputs: 0 = mask / scan / compaction kernels, 1 = one pass with look-back (unset: 0 — the one-pass form measures slower)", parse_bool},
-    {"vis_chunks", "one-pass visibility filter: chunks of 64 e samples per tile, 2 ... 7 (four waves x (chunks + 1) x 128 x 16 bytes of LDS: 64 KB at 7)", parse_one_of<2, 3, 4, 5, 6, 7>},
     {"fused_sample", "the sampling call as ONE launch (count, look-back over the workgroups and emit in the count kernel; 3072 ... 8192 rays of a one-level grid that fits LDS): 0 never, 1 when the caller's guess is at most 80 samples per ray (unset), 2 whatever the guess", parse_one_of<0, 1, 2>},
     {"fused_vis", "1: calls whose workgroups are all resident run the visibility filter as ONE launch (one pass, survivors staged in LDS and flushed behind a look-back over the workgroups); unset / 0: mask pass + compaction kernels (the single launch measures 3.5 us slower at the training size)", parse_bool},
     {"fold_fill", "0: nfa_rendering_fwd fills the rays without a sample with a launch of its own (unset: extra workgroups of its kernel do it for up to 2^20 samples, from the gaps between ascending ray_indices)", parse_bool},

@@ -29,8 +29,6 @@ enum Option : int {
     OPT_CHUNK_PREFETCH,  // 0: sample_occgrid of the torch extension never launches the next ray slice's count pass ahead of its call
     OPT_SPECULATIVE_EMIT,// 0: the extension's sample_occgrid launches the emit pass after the read-back
     OPT_SKIP,            // lane-per-ray lattice count pass: 0 = voxel by voxel (rounds 1-4), 1 = empty-space macro steps (brick distances from L2)
-    OPT_VIS_ONEPASS,     // visibility filter with compacted outputs: 0 = mask / (scan) / compaction kernels, 1 = the one-pass look-back form
-    OPT_VIS_CHUNKS,      // one-pass form: chunks of 64 E samples per tile, 2 ... 7 (the LDS image per wave holds one chunk more: 64 KB per workgroup at 7)
     OPT_FUSED_SAMPLE,    // nfa_traverse_sample's single-launch form: 0 never, 1 up to 80 samples of capacity per ray (default), 2 always inside its window
     OPT_FUSED_VIS,       // 1: the visibility filter of small calls as one launch (static one-pass kernel); default 0 (measured slower)
     OPT_FOLD_FILL,       // 0: nfa_rendering_fwd always fills the rays without a sample with a launch of its own (1: inside its kernel up to 2^20 samples)

@@ -330,7 +330,7 @@ __device__ __forceinline__ void vis_compact_range(const int64_t *__restrict__ ke
 //           group totals: the wave adds the totals of the groups before its own
 // The last wave stores the total in modes 1 and 2.
 constexpr int64_t kVisFusedTiles = 4096, kVisGroupedTiles = 64 * 4096;
-constexpr int64_t kVisOnePassChunks = 4;               // chunks (64 E samples) per tile of that form
+constexpr int64_t kVisOnePassChunks = 4;               // most chunks (64 E samples) per tile of the one-pass form
 template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
@@ -375,216 +375,131 @@ __global__ __launch_bounds__(kBlock) void visibility_compact_kernel(
 }
 
 // ----------------------------------------------------------------------------------------
-// The one-pass form of the filter (option vis_onepass = 1; never chosen automatically: on MI355X it measures 1.3-1.7x SLOWER than
-// the three kernels above although it moves a third fewer bytes — every tile waits for the slowest of the ~1000 tile groups in
-// flight before it, profiles/r05_streaming.md section 3).
+// The one-pass form of the filter (option `fused_vis` = 1; never chosen automatically: on MI355X it measures slower than the two
+// kernels above although it moves a third fewer bytes — round 5 built it for any size with atomic tickets and persistent
+// workgroups (1.3-1.7x slower at 2^24: every tile waits for the slowest of the ~1000 groups in flight before it,
+// profiles/r05_streaming.md section 3); round 6 kept only this STATIC form for calls whose workgroups are all resident at once
+// (19.5 us against 9.2 + 6.9 at the training size, profiles/r06_small_n.md section 3: a publish + look-back costs two memory-side
+// round trips, more than the kernel boundary it replaces).
 //
-// The three-kernel form reads keys / t_starts / t_ends twice (mask pass, compaction) and moves a mask byte per sample in
-// between: 54 bytes per sample for 36 algorithmic ones.  Here a wave walks its rays ONCE: the survivors of its tile are
-// packed into LDS in sample order as they are found (ballot ranks), the tile's survivor count is published, the destination
-// is the sum of the counts of the tiles before (decoupled look-back: a wave reads the 64 states before its own at a time,
-// nearest first, and stops at the first tile that has published its inclusive prefix), and the LDS image leaves as one
-// contiguous, coalesced copy.  36 bytes per sample cross the HBM interface.
-//
-// States are 64-bit words [status:2 | value:62] (0 = nothing yet, 1 = the group's own count, 2 = count of all groups up to and
-// including it), one per GROUP of four consecutive tiles (a workgroup's four waves add up in LDS first: a quarter of the states to
-// look through), zeroed by the launch's memset together with the ticket counter in front of them.  Groups are handed out by an
-// atomic ticket: a workgroup only ever waits for groups with SMALLER tickets, whose workgroups were therefore already running
-// when it drew its own — forward progress does not depend on the order in which the hardware dispatches workgroups, nor on
-// the launch fitting the chip.  Workgroups are persistent (a few per CU) and draw the next ticket while they work on the
-// current one.
+// The two-kernel form reads keys / t_starts / t_ends twice and moves bit planes in between: 45 bytes per sample for 36
+// algorithmic ones.  Here a wave walks its rays ONCE: the survivors of its tile are packed into LDS in sample order as they are
+// found (ballot ranks), the workgroup's survivor count is published as one word of the caller's sync block (lookback.hpp: static
+// ids — one tile group per workgroup by its id —, bounded waits, the block left zero), the destination is the sum of the words of
+// the workgroups before, and the LDS image leaves as one contiguous, coalesced copy.  n_out[0] = -1: the look-back gave up,
+// nothing was stored (the caller runs the two kernels).
 //
 // A ray that straddles far beyond the nominal tile can give a wave more survivors than its LDS image holds.  From the chunk that
 // would overflow on, the wave only counts and leaves keep bytes (in the caller's mask, or in the workspace); once its destination
-// is known it compacts that remainder as the compaction kernel would.  Its count is published at the same point as everybody
-// else's: nobody is serialised behind a long ray.
+// is known it compacts that remainder as the compaction kernel would.
 // ----------------------------------------------------------------------------------------
-constexpr uint64_t kVisValueMask = (1ull << 62) - 1ull;
-constexpr int kVisStateAgg = 1, kVisStatePrefix = 2;
-
-// sum of the survivor counts of tile groups [0, t) (every lane returns it): 256 states per round trip, lane l looking at the
-// groups t - 1 - l, t - 65 - l, ... (position 0 = the nearest)
-__device__ __forceinline__ int64_t vis_lookback(const uint64_t *__restrict__ st, int64_t t, int lane) {
-    constexpr int U = 4;
-    int64_t excl = 0;
-    for (int64_t j = t - 1; j >= 0; j -= 64 * U) {
-        uint64_t v[U];
-        unsigned long long take[U];
-        bool has_prefix;
-        for (;;) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t idx = j - u * 64 - lane;
-                v[u] = idx >= 0 ? __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : ((uint64_t)kVisStatePrefix << 62);            // before the first group: prefix 0
-            }
-            bool ok = true;
-            has_prefix = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const unsigned long long ready = __ballot((v[u] >> 62) != 0);
-                const unsigned long long pre = __ballot((v[u] >> 62) == (uint64_t)kVisStatePrefix);
-                // positions up to the nearest published prefix are summed; everything nearer must be ready
-                unsigned long long need = has_prefix ? 0ull : ~0ull;
-                if (!has_prefix && pre) { need = ((pre & (0ull - pre)) << 1) - 1ull; has_prefix = true; }
-                take[u] = need;
-                ok = ok && ((ready & need) == need);
-            }
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        int64_t sum = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) sum += ((take[u] >> lane) & 1ull) ? (int64_t)(v[u] & kVisValueMask) : (int64_t)0;
-        excl += wave_sum_i64(sum);
-        if (has_prefix) break;
-    }
-    return excl;
-}
-
-#ifndef NFA_VIS_EXP
-#define NFA_VIS_EXP 0          // timing experiments only (results are wrong): 2 no look-back, 4 no staging / no flush
-#endif
-// STATIC (round 6, the form small calls take — nfa_visibility_compact_sync): one tile group per workgroup by its id, every
-// workgroup resident at once (the host launches it only then), the states in the caller's sync block (lookback.hpp: bounded waits,
-// left zero) — no ticket counter, no memset in front of the launch, no persistent loop.  n_out[0] = -1: the look-back gave up, nothing
-// was stored.
-template <int E, bool STATIC = false>
+template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, float eps, float alpha_thre,
-    uint8_t *__restrict__ mask, uint8_t *__restrict__ ov_mask, uint64_t *__restrict__ state, int64_t n_tiles, int cap,
+    uint8_t *__restrict__ mask, uint8_t *__restrict__ ov_mask, uint64_t *__restrict__ sync, int64_t n_tiles, int cap,
     int64_t *__restrict__ n_out, int64_t stamp, int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
     extern __shared__ __align__(16) uint8_t vis_smem[];
-    __shared__ unsigned long long s_ticket[2];
-    __shared__ int64_t s_kept[2][kWavesPerBlock], s_excl[2];
+    __shared__ int64_t s_kept[kWavesPerBlock], s_excl;
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int64_t n_groups = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    unsigned long long *ctr = (unsigned long long *)state;
-    uint64_t *st = state + 1;
     // the wave's LDS image: keys[cap] | t_starts[cap] | t_ends[cap]  (addressed through vis_smem itself: pointers derived from it
     // and selected against the global outputs lose their LDS address space and the compiler parks them in scratch)
     const uint32_t img = (uint32_t)wv * (uint32_t)cap * 16u;
 #define L_KEYS(j) (*(int64_t *)(vis_smem + img + 8u * (uint32_t)(j)))
 #define L_TS(j) (*(float *)(vis_smem + img + 8u * (uint32_t)cap + 4u * (uint32_t)(j)))
 #define L_TE(j) (*(float *)(vis_smem + img + 12u * (uint32_t)cap + 4u * (uint32_t)(j)))
-    unsigned long long t = blockIdx.x;
-    if constexpr (!STATIC) {
-        if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ctr, 1ull);
-        __syncthreads();
-        t = s_ticket[0];
-    }
-    // the workgroup stays: it draws the next ticket while it works on the current one (the atomic's round trip is hidden)
-    for (int it = 0; t < (unsigned long long)n_groups; ++it) {
-        const int par = it & 1;
-        unsigned long long nxt = ~0ull;
-        if constexpr (!STATIC) { if (threadIdx.x == 0) nxt = atomicAdd(ctr, 1ull); }
-        const int64_t w = (int64_t)t * kWavesPerBlock + wv;
-
-        int cnt = 0;                       // survivors in the LDS image
-        int64_t kept = 0;                  // survivors of the tile
-        bool over = false;                 // the image is full: chunks from ov_b on are only counted, their keep bytes are in ov_mask
-        int64_t ov_b = 0, ov_e = 0;
-        float carry = from_alpha ? 1.0f : 0.0f;
-        walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, 0,
-            [&](int64_t i0, auto full) {
-                VisIn<E> p;
-                ld_vec<E>(dens, i0, n, 0.0f, p.d, full);
-                ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
-                ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
-                return p;
-            },
-            [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
-                uint8_t keep[E];
-                vis_keep<E>(from_alpha, act, p, s, carry, eps, alpha_thre, keep);
-                if (mask) st_vec<E>(mask, i0, act, keep);
-                // rank of element (lane, e) among the chunk's survivors, in sample order (index = base + lane E + e)
-                int below = 0, chunk_kept = 0;
+    const int64_t t = blockIdx.x;                      // (the host launches exactly n_groups workgroups)
+    const int64_t w = t * kWavesPerBlock + wv;
+    int cnt = 0;                       // survivors in the LDS image
+    int64_t kept = 0;                  // survivors of the tile
+    bool over = false;                 // the image is full: chunks from ov_b on are only counted, their keep bytes are in ov_mask
+    int64_t ov_b = 0, ov_e = 0;
+    float carry = from_alpha ? 1.0f : 0.0f;
+    walk_rays_fwd<E, NFA_PF, VisIn<E>>(keys, n, w, tile, 0,
+        [&](int64_t i0, auto full) {
+            VisIn<E> p;
+            ld_vec<E>(dens, i0, n, 0.0f, p.d, full);
+            ld_vec<E>(ts, i0, n, 0.0f, p.t0, full);
+            ld_vec<E>(te, i0, n, 0.0f, p.t1, full);
+            return p;
+        },
+        [&](int64_t i0, const bool (&act)[E], const int64_t (&key)[E], const SegFwd<E> &s, const bool (&)[E], const VisIn<E> &p) {
+            uint8_t keep[E];
+            vis_keep<E>(from_alpha, act, p, s, carry, eps, alpha_thre, keep);
+            if (mask) st_vec<E>(mask, i0, act, keep);
+            // rank of element (lane, e) among the chunk's survivors, in sample order (index = base + lane E + e)
+            int below = 0, chunk_kept = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned long long b = __ballot(keep[e] != 0);
+                below += __popcll(b & lanes_lt(lane));
+                chunk_kept += __popcll(b);
+            }
+            if (!over && cnt + chunk_kept > cap) { over = true; ov_b = i0 - (int64_t)lane * E; }      // (wave-uniform)
+            if (!over) {
+                int r = cnt + below;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const unsigned long long b = __ballot(keep[e] != 0);
-                    below += __popcll(b & lanes_lt(lane));
-                    chunk_kept += __popcll(b);
-                }
-                if (!over && cnt + chunk_kept > cap) { over = true; ov_b = i0 - (int64_t)lane * E; }      // (wave-uniform)
-                if (NFA_VIS_EXP & 4) {
-                } else if (!over) {
-                    int r = cnt + below;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (keep[e]) {
-                            L_KEYS(r) = key[e];
-                            L_TS(r) = p.t0[e];
-                            L_TE(r) = p.t1[e];
-                            ++r;
-                        }
-                    }
-                    cnt += chunk_kept;
-                } else {
-                    if (!mask) st_vec<E>(ov_mask, i0, act, keep);
-                    int le = -1;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) if (act[e]) le = e;
-                    const unsigned long long am = __ballot(le >= 0);
-                    if (am) {
-                        const int l = 63 - __clzll((long long)am);
-                        ov_e = i0 - (int64_t)lane * E + l * E + __builtin_amdgcn_readlane(le, l) + 1;
+                    if (keep[e]) {
+                        L_KEYS(r) = key[e];
+                        L_TS(r) = p.t0[e];
+                        L_TE(r) = p.t1[e];
+                        ++r;
                     }
                 }
-                kept += chunk_kept;
-            },
-            [](int64_t) {});
-        if (lane == 0) s_kept[par][wv] = kept;
-        __syncthreads();
-        if (STATIC && wv == 0) {
-            const int64_t tot = s_kept[par][0] + s_kept[par][1] + s_kept[par][2] + s_kept[par][3];
-            const int64_t excl = sync_publish_and_lookback(state, (int64_t)t, tot, 0, 0, lane);
-            if (lane == 0) {
-                s_excl[par] = excl;
-                s_ticket[par ^ 1] = nxt;
-                if ((int64_t)t == n_groups - 1) { *n_out = excl < 0 ? -1 : excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
-            }
-            sync_leave(state, n_groups, lane);
-        } else if (wv == 0) {               // one state per workgroup: the four tiles' survivors
-            const int64_t tot = s_kept[par][0] + s_kept[par][1] + s_kept[par][2] + s_kept[par][3];
-            if (lane == 0) __hip_atomic_store(st + t, ((uint64_t)kVisStateAgg << 62) | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int64_t excl = (NFA_VIS_EXP & 2) ? (int64_t)((t * kWavesPerBlock * tile) % (uint64_t)(n / 2)) : vis_lookback(st, (int64_t)t, lane);
-            if (lane == 0) {
-                __hip_atomic_store(st + t, ((uint64_t)kVisStatePrefix << 62) | (uint64_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_excl[par] = excl;
-                s_ticket[par ^ 1] = nxt;
-                if ((int64_t)t == n_groups - 1) { *n_out = excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
-            }
-        }
-        __syncthreads();
-        int64_t dst = s_excl[par];
-        if (STATIC && dst < 0) return;
+                cnt += chunk_kept;
+            } else {
+                if (!mask) st_vec<E>(ov_mask, i0, act, keep);
+                int le = -1;
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock - 1; ++k) dst += k < wv ? s_kept[par][k] : 0;
-        if (NFA_VIS_EXP & 4) cnt = 0;
-        for (int j = lane; j < cnt; j += 64) {          // the LDS image leaves as one contiguous copy
-            st_stream(o_keys + dst + j, L_KEYS(j));
-            st_stream(o_ts + dst + j, L_TS(j));
-            st_stream(o_te + dst + j, L_TE(j));
-        }
-        if (over) {                                     // the counted-only remainder, as visibility_compact_kernel does it
-            __threadfence();                            // this wave's keep bytes, stored by other lanes, before they are loaded
-            dst += cnt;
-            for (int64_t base = ov_b; base < ov_e; base += 64) {
-                const int64_t i = base + lane;
-                const bool keepb = i < ov_e && ov_mask[i];
-                const unsigned long long b = __ballot(keepb);
-                if (keepb) {
-                    const int64_t k = dst + __popcll(b & lanes_lt(lane));
-                    st_stream(o_keys + k, keys[i]);
-                    st_stream(o_ts + k, ts[i]);
-                    st_stream(o_te + k, te[i]);
+                for (int e = 0; e < E; ++e) if (act[e]) le = e;
+                const unsigned long long am = __ballot(le >= 0);
+                if (am) {
+                    const int l = 63 - __clzll((long long)am);
+                    ov_e = i0 - (int64_t)lane * E + l * E + __builtin_amdgcn_readlane(le, l) + 1;
                 }
-                dst += __popcll(b);
             }
+            kept += chunk_kept;
+        },
+        [](int64_t) {});
+    if (lane == 0) s_kept[wv] = kept;
+    __syncthreads();
+    if (wv == 0) {                      // one word per workgroup: the four tiles' survivors
+        const int64_t tot = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        const int64_t excl = sync_publish_and_lookback(sync, t, tot, 0, 0, lane);
+        if (lane == 0) {
+            s_excl = excl;
+            if (t == n_groups - 1) { *n_out = excl < 0 ? -1 : excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
         }
-        t = s_ticket[par ^ 1];
+        sync_leave(sync, n_groups, lane);
+    }
+    __syncthreads();
+    int64_t dst = s_excl;
+    if (dst < 0) return;
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock - 1; ++k) dst += k < wv ? s_kept[k] : 0;
+    for (int j = lane; j < cnt; j += 64) {          // the LDS image leaves as one contiguous copy
+        st_stream(o_keys + dst + j, L_KEYS(j));
+        st_stream(o_ts + dst + j, L_TS(j));
+        st_stream(o_te + dst + j, L_TE(j));
+    }
+    if (over) {                                     // the counted-only remainder, as visibility_compact_kernel does it
+        __threadfence();                            // this wave's keep bytes, stored by other lanes, before they are loaded
+        dst += cnt;
+        for (int64_t base = ov_b; base < ov_e; base += 64) {
+            const int64_t i = base + lane;
+            const bool keepb = i < ov_e && ov_mask[i];
+            const unsigned long long b = __ballot(keepb);
+            if (keepb) {
+                const int64_t k = dst + __popcll(b & lanes_lt(lane));
+                st_stream(o_keys + k, keys[i]);
+                st_stream(o_ts + k, ts[i]);
+                st_stream(o_te + k, te[i]);
+            }
+            dst += __popcll(b);
+        }
     }
 #undef L_KEYS
 #undef L_TS
@@ -1037,7 +952,7 @@ NFA_EXPORT int nfa_render_weight_from_density_bwd(const int64_t *ray_indices, co
 }
 
 // workspace layout: [ front: bit planes of the mask pass (vis_plane_words; 32 bytes per 64 samples) — or, one-pass form, the keep
-// bytes of overflowing tiles: n ][ tile_cnts: T int64 ][ tile_offs: T int64 ][ tile_rng: 2 T int64 ] (one-pass form: its states)
+// bytes of overflowing tiles: n ][ tile_cnts: T int64 ][ tile_offs: T int64 ][ tile_rng: 2 T int64 ]
 // (sized for the smallest tile any plan of this n can pick: one element per lane)
 static inline int64_t vis_tiles(int64_t n) { return ceil_div(n > 0 ? n : 1, pick_plan(n, false).tile); }
 static inline int64_t vis_front_bytes(int64_t n) {
@@ -1046,10 +961,8 @@ static inline int64_t vis_front_bytes(int64_t n) {
     return ceil_div(planes > m ? planes : m, 16) * 16;
 }
 NFA_EXPORT int64_t nfa_visibility_workspace_bytes(int64_t n) {
-    // (the one-pass form keeps 1 + n / (2 * 64) words behind the front; the three-kernel form 4 words per tile)
-    const int64_t m = n > 0 ? n : 1;
-    const int64_t three = 4 * (int64_t)sizeof(int64_t) * vis_tiles(n), one = (int64_t)sizeof(uint64_t) * (2 + m / 128);
-    return vis_front_bytes(n) + (three > one ? three : one);
+    // (4 words per tile behind the front; the one-pass form only uses the front, for the keep bytes of overflowing tiles)
+    return vis_front_bytes(n) + 4 * (int64_t)sizeof(int64_t) * vis_tiles(n);
 }
 
 NFA_EXPORT int nfa_visibility_compact(const int64_t *ray_indices, const float *t_starts, const float *t_ends,
@@ -1068,7 +981,7 @@ static int visibility_compact_impl(const int64_t *ray_indices, const float *t_st
                                    void *stream);
 
 static bool vis_fusable(int64_t n, const TilePlan &pl) {
-    if (n <= 0 || opt(OPT_FUSED_VIS, 0) == 0 || opt(OPT_VIS_ONEPASS, 0) != 0) return false;
+    if (n <= 0 || opt(OPT_FUSED_VIS, 0) == 0) return false;
     const int64_t T = ceil_div(n, pl.tile), n_wg = tile_blocks(n, pl.tile);
     return T <= kVisFusedTiles && n_wg <= 3 * kNumCU && n_wg <= kSyncMaxBlocks;
 }
@@ -1117,27 +1030,6 @@ static int visibility_compact_impl(const int64_t *ray_indices, const float *t_st
     if (out_ray_indices) NFA_REQUIRE(out_t_starts && out_t_ends, "visibility_compact: compacted outputs must be given together");
     // (the byte mask is only written when the caller asks for it; the compaction reads the bit planes at the head of the workspace)
     const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, dens, out_mask}));
-    // the one-pass form (see visibility_onepass_kernel): opt-in only — measured SLOWER than the kernels below at every size
-    // (profiles/r05_streaming.md section 3)
-    if (out_ray_indices && pl.e <= 2 && resume == 0 && opt(OPT_VIS_ONEPASS, 0) != 0) {
-        const int64_t ch = 64 * pl.e;
-        const int64_t chunks = opt(OPT_VIS_CHUNKS, kVisOnePassChunks);
-        const int64_t otile = chunks * ch, OT = ceil_div(n, otile);
-        const int cap = (int)(otile + ch);
-        // workspace: [ keep bytes of overflowing tiles: n, padded to 16 ][ ticket + tile states: 1 + OT words ]
-        uint64_t *state = (uint64_t *)((uint8_t *)workspace + vis_front_bytes(n));
-        uint8_t *ov_mask = out_mask ? out_mask : (uint8_t *)workspace;
-        if (hipMemsetAsync(state, 0, (size_t)(1 + OT) * sizeof(uint64_t), s) != hipSuccess) return fail(NFA_ERR_LAUNCH, "visibility_compact: memset of the tile states failed");
-        const size_t lds = (size_t)kWavesPerBlock * cap * 16;
-        NFA_REQUIRE(lds <= 64 * 1024, "visibility_compact: vis_chunks = %lld needs %zu bytes of LDS per workgroup", (long long)chunks, lds);
-        const int64_t resident = (int64_t)kNumCU * std::min<int64_t>(8, std::max<int64_t>(1, (160 * 1024) / (int64_t)(lds + 256)));
-        const dim3 g((unsigned)std::min<int64_t>(ceil_div(OT, kWavesPerBlock), resident)), b(kBlock);
-        if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
-                                          early_stop_eps, alpha_thre, out_mask, ov_mask, state, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
-        else hipLaunchKernelGGL((visibility_onepass_kernel<1>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
-                                early_stop_eps, alpha_thre, out_mask, ov_mask, state, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
-        return check_launch("visibility_onepass_kernel");
-    }
     const int64_t tile = pl.tile, T = ceil_div(n, tile);
     uint64_t *planes = (uint64_t *)workspace;
     int64_t *tile_cnts = (int64_t *)((uint8_t *)workspace + vis_front_bytes(n));
@@ -1159,11 +1051,11 @@ static int visibility_compact_impl(const int64_t *ray_indices, const float *t_st
         const size_t lds = (size_t)kWavesPerBlock * cap * 16;
         if (groups <= 3 * kNumCU && groups <= kSyncMaxBlocks) {
             const dim3 g((unsigned)groups), b(kBlock);
-            if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2, true>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+            if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
                                               early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
-            else hipLaunchKernelGGL((visibility_onepass_kernel<1, true>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
+            else hipLaunchKernelGGL((visibility_onepass_kernel<1>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
                                     early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
-            return check_launch("visibility_onepass_kernel<static>");
+            return check_launch("visibility_onepass_kernel");
         }
     }
     NFA_LAUNCH_TILED(visibility_mask_kernel, pl, n, s, ray_indices, t_starts, t_ends,

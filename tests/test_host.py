@@ -68,14 +68,14 @@ def test_options_table_and_environment_seeding():
         with na.options(split_p=16, emit="rays"):
             assert na.get_option("split_p") == 16 and na.get_option("emit") == "rays"
         assert na.get_option("split_p") == 8 and na.get_option("emit") is None
-        assert {"skip", "vis_onepass", "vis_chunks", "emit_rb", "split_cap", "chunk_prefetch"} <= set(names)      # rounds 4-5
+        assert {"skip", "emit_rb", "split_cap", "chunk_prefetch"} <= set(names)      # rounds 4-5
         assert {"fused_sample", "fused_vis", "fold_fill"} <= set(names)                                                # round 6
-        assert "split_thr" not in names                                                                                # (pruned in round 6)
-        na.set_option("vis_onepass", 1); na.set_option("vis_chunks", 6)
-        assert na.get_option("vis_onepass") == 1 and na.get_option("NFA_VIS_CHUNKS") == 6
-        na.set_option("vis_onepass", None); na.set_option("vis_chunks", None)
-        for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1), ("vis_chunks", 1), ("vis_chunks", 8),
-                            ("vis_onepass", 2), ("skip", 2), ("split_p", 32), ("fused_vis", 2), ("fused_sample", 3)):
+        assert not {"split_thr", "vis_onepass", "vis_chunks"} & set(names)                                             # (pruned in round 6)
+        na.set_option("fused_vis", 1); na.set_option("emit_rb", 4)
+        assert na.get_option("fused_vis") == 1 and na.get_option("NFA_EMIT_RB") == 4
+        na.set_option("fused_vis", None); na.set_option("emit_rb", None)
+        for name, value in (("split_p", 3), ("emit", "r"), ("emit", ""), ("tile", 100), ("no_such_option", 1), ("vis_onepass", 1),
+                            ("skip", 2), ("split_p", 32), ("fused_vis", 2), ("fused_sample", 3)):
             if value == "":
                 na.set_option(name, value)          # "" = auto
                 assert na.get_option(name) is None
@@ -106,12 +106,12 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.nfa_packed_grid_words(1, 128, 128, 128) == 32768 + 12 + 512 + 512 + 32768 + 32768 // 16      # (+ one nibble per brick: round 5)
     assert lib.nfa_traverse_workspace_bytes(1000) > 0 and lib.nfa_visibility_workspace_bytes(1000) > 1000
     # the filter's workspace holds its bit planes (two slots of 2 E words per chunk of 64 E samples, E <= 4) plus four words per
-    # wave tile of the smallest plan, or n keep bytes plus a state word per 128 samples for the one-pass form — for every n
+    # wave tile of the smallest plan, or the n keep bytes of the one-pass form's overflowing tiles — for every n
     for n in (0, 1, 63, 64, 65, 1000, 4097, (1 << 17) - 1, 1 << 17, (1 << 20) + 3, 1 << 24):
         ws = lib.nfa_visibility_workspace_bytes(n)
         m = max(n, 1)
         planes = max(-(-m // (64 * e)) * 2 * 2 * e * 8 for e in (1, 2, 4))
-        assert ws % 8 == 0 and ws >= planes + 32 * -(-m // 576) and ws >= m + 8 * (2 + m // 128)
+        assert ws % 8 == 0 and ws >= planes + 32 * -(-m // 576) and ws >= m
 
 
 def test_native_paths_refuse_cpu_tensors():
