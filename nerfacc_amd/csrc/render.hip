@@ -769,9 +769,30 @@ __global__ __launch_bounds__(kBlock) void rendering_bwd_kernel(
                 q[e] = act[e] ? (EXT ? gw[e] * w[e] + p.gT[EXT ? e : 0] * p.T[e] : gw[e] * w[e]) : 0.0f;
             }
             if (g_rgbs) {
+                bool all = true;
 #pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (wr[e]) { g_rgbs[3 * (i0 + e)] = grgb[e][0]; g_rgbs[3 * (i0 + e) + 1] = grgb[e][1]; g_rgbs[3 * (i0 + e) + 2] = grgb[e][2]; }
+                for (int e = 0; e < E; ++e) all = all && wr[e];
+                if (E > 1 && __ballot(all) == ~0ull) {
+                    // interior chunks: the lane's 3 E floats are contiguous (and 4 E-byte aligned: i0 is a multiple of E) — three E-wide
+                    // stores instead of 3 E scalar ones (the mirror of ld_vec_strided)
+                    typedef float vec_t __attribute__((ext_vector_type(E)));
+                    float flat[3 * E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) flat[e * 3 + c] = grgb[e][c];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        vec_t v;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) v[e] = flat[j * E + e];
+                        *reinterpret_cast<vec_t *>(g_rgbs + 3 * i0 + j * E) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (wr[e]) { g_rgbs[3 * (i0 + e)] = grgb[e][0]; g_rgbs[3 * (i0 + e) + 1] = grgb[e][1]; g_rgbs[3 * (i0 + e) + 2] = grgb[e][2]; }
+                }
             }
             seg_scan_bwd<OpSum, E>(q, s, carry, incl, suffix);
 #pragma unroll
@@ -1164,7 +1185,7 @@ NFA_EXPORT int nfa_rendering_bwd(const int64_t *ray_indices, const float *t_star
     (void)weights;      // (not read since round 5: the kernel forms w = trans * alphas, exactly what the forward pass stored; nullable)
     NFA_REQUIRE(ray_indices && t_starts && t_ends && rgbs && trans && alphas, "rendering_bwd: NULL pointer");
     NFA_REQUIRE(!(g_depths && expected_depths) || (opacities && depths), "rendering_bwd: opacities/depths needed for g_depths");
-    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas}));
+    const TilePlan pl = pick_plan(n, aligned16({ray_indices, t_starts, t_ends, rgbs, trans, alphas, g_weights, g_trans, g_alphas, g_sigmas, g_rgbs}));
     const dim3 g_(tile_blocks(n, pl.tile)), b_(kBlock);
 #define NFA_RENDER_BWD(EE, XX) hipLaunchKernelGGL((rendering_bwd_kernel<EE, XX>), g_, b_, 0, (hipStream_t)stream, ray_indices, t_starts, t_ends, rgbs, trans, \
                                                   alphas, opacities, depths, n, pl.tile, pl.spec, n_rays, bkgd, expected_depths, g_colors, g_opacities, g_depths, \
