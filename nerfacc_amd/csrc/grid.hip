@@ -2005,6 +2005,7 @@ NFA_EXPORT int nfa_traverse_sample(const nfa_traverse_args *a, void *workspace, 
             fz.capacity = outputs ? capacity : 0;
             fz.stamp = stamp;
             fz.totals_dev = (int64_t *)((uint8_t *)workspace + ws_totals_offset(a->n_rays));
+            fz.spin = sync_spin_ticks();
             fz.seg_cap = 128;
             while (fz.seg_cap < rs.max_runs) fz.seg_cap *= 2;
             // the emit tail's segment lists take over the workgroup's LDS once its waves have counted

@@ -28,6 +28,9 @@ constexpr int kSyncMaxBlocks = NFA_SYNC_BYTES / 8 - kSyncHeaderWords;      // st
 constexpr uint64_t kStValueMask = (1ull << 62) - 1ull;
 constexpr uint64_t kStAgg = 1, kStPrefix = 2, kStAbort = 3;                // 0 = nothing yet
 constexpr uint64_t kSpinLimitTicks = 200000;                               // 2 ms of s_memrealtime (100 MHz)
+// what the host hands the kernels: option `sync_spin_us` (unset: 2 ms; 0: a look-back gives up at the first state that is not there yet —
+// how the tests reach the callers' fallback paths)
+inline uint64_t sync_spin_ticks() { return (uint64_t)opt(OPT_SYNC_SPIN_US, (int64_t)(kSpinLimitTicks / 100)) * 100ull; }
 
 __device__ __forceinline__ uint64_t sync_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -38,7 +41,7 @@ __device__ __forceinline__ void sync_drain() { asm volatile("s_waitcnt vmcnt(0)"
 // Sum of the values of states [0, b) — all 64 lanes of a wave call it and get the same answer; -1 = a state before b says ABORT,
 // or the wait ran out.  256 states per round trip, lane l looking at b - 1 - l, b - 65 - l, ... (position 0 = the nearest); the
 // walk stops at the nearest state that carries a PREFIX (the sum of everything up to and including its workgroup).
-__device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st, int64_t b, int lane) {
+__device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st, int64_t b, int lane, uint64_t spin_limit = kSpinLimitTicks) {
     constexpr int U = 4;
     int64_t excl = 0;
     const uint64_t t_begin = wall_clock64();
@@ -71,7 +74,8 @@ __device__ __forceinline__ int64_t sync_lookback(const uint64_t *__restrict__ st
             if (ok) break;
             // (the clock is a memory-path read: looked at every 16th round; no sleep between rounds — the loads' own round trip is the
             //  polling period, and one wave per workgroup polls)
-            if ((++spins & 15) == 0 && wall_clock64() - t_begin > kSpinLimitTicks) return -1;
+            // `spin_limit` = 0 (option `sync_spin_us` = 0, tests): give up at the first state that is not there yet
+            if (spin_limit == 0 || ((++spins & 15) == 0 && wall_clock64() - t_begin > spin_limit)) return -1;
         }
         int64_t sum = 0;
 #pragma unroll
@@ -96,15 +100,16 @@ __device__ __forceinline__ void sync_publish(uint64_t *__restrict__ sync, int64_
     }
 }
 // (the two halves of the hand-off, for a caller that has work to do between publishing its aggregate and needing the prefix)
-__device__ __forceinline__ int64_t sync_finish_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int lane) {
+__device__ __forceinline__ int64_t sync_finish_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int lane, uint64_t spin_limit = kSpinLimitTicks) {
     uint64_t *st = sync + kSyncHeaderWords;
-    const int64_t excl = sync_lookback(st, b, lane);
+    const int64_t excl = sync_lookback(st, b, lane, spin_limit);
     if (lane == 0) sync_store(st + b, excl < 0 ? (kStAbort << 62) : ((kStPrefix << 62) | (uint64_t)(excl + agg)));
     return excl;
 }
-__device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane) {
+__device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restrict__ sync, int64_t b, int64_t agg, int64_t extra0, int64_t extra1, int lane,
+                                                             uint64_t spin_limit = kSpinLimitTicks) {
     sync_publish(sync, b, agg, extra0, extra1, lane);
-    return sync_finish_lookback(sync, b, agg, lane);
+    return sync_finish_lookback(sync, b, agg, lane, spin_limit);
 }
 // called by the same wave when it no longer needs the states or the header: the last caller of the launch resets them
 __device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane) {

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void grid_mark_invisible_kernel(
 // ----------------------------------------------------------------------------------------
 template <int CPT>
 __global__ __launch_bounds__(kBlock) void occupied_cells_kernel(const uint8_t *__restrict__ cells, int64_t n_cells, int64_t *__restrict__ out,
-                                                                int64_t capacity, uint64_t *__restrict__ sync)
+                                                                int64_t capacity, uint64_t *__restrict__ sync, uint64_t spin)
 {
     static_assert(CPT % 16 == 0, "whole 16-byte loads");
     __shared__ int64_t s_w[kWavesPerBlock];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void occupied_cells_kernel(const uint8_t *_
     __syncthreads();
     if (wv == 0) {
         const int64_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        int64_t excl = sync_publish_and_lookback(sync, b, tot, 0, 0, lane);
+        int64_t excl = sync_publish_and_lookback(sync, b, tot, 0, 0, lane, spin);
         if (excl < 0) {                                   // (bounded wait ran out: count the cells before this workgroup directly)
             int64_t cnt = 0;
             const int64_t end = b * kBlock * CPT;
@@ -310,11 +310,11 @@ NFA_EXPORT int nfa_grid_occupied_cells(const uint8_t *cells, int64_t n_cells, in
     // cells per thread: 16 while that keeps the launch inside the sync block's states and on the chip at once, else 64 / 256
     const int64_t per16 = ceil_div(n_cells, (int64_t)kBlock * 16), per64 = ceil_div(n_cells, (int64_t)kBlock * 64), per256 = ceil_div(n_cells, (int64_t)kBlock * 256);
     const int64_t limit = std::min<int64_t>(kSyncMaxBlocks, (int64_t)kNumCU * 4);
-    if (per16 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<16>), dim3((unsigned)per16), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
-    else if (per64 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<64>), dim3((unsigned)per64), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
+    if (per16 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<16>), dim3((unsigned)per16), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync, sync_spin_ticks());
+    else if (per64 <= limit) hipLaunchKernelGGL((occupied_cells_kernel<64>), dim3((unsigned)per64), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync, sync_spin_ticks());
     else {
         NFA_REQUIRE(per256 <= limit, "grid_occupied_cells: %lld cells are more than one launch ranks (%lld)", (long long)n_cells, (long long)(limit * kBlock * 256));
-        hipLaunchKernelGGL((occupied_cells_kernel<256>), dim3((unsigned)per256), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync);
+        hipLaunchKernelGGL((occupied_cells_kernel<256>), dim3((unsigned)per256), dim3(kBlock), 0, s, cells, n_cells, out, capacity, (uint64_t *)sync, sync_spin_ticks());
     }
     return check_launch("occupied_cells_kernel");
 }

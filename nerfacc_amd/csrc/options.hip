@@ -34,6 +34,8 @@ bool parse_one_of(const char *s, int64_t *out) {
     return false;
 }
 bool parse_bool(const char *s, int64_t *out) { return parse_one_of<0, 1>(s, out); }
+template <int64_t LO, int64_t HI>
+bool parse_range(const char *s, int64_t *out) { return parse_int(s, out) && *out >= LO && *out <= HI; }
 bool parse_tile(const char *s, int64_t *out) { return parse_int(s, out) && *out >= 64 && *out % 64 == 0; }
 // strictly "rays" | "samples" | "tiles" (anything else used to mean "samples")
 bool parse_emit(const char *s, int64_t *out) {
@@ -65,6 +67,7 @@ const OptionSpec kSpecs[OPT_COUNT] = {
     {"fused_sample", "the sampling call as ONE launch (count, look-back over the workgroups and emit in the count kernel; 3072 ... 8192 rays of a one-level grid that fits LDS): 0 never, 1 when the caller's guess is at most 80 samples per ray (unset), 2 whatever the guess", parse_one_of<0, 1, 2>},
     {"fused_vis", "1: calls whose workgroups are all resident run the visibility filter as ONE launch (one pass, survivors staged in LDS and flushed behind a look-back over the workgroups); unset / 0: mask pass + compaction kernels (the single launch measures 3.5 us slower at the training size)", parse_bool},
     {"fold_fill", "0: nfa_rendering_fwd fills the rays without a sample with a launch of its own (unset: extra workgroups of its kernel do it for up to 2^20 samples, from the gaps between ascending ray_indices)", parse_bool},
+    {"sync_spin_us", "bound of a look-back's wait inside the single-launch forms (nfa_traverse_sample, nfa_visibility_compact_sync, nfa_grid_occupied_cells), microseconds: 0 ... 10000000 (unset: 2000; 0: a look-back gives up at the first state that is not there yet, and the caller's fallback runs — tests)", parse_range<0, 10000000>},
 };
 
 int find_option(const char *name) {

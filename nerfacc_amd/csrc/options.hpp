@@ -32,6 +32,7 @@ enum Option : int {
     OPT_FUSED_SAMPLE,    // nfa_traverse_sample's single-launch form: 0 never, 1 up to 80 samples of capacity per ray (default), 2 always inside its window
     OPT_FUSED_VIS,       // 1: the visibility filter of small calls as one launch (static one-pass kernel); default 0 (measured slower)
     OPT_FOLD_FILL,       // 0: nfa_rendering_fwd always fills the rays without a sample with a launch of its own (1: inside its kernel up to 2^20 samples)
+    OPT_SYNC_SPIN_US,    // bound of every look-back's wait inside the single-launch forms, microseconds (default 2000; 0: give up at once — tests)
     OPT_COUNT
 };
 

@@ -397,7 +397,7 @@ template <int E>
 __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
     const int64_t *__restrict__ keys, const float *__restrict__ ts, const float *__restrict__ te,
     const float *__restrict__ dens, int from_alpha, int64_t n, int64_t tile, float eps, float alpha_thre,
-    uint8_t *__restrict__ mask, uint8_t *__restrict__ ov_mask, uint64_t *__restrict__ sync, int64_t n_tiles, int cap,
+    uint8_t *__restrict__ mask, uint8_t *__restrict__ ov_mask, uint64_t *__restrict__ sync, uint64_t spin, int64_t n_tiles, int cap,
     int64_t *__restrict__ n_out, int64_t stamp, int64_t *__restrict__ o_keys, float *__restrict__ o_ts, float *__restrict__ o_te)
 {
     extern __shared__ __align__(16) uint8_t vis_smem[];
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
     __syncthreads();
     if (wv == 0) {                      // one word per workgroup: the four tiles' survivors
         const int64_t tot = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
-        const int64_t excl = sync_publish_and_lookback(sync, t, tot, 0, 0, lane);
+        const int64_t excl = sync_publish_and_lookback(sync, t, tot, 0, 0, lane, spin);
         if (lane == 0) {
             s_excl = excl;
             if (t == n_groups - 1) { *n_out = excl < 0 ? -1 : excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
@@ -1073,9 +1073,9 @@ static int visibility_compact_impl(const int64_t *ray_indices, const float *t_st
         if (groups <= 3 * kNumCU && groups <= kSyncMaxBlocks) {
             const dim3 g((unsigned)groups), b(kBlock);
             if (pl.e == 2) hipLaunchKernelGGL((visibility_onepass_kernel<2>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
-                                              early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+                                              early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, sync_spin_ticks(), OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
             else hipLaunchKernelGGL((visibility_onepass_kernel<1>), g, b, lds, s, ray_indices, t_starts, t_ends, dens, from_alpha, n, otile,
-                                    early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
+                                    early_stop_eps, alpha_thre, out_mask, ov_mask, (uint64_t *)sync, sync_spin_ticks(), OT, cap, n_out, stamp, out_ray_indices, out_t_starts, out_t_ends);
             return check_launch("visibility_onepass_kernel");
         }
     }

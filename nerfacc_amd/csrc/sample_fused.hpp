@@ -33,6 +33,7 @@ struct FuseArgs {
     int64_t stamp;
     int64_t *totals_dev;   // the workspace's copy of the totals (what nfa_traverse_offsets leaves there)
     int seg_cap;           // emit pass: segment-list entries per wave
+    uint64_t spin;         // bound of the look-back's wait in ticks of the 100 MHz clock (lookback.hpp: sync_spin_ticks)
 };
 
 // The emit pass's hook of the single launch (emit_pass.hpp: Hook): counts and wave-relative starts from the count kernel's registers;
@@ -59,7 +60,7 @@ struct FusedEmitHook {
         const int64_t b = blockIdx.x, nb = gridDim.x;
         int64_t excl = 0;
         if (wv == 0) {
-            excl = sync_finish_lookback(f.sync, b, b_sm, lane);
+            excl = sync_finish_lookback(f.sync, b, b_sm, lane, f.spin);
             if (lane == 0) *s_pre = excl;
             NFA_FUSE_STAMP(2);
         }

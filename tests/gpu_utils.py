@@ -51,3 +51,38 @@ def lego_like(seed, n_rays, res=128):
     d = tgt - o
     d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
     return o, d, aabb, occ[None]
+
+
+def sparse_like(seed, n_rays, res=128):
+    """as lego_like, with an object small enough that the grid's sparse image (non-empty bricks) fits LDS beside the crossing-time
+    arrays of the 512-thread count kernel — the window of the single-launch sampling call (round 6; the tests assert that it is)"""
+    rng = np.random.default_rng(seed)
+    aabb = np.array([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], np.float32)
+    g = (np.arange(res) + 0.5) / res * 3 - 1.5
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    occ = ((X**2 + Y**2 + Z**2) < 0.62**2) & ~((np.abs(X) < 0.2) & (np.abs(Y) < 0.2))
+    occ |= (np.abs(X) < 0.9) & (np.abs(Y) < 0.9) & (np.abs(Z + 0.8) < 0.05)
+    occ |= ((X - 0.9) ** 2 + (Y + 0.8) ** 2 + (Z - 0.7) ** 2) < 0.15**2
+    o = rng.standard_normal((n_rays, 3))
+    o = (4.0 * o / np.linalg.norm(o, axis=-1, keepdims=True)).astype(np.float32)
+    tgt = (rng.random((n_rays, 3)) * 3 - 1.5) * 0.9
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    return o, d, aabb, occ[None]
+
+
+def sampling_is_fused(o, d, occ, aabb, step):
+    """does nfa_traverse_sample take its single-launch form for this call?  (the C ABI's own answer: nfa_traverse_sample_fused)"""
+    import ctypes
+
+    from nerfacc_amd.cuda import _backend
+
+    L = _backend.load_library()
+    O, D, B, A = t(o), t(d), t(occ), t(aabb)
+    a = _backend._traverse_args(O, D, None, B, A, None, None, None, None, None, step, 0.0, 0)
+    R = O.shape[0]
+    cnt, st, tot = (torch.zeros(k, dtype=torch.int64, device=O.device) for k in (R, R, 4))
+    a.sm_cnts, a.sm_starts, a.totals = cnt.data_ptr(), st.data_ptr(), tot.data_ptr()
+    a.workspace_bytes = L.nfa_traverse_workspace_bytes(R)
+    return bool(L.nfa_traverse_sample_fused(ctypes.byref(a)))
+

@@ -75,11 +75,12 @@ def test_fused_filter_back_to_back_with_fused_sampling(force_options):
     one equal to the step with both single-launch forms switched off"""
     import numpy as np
 
-    from gpu_utils import lego_like, t
+    from gpu_utils import sampling_is_fused, sparse_like, t
 
     import nerfacc_amd
 
-    o, d, aabb, occ = lego_like(11, 6564)
+    o, d, aabb, occ = sparse_like(11, 6564)
+    assert sampling_is_fused(o, d, occ, aabb, 5e-3)
     est = nerfacc_amd.OccGridEstimator(roi_aabb=aabb[0].tolist(), resolution=occ.shape[1], levels=1).to(DEV)
     est.binaries = t(occ)
     O, D = t(o), t(d)

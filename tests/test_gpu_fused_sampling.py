@@ -105,11 +105,12 @@ def test_fused_sampling_equals_the_oracle(force_options):
     import torch
 
     import oracle
-    from gpu_utils import lego_like, n, t
+    from gpu_utils import n, sampling_is_fused, sparse_like, t
     from nerfacc_amd import cuda as C
 
     force_options(fused_sample=2)
-    o, d, aabb, occ = lego_like(3, 6564)
+    o, d, aabb, occ = sparse_like(3, 6564)
+    assert sampling_is_fused(o, d, occ, aabb, 5e-3)
     rng = np.random.default_rng(1)
     jit = rng.random(6564, dtype=np.float32)
     args = (t(o), t(d), t(occ), t(aabb), None, None, 5e-3, 0.0)
@@ -154,13 +155,15 @@ def test_fused_sampling_equals_unfused_on_ragged_batches(force_options):
     tensor for tensor, 40 times in a row (a stale sync block or a lost hand-off shows up as a difference or a hang)"""
     import torch
 
-    from gpu_utils import lego_like, t
+    from gpu_utils import sampling_is_fused, sparse_like, t
     from nerfacc_amd import cuda as C
 
     import nerfacc_amd
 
     rng = np.random.default_rng(7)
-    o, d, aabb, occ = lego_like(3, 8192)
+    o, d, aabb, occ = sparse_like(3, 8192)
+    assert sampling_is_fused(o, d, occ, aabb, 5e-3) and sampling_is_fused(o[:3072], d[:3072], occ, aabb, 5e-3)
+    assert not sampling_is_fused(o[:3071], d[:3071], occ, aabb, 5e-3)            # (below the window: three launches)
     # a third of the rays point away from the box
     flip = rng.random(8192) < 0.33
     d[flip] = -d[flip]
@@ -193,11 +196,12 @@ def test_fused_sampling_on_two_streams(force_options):
 
     import torch
 
-    from gpu_utils import lego_like, t
+    from gpu_utils import sampling_is_fused, sparse_like, t
     from nerfacc_amd import cuda as C
 
     force_options(fused_sample=2)
-    o, d, aabb, occ = lego_like(5, 8192)
+    o, d, aabb, occ = sparse_like(5, 8192)
+    assert sampling_is_fused(o, d, occ, aabb, 5e-3)
     O, D, B, A = t(o), t(d), t(occ), t(aabb)
     ref = C.sample_occgrid(O, D, B, A, None, None, 5e-3, 0.0, near_plane=0.0, far_plane=1e10)
     torch.cuda.synchronize()
