@@ -489,9 +489,19 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!waited) { gbase = hook.wait(); waited = true; }
+            // One chunk of 64 quad slots in two halves: `quad_compute` — which run a slot lies in, its lattice points — needs nothing
+            // but the segment list; `quad_store` needs the offset of the wave's first sample.  A deferred hook's wait sits between
+            // the two halves of the FIRST chunk (round 6: 38 of a training wave's ~40 quads; the look-back's last microseconds are
+            // spent on LDS reads and lattice arithmetic instead of waiting), later chunks run back to back.
+            struct QuadOut {
+                bool live = false;
+                int nv = 0, seg = 0, j = 0;
+                float sv[5];
+                int64_t s_rel = 0, rr = 0;      // first sample (without the deferred offset), ray
+            };
             int seg_lo = 0;                                          // wave-uniform: the run of the chunk's first quad
-            for (int qc = 0; qc < (gbase < 0 ? 0 : n_quads); qc += 64) {
+            auto quad_compute = [&](int qc) {
+                QuadOut q;
                 const int slot = qc + lane;
                 int seg = seg_lo;
 #if !NFA_EMIT_BISECT
@@ -527,7 +537,6 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
                         const int sp = seg_spos[seg];
                         const int j = 4 * (slot - seg_qpos[seg]);                   // the quad's first sample within its run
                         const int len = (seg + 1 < n_sub ? seg_spos[seg + 1] : span) - sp;
-                        const int nv = len - j < 4 ? len - j : 4;                   // samples of this quad (>= 1)
                         const int j1 = seg_j1[seg];
                         float tbase = seg_t0[seg];
                         uint32_t tb = nfa_f2u(tbase);
@@ -539,55 +548,81 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
                             inc = L.inc_at(tb);
                             jj = j - j1;
                         }
-                        float sv[5];
                         const uint64_t top = (uint64_t)((tb & 0x7fffffu) | 0x800000u) + (uint64_t)(uint32_t)(jj + 4) * inc;
                         if (inc != 0u && top < (1ull << 24)) {
                             const uint32_t b0 = tb + (uint32_t)jj * inc;
 #pragma unroll
-                            for (int k = 0; k < 5; ++k) sv[k] = nfa_u2f(b0 + (uint32_t)k * inc);
+                            for (int k = 0; k < 5; ++k) q.sv[k] = nfa_u2f(b0 + (uint32_t)k * inc);
                         } else {                                                    // (a quad on a binade edge, a second edge in one run)
-                            sv[0] = nfa_lattice_advance(tbase, dt, (int64_t)jj, nullptr);
+                            q.sv[0] = nfa_lattice_advance(tbase, dt, (int64_t)jj, nullptr);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) sv[k + 1] = sv[k] + dt;
+                            for (int k = 0; k < 4; ++k) q.sv[k + 1] = q.sv[k] + dt;
                         }
-                        const int64_t s = gbase + S_a + sp + j, rr = r0 + ray_s;
-                        if (!IV && nv == 4) {
-                            typedef float vf4 __attribute__((ext_vector_type(4)));
-                            if (a.t_starts) {
-                                const vf4 v0 = {sv[0], sv[1], sv[2], sv[3]}, v1 = {sv[1], sv[2], sv[3], sv[4]};
-                                __builtin_memcpy(a.t_starts + s, &v0, 16);
-                                __builtin_memcpy(a.t_ends + s, &v1, 16);
-                            }
-                            if (a.sm_vals) {
-                                const vf4 m = {(sv[1] + sv[0]) * 0.5f, (sv[2] + sv[1]) * 0.5f, (sv[3] + sv[2]) * 0.5f, (sv[4] + sv[3]) * 0.5f};
-                                __builtin_memcpy(a.sm_vals + s, &m, 16);
-                            }
-                            if (a.sm_ray_indices) {
-                                const int64_t rv[4] = {rr, rr, rr, rr};
-                                __builtin_memcpy(a.sm_ray_indices + s, rv, 32);
-                            }
-                            if (a.sm_is_valid) { const uint32_t ones = 0x01010101u; __builtin_memcpy(a.sm_is_valid + s, &ones, 4); }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (e >= nv) break;
-                                const float ta = sv[e], tb2 = sv[e + 1];
-                                if (a.sm_vals) a.sm_vals[s + e] = (tb2 + ta) * 0.5f;
-                                if (a.sm_ray_indices) a.sm_ray_indices[s + e] = rr;
-                                if (a.sm_is_valid) a.sm_is_valid[s + e] = 1;
-                                if (a.t_starts) { a.t_starts[s + e] = ta; a.t_ends[s + e] = tb2; }
-                                if (IV && a.iv_vals) {
-                                    // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
-                                    const int64_t e_right = s + e + seg_eoff[seg];
-                                    a.iv_vals[e_right] = tb2; a.iv_ray_indices[e_right] = rr; a.iv_is_right[e_right] = 1;
-                                    a.iv_is_left[e_right - 1] = 1;
-                                    if (j + e == 0) { a.iv_vals[e_right - 1] = ta; a.iv_ray_indices[e_right - 1] = rr; }
-                                }
-                            }
-                        }
+                        q.live = true;
+                        q.nv = len - j < 4 ? len - j : 4;                           // samples of this quad (>= 1)
+                        q.seg = seg;
+                        q.j = j;
+                        q.s_rel = S_a + sp + j;
+                        q.rr = r0 + ray_s;
                     }
                 }
                 seg_lo = readlane_dyn_i32(seg, 63);                  // (lane 63 idle = the last chunk)
+                return q;
+            };
+            auto quad_store = [&](const QuadOut &q) {
+                if (!q.live) return;
+                const float (&sv)[5] = q.sv;
+                const int nv = q.nv;
+                const int64_t s = gbase + q.s_rel, rr = q.rr;
+                if (!IV && nv == 4) {
+                    typedef float vf4 __attribute__((ext_vector_type(4)));
+                    if (a.t_starts) {
+                        const vf4 v0 = {sv[0], sv[1], sv[2], sv[3]}, v1 = {sv[1], sv[2], sv[3], sv[4]};
+                        __builtin_memcpy(a.t_starts + s, &v0, 16);
+                        __builtin_memcpy(a.t_ends + s, &v1, 16);
+                    }
+                    if (a.sm_vals) {
+                        const vf4 m = {(sv[1] + sv[0]) * 0.5f, (sv[2] + sv[1]) * 0.5f, (sv[3] + sv[2]) * 0.5f, (sv[4] + sv[3]) * 0.5f};
+                        __builtin_memcpy(a.sm_vals + s, &m, 16);
+                    }
+                    if (a.sm_ray_indices) {
+                        const int64_t rv[4] = {rr, rr, rr, rr};
+                        __builtin_memcpy(a.sm_ray_indices + s, rv, 32);
+                    }
+                    if (a.sm_is_valid) { const uint32_t ones = 0x01010101u; __builtin_memcpy(a.sm_is_valid + s, &ones, 4); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e >= nv) break;
+                        const float ta = sv[e], tb2 = sv[e + 1];
+                        if (a.sm_vals) a.sm_vals[s + e] = (tb2 + ta) * 0.5f;
+                        if (a.sm_ray_indices) a.sm_ray_indices[s + e] = rr;
+                        if (a.sm_is_valid) a.sm_is_valid[s + e] = 1;
+                        if (a.t_starts) { a.t_starts[s + e] = ta; a.t_ends[s + e] = tb2; }
+                        if (IV && a.iv_vals) {
+                            // edge layout of a ray: every run contributes len + 1 edges (grid.cu:219-245)
+                            const int64_t e_right = s + e + seg_eoff[q.seg];
+                            a.iv_vals[e_right] = tb2; a.iv_ray_indices[e_right] = rr; a.iv_is_right[e_right] = 1;
+                            a.iv_is_left[e_right - 1] = 1;
+                            if (q.j + e == 0) { a.iv_vals[e_right - 1] = ta; a.iv_ray_indices[e_right - 1] = rr; }
+                        }
+                    }
+                }
+            };
+            int qc = 0;
+            if (Hook::kDeferred && !waited && n_quads > 0) {           // (wave-uniform) the first chunk's arithmetic, then the wait, then its stores
+                const QuadOut q0 = quad_compute(0);
+                gbase = hook.wait();
+                waited = true;
+                if (gbase >= 0) quad_store(q0);
+                qc = 64;
+            }
+            if (!waited) { gbase = hook.wait(); waited = true; }
+            if (gbase >= 0) {
+                for (; qc < n_quads; qc += 64) {
+                    const QuadOut q = quad_compute(qc);
+                    quad_store(q);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                          // the list is rewritten by the next sub-block
