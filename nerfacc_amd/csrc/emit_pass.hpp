@@ -491,7 +491,7 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // One chunk of 64 quad slots in two halves: `quad_compute` — which run a slot lies in, its lattice points — needs nothing
             // but the segment list; `quad_store` needs the offset of the wave's first sample.  A deferred hook's wait sits between
-            // the two halves of the FIRST chunk (round 6: 38 of a training wave's ~40 quads; the look-back's last microseconds are
+            // the two halves of the FIRST TWO chunks (round 6: a training wave has ~40 quads; the look-back's last microseconds are
             // spent on LDS reads and lattice arithmetic instead of waiting), later chunks run back to back.
             struct QuadOut {
                 bool live = false;
@@ -610,12 +610,14 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
                 }
             };
             int qc = 0;
-            if (Hook::kDeferred && !waited && n_quads > 0) {           // (wave-uniform) the first chunk's arithmetic, then the wait, then its stores
+            if (Hook::kDeferred && !waited && n_quads > 0) {           // (wave-uniform) the first two chunks' arithmetic, then the wait, then their stores
                 const QuadOut q0 = quad_compute(0);
+                QuadOut q1;
+                if (n_quads > 64) q1 = quad_compute(64);
                 gbase = hook.wait();
                 waited = true;
-                if (gbase >= 0) quad_store(q0);
-                qc = 64;
+                if (gbase >= 0) { quad_store(q0); quad_store(q1); }
+                qc = n_quads > 64 ? 128 : 64;
             }
             if (!waited) { gbase = hook.wait(); waited = true; }
             if (gbase >= 0) {

@@ -111,18 +111,35 @@ __device__ __forceinline__ int64_t sync_publish_and_lookback(uint64_t *__restric
     sync_publish(sync, b, agg, extra0, extra1, lane);
     return sync_finish_lookback(sync, b, agg, lane, spin_limit);
 }
-// called by the same wave when it no longer needs the states or the header: the last caller of the launch resets them
-__device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane) {
+// Called by the same wave when it no longer needs the states or the header: the last caller of the launch resets them — after
+// `verdict(aborted, total)` has run on it (all 64 lanes; `aborted`: some workgroup's look-back gave up; `total`: what the highest
+// workgroup deposited, see sync_deposit).  The VERDICT of a launch — its total, or "a hand-off gave up: run the separate kernels" —
+// has to come from the workgroup that leaves LAST: only it knows that every other workgroup has decided.  (The highest workgroup can
+// finish its own look-back while a lower one, which started to wait earlier, is about to give up on a state that has just arrived:
+// reporting from there would call a launch complete whose lower workgroup stored nothing.)
+//   header words: [0] workgroups that have left, [1] / [2] the caller's extras, [3] workgroups that gave up, [4] total + 1
+__device__ __forceinline__ void sync_deposit(uint64_t *__restrict__ sync, int64_t excl, int64_t total_if_highest, bool highest, int lane) {
+    if (lane != 0) return;
+    if (excl < 0) sync_add(sync + 3, 1ull);
+    else if (highest) sync_store(sync + 4, (uint64_t)total_if_highest + 1ull);
+}
+template <class Verdict>
+__device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane, Verdict verdict) {
     unsigned long long d = 0;
     if (lane == 0) {
-        sync_drain();                                      // this workgroup's state stores have reached memory
+        sync_drain();                                      // this workgroup's state stores, its deposit, have reached memory
         d = __hip_atomic_fetch_add((unsigned long long *)sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     d = (unsigned long long)readfirstlane_i64((int64_t)d);
     if ((int64_t)d != n_blocks - 1) return;
+    const uint64_t gave_up = sync_load(sync + 3), total1 = sync_load(sync + 4);
+    verdict(gave_up != 0ull || total1 == 0ull, (int64_t)total1 - 1);
     uint64_t *st = sync + kSyncHeaderWords;
     for (int64_t i = lane; i < n_blocks; i += 64) sync_store(st + i, 0ull);
-    if (lane < 4) sync_store(sync + lane, 0ull);
+    if (lane < 8) sync_store(sync + lane, 0ull);
+}
+__device__ __forceinline__ void sync_leave(uint64_t *__restrict__ sync, int64_t n_blocks, int lane) {
+    sync_leave(sync, n_blocks, lane, [](bool, int64_t) {});
 }
 
 }  // namespace nfa

@@ -469,11 +469,14 @@ __global__ __launch_bounds__(kBlock) void visibility_onepass_kernel(
     if (wv == 0) {                      // one word per workgroup: the four tiles' survivors
         const int64_t tot = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
         const int64_t excl = sync_publish_and_lookback(sync, t, tot, 0, 0, lane, spin);
-        if (lane == 0) {
-            s_excl = excl;
-            if (t == n_groups - 1) { *n_out = excl < 0 ? -1 : excl + tot; if (stamp) { __threadfence_system(); n_out[1] = stamp; } }
-        }
-        sync_leave(sync, n_groups, lane);
+        if (lane == 0) s_excl = excl;
+        // the call's result comes from the workgroup that leaves last: only it knows that no look-back of the launch gave up
+        sync_deposit(sync, excl, excl + tot, t == n_groups - 1, lane);
+        sync_leave(sync, n_groups, lane, [&](bool gave_up, int64_t total) {
+            if (lane != 0) return;
+            *n_out = gave_up ? -1 : total;
+            if (stamp) { __threadfence_system(); n_out[1] = stamp; }
+        });
     }
     __syncthreads();
     int64_t dst = s_excl;

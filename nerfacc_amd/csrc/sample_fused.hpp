@@ -10,8 +10,8 @@
 //   4. every WAVE expands its own rays' run records into (ray_indices, t_starts, t_ends) with the tile form of the emit pass
 //      (emit_pass.hpp: the wave's 64 / P rays are one ray block, the records it reads were stored by its own workgroup a moment
 //      ago), into outputs the caller sized from its previous call (`capacity`; a wave whose samples end beyond it stores nothing).
-// The workgroup with the highest id stores the totals and the caller's stamp as soon as its look-back is through — the host is
-// released when every ray has been COUNTED, not when the last sample is written.  totals[1] = -1 says the look-back gave up (bounded
+// The workgroup that is through with its look-back LAST stores the totals and the caller's stamp — the host is released when every
+// ray has been COUNTED and every hand-off decided, not when the last sample is written.  totals[1] = -1 says the look-back gave up (bounded
 // wait): counts, run records and wave sums are complete as after nfa_traverse_count, and the caller goes on with
 // nfa_traverse_offsets.
 #pragma once
@@ -65,19 +65,21 @@ struct FusedEmitHook {
             NFA_FUSE_STAMP(2);
         }
         __syncthreads();
-        // behind the barrier (the workgroup's other waves are off to their stores): the call's totals and the host's stamp from the
-        // last workgroup, and this workgroup's leave — each a memory round trip the barrier does not have to wait for
+        // behind the barrier (the workgroup's other waves are off to their stores): this workgroup's leave, and — on the workgroup that
+        // leaves LAST, the only one that knows every look-back of the launch has been decided (lookback.hpp) — the call's totals and
+        // the host's stamp
         if (wv == 0) {
-            if (lane == 0 && b == nb - 1) {
-                // (every workgroup before this one added its edges / overflowed rays before its state became visible)
+            sync_deposit(f.sync, excl, excl + b_sm, b == nb - 1, lane);
+            sync_leave(f.sync, nb, lane, [&](bool gave_up, int64_t total) {
+                if (lane != 0) return;
+                // (every workgroup added its edges / overflowed rays before its state became visible)
                 const int64_t ed = (int64_t)sync_load(f.sync + 1), ov = (int64_t)sync_load(f.sync + 2);
-                const int64_t n = excl < 0 ? -1 : excl + b_sm;
+                const int64_t n = gave_up ? -1 : total;
                 f.totals_dev[0] = ed; f.totals_dev[1] = n; f.totals_dev[2] = ov; f.totals_dev[3] = 0;
                 a.totals[0] = ed; a.totals[1] = n; a.totals[2] = ov;
                 __threadfence_system();
                 a.totals[3] = f.stamp;
-            }
-            sync_leave(f.sync, nb, lane);
+            });
         }
         const int64_t pre = *s_pre;
         if (pre < 0) return -1;

@@ -3,7 +3,7 @@
 # (per-workgroup wall-clock stamps), the replay fused / in three launches with the oracle check, a kernel trace
 export TMPDIR=/tmp
 O=gpurun_out/r06_fused_sample; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_fused_sampling.py tests/test_k2_reference.py tests/test_gpu_sync_fallbacks.py tests/test_gpu_fuzz.py tests/test_gpu_grid.py tests/test_gpu_scenes.py -x -q 2>&1 | tail -6 > $O/tests.log
+timeout 1200 python -m pytest tests/test_gpu_fused_sampling.py tests/test_gpu_fused_filter.py tests/test_k2_reference.py tests/test_gpu_sync_fallbacks.py tests/test_gpu_fuzz.py tests/test_gpu_grid.py tests/test_gpu_scenes.py tests/test_gpu_occgrid.py -x -q 2>&1 | tail -6 > $O/tests.log
 timeout 300 python tools/fuse_trace.py profiles/r02_sampling_state.npz 20 > $O/fuse_trace.log 2>&1
 for f in 1 0; do
   NFA_FUSED_SAMPLE=$f python tools/traverse_replay.py profiles/r02_sampling_state.npz 200 --check > $O/replay_f$f.log 2>&1
