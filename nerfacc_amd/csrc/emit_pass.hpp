@@ -401,6 +401,21 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             if (n_total > capacity) return;                         // outputs too small: the caller launches again after its read-back
             checked = true;
         }
+#ifdef NFA_EMIT_CHECK
+        // (debug build: what the kernel was handed, validated before anything depends on it)
+        {
+            const bool bad_counts = own && (cnt < 0 || S < 0 || (n_total > 0 && S + cnt > n_total));
+            const bool bad_runs = own && cnt > 0 && nr != kRunsOverflow && (nr < 1 || nr > rs.max_runs);
+            const bool bad_rec = own && cnt > 0 && nr != kRunsOverflow && !bad_runs &&
+                                 ((w > 0 && w < nr && w < kEmitSpeculate && (first_q <= 0 || first_q >= cnt)) ||
+                                  (w + 1 < nr && w < kEmitSpeculate && (next_q <= first_q || next_q >= cnt)));
+            if (bad_counts || bad_runs || bad_rec)
+                printf("EMIT CHECK: block %d wave %d lane %d ray %lld of %lld: cnt %lld S %lld nr %d max_runs %d first %d next %d n_total %lld capacity %lld rb %d seg_cap %d (%d%d%d)\n",
+                       (int)blockIdx.x, (int)(threadIdx.x >> 6), lane, (long long)r, (long long)R, (long long)cnt, (long long)S, nr, rs.max_runs, first_q, next_q,
+                       (long long)n_total, (long long)capacity, rb_log2, seg_cap, (int)bad_counts, (int)bad_runs, (int)bad_rec);
+            if (__ballot(bad_counts || bad_runs || bad_rec)) return;
+        }
+#endif
         if (cnt < 0) cnt = 0;
         const bool skip = nr == kRunsOverflow;
         const int nseg = cnt > 0 ? (skip ? 1 : nr) : 0;
