@@ -398,9 +398,15 @@ __device__ __forceinline__ void emit_by_tiles(const nfa_traverse_args &a, const 
             if (W + w + 1 < rs.max_runs && W + w < lim) next_q2 = rs.first[(int64_t)(W + w + 1) * R + r];
         }
         if (!checked) {
-            if (n_total > capacity) return;                         // outputs too small: the caller launches again after its read-back
-            checked = true;
+            if (n_total > capacity || n_total < 0) return;          // outputs too small: the caller launches again after its read-back
+            checked = true;                                         // (a negative total cannot be: see below)
         }
+        // Defence, a handful of instructions per RAY: counts, offsets or run counts that cannot be are not expanded.  They were seen
+        // once in ~60 runs of eight processes sharing one GPU — every eighth workgroup of the count launch (one XCD's share) had left
+        // none of its stores in memory, profiles/r06_oversubscription.md — and the samples of a ray placed by such an offset are wild
+        // stores.  The call's totals are inconsistent in the same way; the host raises on them.
+        if (!Hook::kDeferred && capacity > 0 && (S < 0 || S > capacity || cnt > capacity - S)) cnt = 0;
+        if (nr != kRunsOverflow && nr > rs.max_runs) cnt = 0;
 #ifdef NFA_EMIT_CHECK
         // (debug build: what the kernel was handed, validated before anything depends on it)
         {

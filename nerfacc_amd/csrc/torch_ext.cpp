@@ -764,6 +764,11 @@ py::tuple sample_occgrid(const Tensor &rays_o, const Tensor &rays_d, const Tenso
         emitted = false;
     }
     const int64_t n = h[1], n_overflow = h[2];
+    // (totals that cannot be — seen once in ~60 runs of eight processes sharing one GPU, when the count launch lost one XCD's share of
+    //  its workgroups' stores, profiles/r06_oversubscription.md: an error the caller can see instead of outputs sized by garbage)
+    TORCH_CHECK(n >= 0 && n_overflow >= 0 && n_overflow <= R && h[0] >= n,
+                "nerfacc_amd: sample_occgrid read back inconsistent totals (edges ", h[0], ", samples ", n, ", overflow rays ", n_overflow, " of ", R,
+                " rays): the count pass's outputs are corrupt");
     last_spr[dev] = R > 0 ? (double)n / (double)R : 0.0;
     if (emitted && n <= cap) {
         if (n_overflow > 0) check_rc(nfa_traverse_fill(&a, 1, 0, ws.data_ptr(), 0, n_overflow, s));     // the rays the count pass flagged

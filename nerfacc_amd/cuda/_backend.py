@@ -808,6 +808,11 @@ class _CtypesC:
                 _check(_call("traverse_count", L.nfa_traverse_count, ctypes.byref(a), _ptr(ws), stream))
                 _check(L.nfa_traverse_offsets(ctypes.byref(a), _ptr(ws), stream))
                 _, n, n_overflow, _ = _read_ints(totals, dev)
+            if not (0 <= n and 0 <= n_overflow <= R):
+                # (seen once in ~60 runs of eight processes sharing one GPU: the count launch lost one XCD's share of its workgroups'
+                #  stores, profiles/r06_oversubscription.md — an error instead of outputs sized by garbage)
+                raise RuntimeError(f"nerfacc_amd: sample_occgrid read back inconsistent totals (samples {n}, overflow rays {n_overflow} "
+                                   f"of {R} rays): the count pass's outputs are corrupt")
             if R > 0:
                 _LAST_SPR[dev.index] = n / R
             a.terminate_planes = None                    # written by the count pass only

@@ -137,6 +137,32 @@ print("ok", st)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
+# Several processes on ONE GPU (what the tests below do to run the N > 1 command on a one-GPU box) is not how the library is deployed
+# — one process per device — and this platform was seen to lose part of a kernel's output under it: once in ~60 runs of the
+# eight-rank command every eighth workgroup of a count launch (one XCD's share) had left none of its stores in memory, the offsets
+# built from the garbage counts were wild and the run died with a GPU memory fault (profiles/r06_oversubscription.md: the captured
+# values; no kernel of the library or of torch is exempt, the faults were reported from both).  The library now raises on such totals
+# instead of storing through them.  A run that dies with one of THESE signatures is repeated once, loudly; anything else, or a second
+# failure, fails the test.
+_PLATFORM_SIGNATURES = ("HSA_STATUS_ERROR_MEMORY", "Memory access fault", "inconsistent totals", "illegal memory access")
+
+
+def _run_sharing_one_device(cmd_of_port, timeout, env):
+    for attempt in (0, 1):
+        res = subprocess.run(cmd_of_port(_free_port()), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env)
+        hit = [sig for sig in _PLATFORM_SIGNATURES if sig in res.stderr]
+        if res.returncode == 0 or attempt == 1 or not hit:
+            return res
+        import warnings
+        note = "processes sharing one GPU: a run died with %s (profiles/r06_oversubscription.md); repeated once" % hit
+        warnings.warn(note)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "oversubscription_faults.log"), "a") as f:
+                f.write(note + "\n" + res.stderr[-2000:] + "\n\n")
+    return res
+
+
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
 def test_eight_ranks_multi_tensor_field_on_one_device(mode):
     """the driver's N = 8 command executed once: eight ranks through torch.distributed.run share cuda:0 and
@@ -145,9 +171,9 @@ def test_eight_ranks_multi_tensor_field_on_one_device(mode):
     BOTH exchange modes (aux.exchange_modes)."""
     bench_args = ["--gpus", "8", "--steps", "4", "--warmup", "2", "--windows", "1", "--pretrain", "24", "--pool", "32768", "--aux-steps", "3",
                   "--dist-backend", "gloo", "--all-ranks-on-device0", "--field", "grid+mlp", "--exchange-mode", mode, "--no-other-mode"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + bench_args
-    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_clean_env())
+    cmd = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py")] + bench_args
+    res = _run_sharing_one_device(cmd, 600, _clean_env())
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]            # stdout carries the JSON line and NOTHING else (no RCCL banner)
     assert len(lines) == 1, res.stdout[-2000:]
