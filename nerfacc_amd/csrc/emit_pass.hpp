@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void traverse_emit_kernel(nfa_traverse_args
                                                                const int64_t *__restrict__ n_dev, int speculative, int hint)
 {
     const int64_t n_ed = n_dev[0], n_sm = n_dev[1];
-    if (speculative && n_sm > capacity) return;
+    if (speculative && (n_sm > capacity || n_sm < 0)) return;        // (a negative total cannot be: emit_by_tiles has the story)
     const int64_t runs = n_ed - n_sm > 0 ? n_ed - n_sm : 1;
     const bool long_runs = a.cone_angle != 0.0f ? n_sm >= 8 * runs : (n_sm >= 900000 && n_sm >= 20 * runs);
     if (hint == 1 || (hint != 2 && long_runs)) emit_by_ray_groups(a, rs);
