@@ -42,7 +42,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                                                                      int64_t *__restrict__ block_sums, RunStore rs, VoxelStore vs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    NFA_PHASE_BEGIN();
     const Occ<LDS_OCC> occ = stage_occupancy<LDS_OCC>(gv, smem);
+    NFA_PHASE_MARK(0);
     int32_t *seg_n = (int32_t *)(smem + occ.bytes);      // [kBlock] records of every lane's segment; -1: the lane has no segment
     float *seg_start = (float *)(seg_n + kBlock);        // [kBlock] the segment's clipped start (grid.cu:148)
     float *seg_end = seg_start + kBlock;                 // [kBlock] and end: no voxel of the segment exits later
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
     float seg_lo = 0.f, seg_hi = 0.f;
     const bool live = ray_ok && slot + 1 < 2 * G && segment_of(ev, slot, G, near, far, level, seg_lo, seg_hi);
 
+    NFA_PHASE_MARK(1);
     // ---- phase 1: the segment's (the part's) voxels -> records
     uint32_t *const my = vs.rec + (int64_t)blockIdx.x * (vs.cap + VoxelStore::kSlack) * kBlock + tid;
     int n = 0;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
             part_live = live && sub == 0;                  // odd index bookkeeping: the segment's first lane walks all of it
         }
     }
+    NFA_PHASE_MARK(2);
     if (part_live) {
         const uint32_t *lc = (const uint32_t *)occ.smem;
         constexpr int B = 4;
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
             if (n > vs.cap) { bad = true; more = false; }        // cannot happen (cap = rx + ry + rz); keeps a broken walk inside its plane
         }
     }
+    NFA_PHASE_MARK(3);
     seg_n[tid] = n;                                        // 0: no segment in this lane's slot, or an empty / dead part
     seg_start[tid] = seg_lo;
     seg_end[tid] = seg_hi;
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
     const unsigned long long live_lists = (__ballot(n > 0) >> group_base) & group_mask;     // bit l: lane l of the ray has records
     __threadfence_block();
     __syncthreads();
+    NFA_PHASE_MARK(4);
 
     // ---- phase 2: the chain, one lane per ray
     int64_t out_iv = 0, out_sm = 0, out_ovf = 0;
@@ -237,12 +243,24 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                 if (seg_begins && !cont) {                          // march to the segment's start (grid.cu:153-163)
                     const float lo = seg_start[tid + sg];
                     const float dt = march_dt(t, cone, step_size), h = dt * 0.5f;
+#ifdef NFA_PHASE_CYCLES
+                    const unsigned long long c0_ = __builtin_readcyclecounter();
+#endif
                     while (t + h < lo) {
                         const float nt = t + dt;
                         if (nt == t) { t = lo; break; }             // stuck lattice: as the oracle's lattice_skip
                         t = nt;
+#ifdef NFA_PHASE_CYCLES
+                        ph_[13] += 1ull;
+#endif
                     }
+#ifdef NFA_PHASE_CYCLES
+                    ph_[9] += __builtin_readcyclecounter() - c0_;
+#endif
                 }
+#ifdef NFA_PHASE_CYCLES
+                ph_[10] += (unsigned long long)nv; ph_[12] += 1ull;
+#endif
                 for (int v = 0; v < nv && !dead; ++v) {
                     const uint32_t rec = nxt;
                     p += kBlock;
@@ -266,6 +284,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                         // test t + dt/2 < e as ONE fma: dt * 0.5 is exact, so fma(dt, 0.5, t) rounds the same sum once.
                         // add, mul, max, fma, compare: 8 instructions per step with the loop's own three (13 before, 20 with the
                         // stuck test).
+#ifdef NFA_PHASE_CYCLES
+                        const unsigned long long c1_ = __builtin_readcyclecounter();
+#endif
                         if (fast_seg) {
                             const float cA = oc ? cone : 0.0f, fl = oc ? step_size : dt;
                             int k = 0;
@@ -275,6 +296,9 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                                 ++k;
                             } while (fmaf(dt, 0.5f, t) < e);
                             k_oc += oc ? k : 0;
+#ifdef NFA_PHASE_CYCLES
+                            ph_[11] += (unsigned long long)k;
+#endif
                         } else {
                             while (go) {
                                 const float nt = t + dt;
@@ -284,8 +308,14 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                                 dead = stuck && oc;                         // (the reference would spin here forever)
                                 dt = oc ? march_dt(nt, cone, step_size) : dt;
                                 go = !stuck && t + dt * 0.5f < e;
+#ifdef NFA_PHASE_CYCLES
+                                ph_[8] += 1ull;
+#endif
                             }
                         }
+#ifdef NFA_PHASE_CYCLES
+                        ph_[7] += __builtin_readcyclecounter() - c1_;
+#endif
                     }
                 }
                 n_sm += k_oc;
@@ -310,5 +340,8 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
         if (a.iv_cnts) a.iv_cnts[r] = out_iv;
         a.sm_cnts[r] = out_sm;
     }
+    NFA_PHASE_MARK(5);
     publish_wave_sums(out_iv, out_sm, out_ovf, block_sums);
+    NFA_PHASE_MARK(6);
+    NFA_PHASE_END();
 }
