@@ -243,9 +243,6 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                 if (seg_begins && !cont) {                          // march to the segment's start (grid.cu:153-163)
                     const float lo = seg_start[tid + sg];
                     const float dt = march_dt(t, cone, step_size), h = dt * 0.5f;
-#ifdef NFA_PHASE_CYCLES
-                    const unsigned long long c0_ = __builtin_readcyclecounter();
-#endif
                     while (t + h < lo) {
                         const float nt = t + dt;
                         if (nt == t) { t = lo; break; }             // stuck lattice: as the oracle's lattice_skip
@@ -254,70 +251,70 @@ __global__ __launch_bounds__(kBlock) void traverse_count_cone_kernel(nfa_travers
                         ph_[13] += 1ull;
 #endif
                     }
-#ifdef NFA_PHASE_CYCLES
-                    ph_[9] += __builtin_readcyclecounter() - c0_;
-#endif
                 }
 #ifdef NFA_PHASE_CYCLES
                 ph_[10] += (unsigned long long)nv; ph_[12] += 1ull;
 #endif
-                for (int v = 0; v < nv && !dead; ++v) {
-                    const uint32_t rec = nxt;
-                    p += kBlock;
-                    nxt = *p;                                       // (the row behind a segment's last record exists: slack rows)
-                    const bool oc = (rec >> 31) != 0u;
-                    const float e = __uint_as_float(rec & 0x7fffffffu);
-                    float dt = march_dt(t, cone, step_size), h = dt * 0.5f;
-                    bool go = t + h < e;
-                    if (oc && go && !cont) {                        // a run of samples starts here
-                        if (store_runs && n_runs < rs.max_runs) {
-                            rs.t0[(int64_t)n_runs * R + r] = t;
-                            rs.first[(int64_t)n_runs * R + r] = (int32_t)(n_sm + k_oc);
+                // The list's voxels, in two versions (round 6): the FAST one — fast_seg holds for the whole list, decided above — has no
+                // stuck lattice, hence no `dead` ray, no careful step loop and none of the mask bookkeeping the compiler keeps for
+                // them between two records (tools/cone_phases.py: the code between two records was ~650 of the chain's cycles
+                // per voxel, the steps ~130); the careful one is the loop as it was.
+                auto voxels = [&](auto fast) {
+                    constexpr bool kFast = decltype(fast)::value;
+                    for (int v = 0; v < nv && (kFast || !dead); ++v) {
+                        const uint32_t rec = nxt;
+                        p += kBlock;
+                        nxt = *p;                                   // (the row behind a segment's last record exists: slack rows)
+                        const bool oc = (rec >> 31) != 0u;
+                        const float e = __uint_as_float(rec & 0x7fffffffu);
+                        float dt = march_dt(t, cone, step_size), h = dt * 0.5f;
+                        bool go = t + h < e;
+                        if (oc && go && !cont) {                    // a run of samples starts here
+                            if (store_runs && n_runs < rs.max_runs) {
+                                rs.t0[(int64_t)n_runs * R + r] = t;
+                                rs.first[(int64_t)n_runs * R + r] = (int32_t)(n_sm + k_oc);
+                            }
+                            ++n_runs;
                         }
-                        ++n_runs;
-                    }
-                    cont = oc ? (cont || go) : false;               // grid.cu:205, 256
-                    if (go) {
-                        // The step loop, written for its dependent instruction count (the steps are what this phase's time
-                        // is made of).  (1) No stuck test and (2) no upper clamp: see fast_seg above.  (3) No select between "dt re-evaluated" (occupied) and "dt as at the
-                        // voxel's entry" (empty): dt = max(t * cA, floor) with cA = cone / 0 and floor = step / dt.  (4) the
-                        // test t + dt/2 < e as ONE fma: dt * 0.5 is exact, so fma(dt, 0.5, t) rounds the same sum once.
-                        // add, mul, max, fma, compare: 8 instructions per step with the loop's own three (13 before, 20 with the
-                        // stuck test).
+                        cont = oc ? (cont || go) : false;           // grid.cu:205, 256
+                        if (go) {
+                            // The step loop, written for its dependent instruction count.  (1) No stuck test and (2) no upper
+                            // clamp: see fast_seg above.  (3) No select between "dt re-evaluated" (occupied) and "dt as at the
+                            // voxel's entry" (empty): dt = max(t * cA, floor) with cA = cone / 0 and floor = step / dt.  (4) the
+                            // test t + dt/2 < e as ONE fma: dt * 0.5 is exact, so fma(dt, 0.5, t) rounds the same sum once.
+                            // add, mul, max, fma, compare: 8 instructions per step with the loop's own three (13 before, 20 with
+                            // the stuck test).
+                            if constexpr (kFast) {
+                                const float cA = oc ? cone : 0.0f, fl = oc ? step_size : dt;
+                                int k = 0;
+                                do {
+                                    t = t + dt;
+                                    dt = fmaxf(t * cA, fl);
+                                    ++k;
+                                } while (fmaf(dt, 0.5f, t) < e);
+                                k_oc += oc ? k : 0;
 #ifdef NFA_PHASE_CYCLES
-                        const unsigned long long c1_ = __builtin_readcyclecounter();
+                                ph_[11] += (unsigned long long)k;
 #endif
-                        if (fast_seg) {
-                            const float cA = oc ? cone : 0.0f, fl = oc ? step_size : dt;
-                            int k = 0;
-                            do {
-                                t = t + dt;
-                                dt = fmaxf(t * cA, fl);
-                                ++k;
-                            } while (fmaf(dt, 0.5f, t) < e);
-                            k_oc += oc ? k : 0;
+                            } else {
+                                while (go) {
+                                    const float nt = t + dt;
+                                    const bool stuck = nt == t;
+                                    n_sm += oc ? 1 : 0;
+                                    t = (stuck && !oc) ? e : nt;            // stuck lattice in an empty voxel: as the oracle's lattice_skip
+                                    dead = stuck && oc;                     // (the reference would spin here forever)
+                                    dt = oc ? march_dt(nt, cone, step_size) : dt;
+                                    go = !stuck && t + dt * 0.5f < e;
 #ifdef NFA_PHASE_CYCLES
-                            ph_[11] += (unsigned long long)k;
+                                    ph_[8] += 1ull;
 #endif
-                        } else {
-                            while (go) {
-                                const float nt = t + dt;
-                                const bool stuck = nt == t;
-                                n_sm += oc ? 1 : 0;
-                                t = (stuck && !oc) ? e : nt;                // stuck lattice in an empty voxel: as the oracle's lattice_skip
-                                dead = stuck && oc;                         // (the reference would spin here forever)
-                                dt = oc ? march_dt(nt, cone, step_size) : dt;
-                                go = !stuck && t + dt * 0.5f < e;
-#ifdef NFA_PHASE_CYCLES
-                                ph_[8] += 1ull;
-#endif
+                                }
                             }
                         }
-#ifdef NFA_PHASE_CYCLES
-                        ph_[7] += __builtin_readcyclecounter() - c1_;
-#endif
                     }
-                }
+                };
+                if (fast_seg) voxels(std::true_type());
+                else voxels(std::false_type());
                 n_sm += k_oc;
             }
             const int64_t n_iv = n_sm + n_runs;                     // every run has one edge more than samples (grid.cu:219-245)
