@@ -176,6 +176,7 @@ __host__ __device__ inline PackedLayout packed_layout(int n_grids, int rx, int r
 // FROM_OCCS: the voxels come from the float occupancies (`occs > min(mean, occ_thre)`, occ_grid.py:392-404) and the
 // bool grid is an OUTPUT — threshold and bit-pack in one pass (nfa_grid_threshold_packed).
 constexpr int kPackBlock = 512;
+constexpr int kPackWords = 4;      // coarse words (32 bricks each) per workgroup
 template <bool FROM_OCCS>
 __global__ __launch_bounds__(kPackBlock) void pack_bricks_kernel(
     const uint8_t *__restrict__ binaries, int n_grids, int rx, int ry, int rz,
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(kPackBlock) void pack_bricks_kernel(
     const float *__restrict__ occs, const double *__restrict__ partials, int n_partials, float occ_thre,
     uint8_t *__restrict__ binaries_out, float *__restrict__ thre_out)
 {
-    __shared__ uint32_t s_any[kPackBlock / 64];
-    __shared__ int s_cnt[kPackBlock / 64];
+    __shared__ uint32_t s_any[kPackWords][kPackBlock / 64];
+    __shared__ int s_cnt[kPackWords][kPackBlock / 64];
     float thre = 0.0f;
     if (FROM_OCCS) {
         __shared__ float s_thre;
@@ -203,8 +204,16 @@ __global__ __launch_bounds__(kPackBlock) void pack_bricks_kernel(
     const int64_t n_words = (total + 31) / 32;
     const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
     const int lb = (int)(threadIdx.x >> 4), dx = (int)((threadIdx.x >> 2) & 3), dy = (int)(threadIdx.x & 3);
-    for (int64_t w = blockIdx.x; w < n_words; w += gridDim.x) {
-        const int64_t b = w * 32 + lb;
+    // kPackWords consecutive coarse words per workgroup (round 6).  (1) ONE atomic per workgroup and level (thread 0 adds up): the
+    // atomics on a level's counter serialise in the L2 — one per word, 1 024 of them for a 128^3 grid and 4 096 for four levels, were
+    // a third of this kernel's 19 / 44 us.  (2) The words' loads are all requested before the first is looked at, and the workgroup
+    // meets ONCE: a word per trip was a memory round trip and two barriers per word.
+    const int64_t w_begin = (int64_t)blockIdx.x * kPackWords;
+    uint32_t nibs[kPackWords];
+    int64_t gs[kPackWords];
+#pragma unroll
+    for (int i = 0; i < kPackWords; ++i) {
+        const int64_t b = (w_begin + i) * 32 + lb;
         uint32_t nib = 0;
         int64_t g = 0;
         if (b < total) {
@@ -237,44 +246,61 @@ __global__ __launch_bounds__(kPackBlock) void pack_bricks_kernel(
                 }
             }
         }
+        nibs[i] = nib;
+        gs[i] = g;
+    }
+    const bool leader = (threadIdx.x & 15) == 0;
+    const int sh = dx * 16 + dy * 4;
+#pragma unroll
+    for (int i = 0; i < kPackWords; ++i) {
+        const int64_t w = w_begin + i, b = w * 32 + lb;
         // the brick's word: bit dx * 16 + dy * 4 + dz — OR over the brick's sixteen lanes (row rotations by 1, 2, 4, 8)
-        const int sh = dx * 16 + dy * 4;
-        uint32_t lo = sh < 32 ? nib << sh : 0u, hi = sh >= 32 ? nib << (sh - 32) : 0u;
+        uint32_t lo = sh < 32 ? nibs[i] << sh : 0u, hi = sh >= 32 ? nibs[i] << (sh - 32) : 0u;
 #define NFA_ROW_OR(N)                                                                                          \
         lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x120 + N, 0xf, 0xf, false);                      \
         hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x120 + N, 0xf, 0xf, false);
         NFA_ROW_OR(1) NFA_ROW_OR(2) NFA_ROW_OR(4) NFA_ROW_OR(8)
 #undef NFA_ROW_OR
         const uint64_t bits = ((uint64_t)hi << 32) | lo;
-        const bool leader = (threadIdx.x & 15) == 0;
         if (leader && b < total) bricks[b] = bits;
         // the wave's four bricks: non-empty flags (bits 4 wv ... 4 wv + 3 of the coarse word) and occupied voxels
         const unsigned long long any = __ballot(leader && bits != 0ull);
         const uint32_t four = (uint32_t)((any & 1ull) | ((any >> 15) & 2ull) | ((any >> 30) & 4ull) | ((any >> 45) & 8ull));
         const int cnt = (int)wave_sum_i64(leader ? (int64_t)__popcll(bits) : (int64_t)0);
+        if (lane == 0) { s_any[i][wv] = four; s_cnt[i][wv] = cnt; }
         // occupied voxels per level (integer atomics: deterministic): lets OccGridEstimator size its list of occupied cells without
-        // a sync.  One atomic per workgroup (every brick adding to the same word serialises in the L2: 105 us for 32 k bricks)
-        // unless its 32 bricks straddle two levels.
-        const int64_t g_first = (w * 32) / per_grid, g_last = ((w * 32 + 31 < total ? w * 32 + 31 : total - 1)) / per_grid;
-        if (lane == 0) { s_any[wv] = four; s_cnt[wv] = cnt; }
-        if (g_first != g_last && leader && bits) atomicAdd((unsigned long long *)(level_counts + g), (unsigned long long)__popcll(bits));
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        // a sync.  A word whose 32 bricks straddle two levels adds brick by brick.
+        if (w < n_words) {
+            const int64_t g_first = (w * 32) / per_grid, g_last = ((w * 32 + 31 < total ? w * 32 + 31 : total - 1)) / per_grid;
+            if (g_first != g_last && leader && bits && b < total) atomicAdd((unsigned long long *)(level_counts + gs[i]), (unsigned long long)__popcll(bits));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t acc_cnt = 0, acc_g = -1;
+        for (int i = 0; i < kPackWords; ++i) {
+            const int64_t w = w_begin + i;
+            if (w >= n_words) break;
             uint32_t word = 0;
             int tot = 0;
 #pragma unroll
-            for (int k = 0; k < kPackBlock / 64; ++k) { word |= s_any[k] << (4 * k); tot += s_cnt[k]; }
+            for (int k = 0; k < kPackBlock / 64; ++k) { word |= s_any[i][k] << (4 * k); tot += s_cnt[i][k]; }
             coarse[w] = word;
-            if (g_first == g_last && tot) atomicAdd((unsigned long long *)(level_counts + g_first), (unsigned long long)tot);
+            const int64_t g_first = (w * 32) / per_grid, g_last = ((w * 32 + 31 < total ? w * 32 + 31 : total - 1)) / per_grid;
+            if (g_first == g_last && tot) {
+                if (acc_g != g_first && acc_cnt) atomicAdd((unsigned long long *)(level_counts + acc_g), (unsigned long long)acc_cnt);
+                if (acc_g != g_first) { acc_g = g_first; acc_cnt = 0; }
+                acc_cnt += tot;
+            }
         }
-        __syncthreads();
+        if (acc_cnt) atomicAdd((unsigned long long *)(level_counts + acc_g), (unsigned long long)acc_cnt);
     }
 }
 
-// one workgroup per coarse word, at most 16 per CU (the kernel loops beyond)
+// a workgroup per kPackWords coarse words
 inline unsigned pack_blocks(int64_t n_bricks) {
     const int64_t w = (n_bricks + 31) / 32;
-    return (unsigned)(w < 1 ? 1 : (w > (int64_t)kNumCU * 16 ? (int64_t)kNumCU * 16 : w));
+    return (unsigned)(w < 1 ? 1 : ceil_div(w, (int64_t)kPackWords));
 }
 
 // rank prefix over the coarse words (single workgroup; n_words is 1024 for 128^3)
