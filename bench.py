@@ -260,6 +260,16 @@ def main():
     line = None
     try:
         line = run(args)
+    except BaseException:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # a rank of a multi-rank job fails FAST: traceback, then the process ends without running the process group's teardown
+            # (a collective the other ranks will never join) — the launcher sees the exit code and ends the job.  Seen as a
+            # half-hour hang (gloo's timeout) when one rank of eight raised from sample_occgrid (profiles/r06_oversubscription.md)
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
+        raise
     finally:
         sys.stdout.flush()
         try:
@@ -346,10 +356,14 @@ def run(args):
             with socket.socket() as sock:
                 sock.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
+        # (collectives give up after five minutes, not after the backends' 10 / 30: a rank that fell out of step ends the job, it
+        #  does not park it)
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=300)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world_size)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world_size, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size, timeout=pg_timeout)
     fixed_rays = args.rays_per_iter // world_size if args.rays_per_iter > 0 else 0
 
     torch.manual_seed(42)
@@ -591,6 +605,10 @@ def run(args):
             exchange_modes[alt] = {"ms_per_step": r["elapsed"] / args.aux_steps * 1e3, "comm_ms_per_step": c["wait_ms"],
                                    "comm_window_ms_per_step": c["window_ms"], "steps": args.aux_steps}
         except Exception as e:      # noqa: BLE001
+            if world_size > 1:
+                # ONE rank's error (the other ranks keep stepping this leg's collectives): swallowing it here leaves the job
+                # waiting for this rank until the backend's timeout — half an hour with gloo.  The rank dies, the launcher ends the job.
+                raise
             exchange_modes[alt] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             optimizer.timing = False

@@ -142,14 +142,33 @@ print("ok", st)
 # eight-rank command every eighth workgroup of a count launch (one XCD's share) had left none of its stores in memory, the offsets
 # built from the garbage counts were wild and the run died with a GPU memory fault (profiles/r06_oversubscription.md: the captured
 # values; no kernel of the library or of torch is exempt, the faults were reported from both).  The library now raises on such totals
-# instead of storing through them.  A run that dies with one of THESE signatures is repeated once, loudly; anything else, or a second
-# failure, fails the test.
-_PLATFORM_SIGNATURES = ("HSA_STATUS_ERROR_MEMORY", "Memory access fault", "inconsistent totals", "illegal memory access")
+# instead of storing through them, and a rank of bench.py that raises ends its job at once (os._exit: no teardown collective the other
+# ranks never join).  A run that dies with one of THESE signatures — or has to be killed for saying nothing within its time limit — is
+# repeated once, loudly; anything else, or a second failure, fails the test.
+_PLATFORM_SIGNATURES = ("HSA_STATUS_ERROR_MEMORY", "Memory access fault", "inconsistent totals", "illegal memory access",
+                        "killed with its process group")
+
+
+def _run_group(cmd, timeout, env):
+    """subprocess.run whose command gets a process group of its own: a run that outlives `timeout` is killed WITH its ranks (the
+    launcher's children would otherwise stay on the GPU) and comes back with return code -9 and the note in its stderr"""
+    import signal
+    proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = proc.communicate()
+        err = (err or "") + f"\n[killed with its process group: no result after {timeout} s]\n"
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
 
 
 def _run_sharing_one_device(cmd_of_port, timeout, env):
     for attempt in (0, 1):
-        res = subprocess.run(cmd_of_port(_free_port()), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env)
+        res = _run_group(cmd_of_port(_free_port()), timeout, env)
         hit = [sig for sig in _PLATFORM_SIGNATURES if sig in res.stderr]
         if res.returncode == 0 or attempt == 1 or not hit:
             return res

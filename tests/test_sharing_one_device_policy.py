@@ -48,3 +48,30 @@ def test_other_failures_are_not_repeated(tmp_path):
     res = M._run_sharing_one_device(_cmd(str(tmp_path), FAIL_ONCE % (1, "AssertionError: replicas differ")), 60, dict(os.environ))
     assert res.returncode == 1
     assert open(os.path.join(str(tmp_path), "state")).read() == "1"
+
+
+def test_a_silent_run_is_killed_with_its_children(tmp_path):
+    script = """
+import os, subprocess, sys, time
+state = sys.argv[1]
+n = int(open(state).read()) if os.path.exists(state) else 0
+open(state, "w").write(str(n + 1))
+if n == 0:
+    child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+    open(state + ".child", "w").write(str(child.pid))
+    time.sleep(600)
+print("ok")
+"""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = M._run_sharing_one_device(_cmd(str(tmp_path), script), 5, dict(os.environ))
+    assert res.returncode == 0 and "ok" in res.stdout
+    pid = int(open(os.path.join(str(tmp_path), "state.child")).read())
+    import time
+    time.sleep(0.5)
+    try:                      # the grandchild went with its group (a zombie until reaped by init is fine: signal 0 to a dead pid raises)
+        os.kill(pid, 0)
+        alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+    except (ProcessLookupError, FileNotFoundError):
+        alive = False
+    assert not alive
