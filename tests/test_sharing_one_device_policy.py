@@ -75,3 +75,20 @@ print("ok")
     except (ProcessLookupError, FileNotFoundError):
         alive = False
     assert not alive
+
+
+def test_a_rank_of_a_multi_rank_bench_fails_fast(tmp_path):
+    """bench.py's main(): under WORLD_SIZE > 1 an exception out of run() ends the process at once with code 1 and the traceback on
+    stderr (no interpreter teardown, no process-group destructor waiting for ranks that will never come); a single process re-raises"""
+    import subprocess
+    code = ("import os, sys; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "def boom(args): raise RuntimeError('nerfacc_amd: sample_occgrid read back inconsistent totals (stand-in)')\n"
+            "bench.run = boom\n"
+            "import atexit; atexit.register(lambda: print('ATEXIT RAN', file=sys.stderr))\n"
+            "bench.main()\n") % M.ROOT
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    res = subprocess.run([sys.executable, "-c", code], cwd=M.ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert res.returncode == 1 and "inconsistent totals" in res.stderr and "ATEXIT RAN" not in res.stderr, res.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    res = subprocess.run([sys.executable, "-c", code], cwd=M.ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert res.returncode == 1 and "inconsistent totals" in res.stderr and "ATEXIT RAN" in res.stderr, res.stderr[-2000:]
